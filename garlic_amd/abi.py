@@ -1,0 +1,202 @@
+"""ctypes binding of libgarlic_hip.so (C ABI declared in include/garlic_hip.h).
+
+This is plumbing for the tests and bench.py; the product is the shared library.  There is no
+CPU fallback anywhere in this package: if the library is missing or no gfx950 device is
+present, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgarlic_hip.so")
+
+OK, ERR_INVALID, ERR_HIP, ERR_STATE, ERR_NOMEM = 0, 1, 2, 3, 4
+HOST, DEVICE = 0, 1
+MISSING = -9999.0
+
+# every symbol include/garlic_hip.h declares (tests check the library exports them all)
+SYMBOLS = [
+    "garlic_hip_abi_version", "garlic_hip_last_error", "garlic_hip_device_count",
+    "garlic_ctx_create", "garlic_ctx_destroy", "garlic_ctx_synchronize",
+    "garlic_panel_create", "garlic_panel_destroy", "garlic_panel_set_map",
+    "garlic_panel_set_freq", "garlic_panel_set_genotypes", "garlic_panel_set_gl",
+    "garlic_panel_set_ld", "garlic_lod_out_layout", "garlic_lod_windows",
+    "garlic_wlod_windows", "garlic_last_call_stats",
+]
+
+
+class CallStats(C.Structure):
+    _fields_ = [("n_segments", C.c_int64), ("n_runs", C.c_int64), ("n_chain_items", C.c_int64),
+                ("n_valid_windows", C.c_int64), ("n_missing", C.c_int64),
+                ("chain_kernel_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+class GarlicError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libgarlic_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+_vp = C.c_void_p
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_f64p = C.POINTER(C.c_double)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C garlic_amd/csrc` (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    L.garlic_hip_abi_version.restype = C.c_int
+    L.garlic_hip_last_error.restype = C.c_char_p
+    L.garlic_hip_device_count.argtypes = [_i32p]
+    L.garlic_ctx_create.argtypes = [C.c_int32, _vp, C.POINTER(_vp)]
+    L.garlic_ctx_destroy.argtypes = [_vp]
+    L.garlic_ctx_synchronize.argtypes = [_vp]
+    L.garlic_panel_create.argtypes = [_vp, C.c_int32, _i32p, C.c_int32, C.POINTER(_vp)]
+    L.garlic_panel_destroy.argtypes = [_vp]
+    L.garlic_panel_set_map.argtypes = [_vp, _i32p, _f64p, _i32p, _i32p]
+    L.garlic_panel_set_freq.argtypes = [_vp, _f64p]
+    L.garlic_panel_set_genotypes.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
+    L.garlic_panel_set_gl.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
+    L.garlic_panel_set_ld.argtypes = [_vp, C.c_int32, _vp, C.c_int32]
+    L.garlic_lod_out_layout.argtypes = [_vp, C.c_int32, C.c_int32, _i64p, _i64p, _i64p]
+    L.garlic_lod_windows.argtypes = [_vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_int32, _vp, C.c_int32]
+    L.garlic_wlod_windows.argtypes = [_vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_double, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32]
+    L.garlic_last_call_stats.argtypes = [_vp, C.POINTER(CallStats)]
+    for name in SYMBOLS:
+        f = getattr(L, name)
+        if f.restype is C.c_int and name not in ("garlic_hip_abi_version",):
+            f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != OK:
+        raise GarlicError(rc, lib().garlic_hip_last_error().decode())
+
+
+def _ptr(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+class Context:
+    """One device + one HIP stream (garlic_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self.handle = _vp()
+        check(lib().garlic_ctx_create(device, _vp(stream) if stream else None, C.byref(self.handle)))
+        self.device = device
+
+    def synchronize(self):
+        check(lib().garlic_ctx_synchronize(self.handle))
+
+    def close(self):
+        if self.handle:
+            lib().garlic_ctx_destroy(self.handle)
+            self.handle = _vp()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class Panel:
+    """Device-resident genotype panel (garlic_panel) for the individuals one context owns."""
+
+    def __init__(self, ctx, chr_nloci, nind):
+        self.ctx = ctx
+        self.chr_nloci = np.ascontiguousarray(chr_nloci, dtype=np.int32)
+        self.nchr = int(self.chr_nloci.shape[0])
+        self.nloci = int(self.chr_nloci.sum())
+        self.nind = int(nind)
+        self.handle = _vp()
+        check(lib().garlic_panel_create(ctx.handle, self.nchr, _ptr(self.chr_nloci, _i32p), self.nind,
+                                        C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            lib().garlic_panel_destroy(self.handle)
+            self.handle = _vp()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_map(self, pos, centro_start, centro_end, gpos=None):
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        cs = np.ascontiguousarray(centro_start, dtype=np.int32)
+        ce = np.ascontiguousarray(centro_end, dtype=np.int32)
+        assert pos.shape[0] == self.nloci and cs.shape[0] == self.nchr and ce.shape[0] == self.nchr
+        if gpos is not None:
+            gpos = np.ascontiguousarray(gpos, dtype=np.float64)
+            assert gpos.shape[0] == self.nloci
+        check(lib().garlic_panel_set_map(self.handle, _ptr(pos, _i32p), _ptr(gpos, _f64p),
+                                         _ptr(cs, _i32p), _ptr(ce, _i32p)))
+
+    def set_freq(self, freq):
+        freq = np.ascontiguousarray(freq, dtype=np.float64)
+        assert freq.shape[0] == self.nloci
+        check(lib().garlic_panel_set_freq(self.handle, _ptr(freq, _f64p)))
+
+    def set_genotypes(self, geno, locus_begin=0):
+        """geno: int16 numpy array [nloci_chunk][>= nind] (host)."""
+        geno = np.asarray(geno)
+        assert geno.dtype == np.int16 and geno.ndim == 2 and geno.strides[1] == 2
+        ld = geno.strides[0] // 2
+        check(lib().garlic_panel_set_genotypes(self.handle, _vp(geno.ctypes.data), ld, locus_begin,
+                                               geno.shape[0], HOST))
+
+    def set_genotypes_device(self, ptr, ld, locus_begin, locus_count):
+        """ptr: device address of int16 [locus_count][ld] (e.g. torch tensor .data_ptr())."""
+        check(lib().garlic_panel_set_genotypes(self.handle, _vp(ptr), ld, locus_begin, locus_count,
+                                               DEVICE))
+
+    def out_layout(self, pitch_align=1, nind_out=None):
+        nind_out = self.nind if nind_out is None else nind_out
+        base = np.empty(self.nchr, dtype=np.int64)
+        pitch = np.empty(self.nchr, dtype=np.int64)
+        total = C.c_int64()
+        check(lib().garlic_lod_out_layout(self.handle, pitch_align, nind_out, _ptr(base, _i64p),
+                                          _ptr(pitch, _i64p), C.byref(total)))
+        return base, pitch, total.value
+
+    def lod_windows(self, winsize, error, max_gap, ind_begin=0, ind_count=None, pitch_align=1,
+                    use_gl=False):
+        """Host-output convenience: returns a list of per-chromosome [ind_count][nloci_c] arrays."""
+        ind_count = self.nind - ind_begin if ind_count is None else ind_count
+        base, pitch, total = self.out_layout(pitch_align, ind_count)
+        out = np.empty(total, dtype=np.float64)
+        check(lib().garlic_lod_windows(self.handle, winsize, error, max_gap, int(use_gl), ind_begin,
+                                       ind_count, pitch_align, _vp(out.ctypes.data), HOST))
+        res = []
+        for c in range(self.nchr):
+            n = int(self.chr_nloci[c])
+            blk = out[base[c]: base[c] + ind_count * pitch[c]].reshape(ind_count, pitch[c])
+            res.append(blk[:, :n])
+        return res
+
+    def lod_windows_device(self, out_ptr, winsize, error, max_gap, ind_begin=0, ind_count=None,
+                           pitch_align=32, use_gl=False):
+        ind_count = self.nind - ind_begin if ind_count is None else ind_count
+        check(lib().garlic_lod_windows(self.handle, winsize, error, max_gap, int(use_gl), ind_begin,
+                                       ind_count, pitch_align, _vp(out_ptr), DEVICE))
+
+    def stats(self):
+        st = CallStats()
+        check(lib().garlic_last_call_stats(self.handle, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in CallStats._fields_}

@@ -1,0 +1,642 @@
+// libgarlic_hip.so -- C ABI (include/garlic_hip.h) over the gfx950 kernels in lod_kernels.hpp.
+//
+// Host side of the hot path: what calcLODWindows / calcLOD do around the inner loop
+// (src/garlic-roh.cpp:18-44, 279-309) -- per-chromosome bookkeeping, the per-SNP term table
+// (lod(), src/garlic-roh.cpp:355-386, evaluated once per SNP and genotype with the HOST libm so
+// that log10 is the very function the reference calls), segment -> run -> work-list planning --
+// and the launches.  There is no CPU fallback: without a HIP device every compute call fails.
+#include "../../include/garlic_hip.h"
+#include "lod_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace garlic;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? GARLIC_ERR_NOMEM : GARLIC_ERR_HIP,      \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,   \
+                        __LINE__);                                                          \
+    } while (0)
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return GARLIC_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)));
+        cap = n;
+        return GARLIC_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// lod(), src/garlic-roh.cpp:355-386.  Host arithmetic, host libm: identical to the reference.
+double host_lod(int genotype, double freq, double error)
+{
+    double autozygous = 1, nonAutozygous = 1;
+    if (freq == 0 || freq == 1) {
+    } else if (genotype == 0) {
+        nonAutozygous = (1 - freq) * (1 - freq);
+        autozygous = (1 - error) * (1 - freq) + error * nonAutozygous;
+    } else if (genotype == 1) {
+        nonAutozygous = 2 * (freq) * (1 - freq);
+        autozygous = error * nonAutozygous;
+    } else if (genotype == 2) {
+        nonAutozygous = (freq) * (freq);
+        autozygous = (1 - error) * (freq) + error * nonAutozygous;
+    }
+    return log10(autozygous / nonAutozygous);
+}
+
+template <class F> void parallel_for(int64_t n, int64_t grain, F f)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)std::min<int64_t>(std::min<unsigned>(hw ? hw : 1, 16), (n + grain - 1) / grain);
+    if (nt <= 1) { f(0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++)
+        th.emplace_back([=] { f(n * t / nt, n * (t + 1) / nt); });
+    for (auto &x : th) x.join();
+}
+
+} // namespace
+
+struct garlic_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;
+};
+
+struct garlic_panel {
+    garlic_ctx *ctx = nullptr;
+    int32_t nchr = 0;
+    int32_t nind = 0;
+    int64_t nloci = 0;
+    int64_t nind_pad = 0;
+    int64_t nwordrows = 0;
+    std::vector<int32_t> chr_nloci;
+    std::vector<int64_t> chr_off; // nchr + 1
+    // host copies of the small per-SNP inputs
+    std::vector<int32_t> pos, cs, ce;
+    std::vector<double> gpos, freq;
+    bool have_map = false, have_freq = false, have_geno = false, have_gpos = false;
+    // device state
+    DevBuf<uint32_t> d_packed;
+    DevBuf<int32_t> d_pos, d_cs, d_ce;
+    DevBuf<int64_t> d_chr_off;
+    DevBuf<double> d_tab;
+    bool tab_valid = false;
+    double tab_error = 0;
+    // segment boundaries (global loci, ascending), cached per max_gap
+    bool seg_valid = false;
+    int32_t seg_max_gap = 0;
+    std::vector<int64_t> boundaries;
+    DevBuf<int32_t> d_blk_counts, d_blk_offsets, d_total;
+    DevBuf<int64_t> d_boundaries;
+    // per-call scratch
+    DevBuf<ChainItem> d_items;
+    DevBuf<FillItem> d_fill;
+    DevBuf<ChrDev> d_chrs;
+    DevBuf<int16_t> d_stage16;
+    DevBuf<double> d_out;
+    garlic_call_stats stats{};
+};
+
+namespace {
+
+int set_device(garlic_ctx *ctx)
+{
+    HIP_TRY(hipSetDevice(ctx->device));
+    return GARLIC_OK;
+}
+
+// ---- segment boundaries on the device (integer scans), read back once per (map, max_gap)
+int ensure_segments(garlic_panel *p, int32_t max_gap)
+{
+    if (p->seg_valid && p->seg_max_gap == max_gap) return GARLIC_OK;
+    garlic_ctx *ctx = p->ctx;
+    const int64_t per_block = (int64_t)SEG_BLOCK * SEG_ITEMS;
+    const int nblocks = (int)((p->nloci + per_block - 1) / per_block);
+    int rc;
+    if ((rc = p->d_blk_counts.reserve(nblocks))) return rc;
+    if ((rc = p->d_blk_offsets.reserve(nblocks))) return rc;
+    if ((rc = p->d_total.reserve(1))) return rc;
+    hipLaunchKernelGGL(seg_count_kernel, dim3(nblocks), dim3(SEG_BLOCK), 0, ctx->stream, p->d_pos.p,
+                       p->d_chr_off.p, p->d_cs.p, p->d_ce.p, p->nchr, p->nloci, max_gap,
+                       p->d_blk_counts.p);
+    hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(WAVE), 0, ctx->stream, p->d_blk_counts.p,
+                       nblocks, p->d_blk_offsets.p, p->d_total.p);
+    int32_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, p->d_total.p, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (total < p->nchr) return fail(GARLIC_ERR_HIP, "segment scan returned %d boundaries", total);
+    if ((rc = p->d_boundaries.reserve((size_t)total))) return rc;
+    hipLaunchKernelGGL(seg_compact_kernel, dim3(nblocks), dim3(SEG_BLOCK), 0, ctx->stream,
+                       p->d_pos.p, p->d_chr_off.p, p->d_cs.p, p->d_ce.p, p->nchr, p->nloci, max_gap,
+                       p->d_blk_offsets.p, p->d_boundaries.p);
+    p->boundaries.resize((size_t)total);
+    HIP_TRY(hipMemcpyAsync(p->boundaries.data(), p->d_boundaries.p, sizeof(int64_t) * total,
+                           hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipGetLastError());
+    p->seg_valid = true;
+    p->seg_max_gap = max_gap;
+    return GARLIC_OK;
+}
+
+// ---- per-SNP term table {lod(0), lod(1), lod(2), lod(missing)=+0.0}, host libm
+int ensure_term_table(garlic_panel *p, double error)
+{
+    if (p->tab_valid && memcmp(&p->tab_error, &error, sizeof error) == 0) return GARLIC_OK;
+    const int64_t rows = GOFF + p->nloci + GPAD_BACK;
+    std::vector<double> tab((size_t)rows * 4, 0.0);
+    const double *freq = p->freq.data();
+    double *t = tab.data() + (size_t)GOFF * 4;
+    parallel_for(p->nloci, 1 << 16, [=](int64_t lo, int64_t hi) {
+        for (int64_t l = lo; l < hi; l++) {
+            t[l * 4 + 0] = host_lod(0, freq[l], error);
+            t[l * 4 + 1] = host_lod(1, freq[l], error);
+            t[l * 4 + 2] = host_lod(2, freq[l], error);
+            t[l * 4 + 3] = host_lod(-9, freq[l], error);
+        }
+    });
+    int rc;
+    if ((rc = p->d_tab.reserve((size_t)rows * 4))) return rc;
+    HIP_TRY(hipMemcpyAsync(p->d_tab.p, tab.data(), sizeof(double) * rows * 4, hipMemcpyHostToDevice,
+                           p->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    p->tab_valid = true;
+    p->tab_error = error;
+    return GARLIC_OK;
+}
+
+struct Layout {
+    std::vector<int64_t> base, pitch;
+    int64_t total = 0;
+};
+
+Layout make_layout(const garlic_panel *p, int32_t pitch_align, int32_t nind_out)
+{
+    Layout L;
+    L.base.resize(p->nchr);
+    L.pitch.resize(p->nchr);
+    int64_t off = 0;
+    const int64_t al = std::max(1, pitch_align);
+    for (int c = 0; c < p->nchr; c++) {
+        int64_t pitch = ((int64_t)p->chr_nloci[c] + al - 1) / al * al;
+        off = (off + al - 1) / al * al;
+        L.base[c] = off;
+        L.pitch[c] = pitch;
+        off += pitch * nind_out;
+    }
+    L.total = off;
+    return L;
+}
+
+struct Run {
+    int32_t chr, a, b;
+};
+
+// segments -> maximal runs of valid windows for one window size, and the MISSING stretches
+void plan_runs(const garlic_panel *p, int32_t W, std::vector<Run> &runs, std::vector<FillItem> &fill,
+               int64_t &n_valid)
+{
+    runs.clear();
+    fill.clear();
+    n_valid = 0;
+    size_t k = 0;
+    const size_t nb = p->boundaries.size();
+    for (int c = 0; c < p->nchr; c++) {
+        const int64_t c0 = p->chr_off[c], c1 = p->chr_off[c + 1];
+        int32_t cursor = 0; // first chromosome-local window not yet accounted for
+        while (k < nb && p->boundaries[k] < c1) {
+            const int64_t s = p->boundaries[k];
+            const int64_t e = (k + 1 < nb && p->boundaries[k + 1] < c1) ? p->boundaries[k + 1] : c1;
+            k++;
+            const int64_t len = e - s;
+            if (len >= W) {
+                Run r{c, (int32_t)(s - c0), (int32_t)(e - W - c0)};
+                if (r.a > cursor) fill.push_back(FillItem{c, cursor, r.a, 0});
+                runs.push_back(r);
+                n_valid += r.b - r.a + 1;
+                cursor = r.b + 1;
+            }
+        }
+        const int32_t n = (int32_t)(c1 - c0);
+        if (cursor < n) fill.push_back(FillItem{c, cursor, n, 0});
+    }
+}
+
+int launch_lod(garlic_panel *p, int32_t W, double error, int32_t max_gap, int32_t ind_begin,
+               int32_t ind_count, int32_t pitch_align, double *out, int32_t where)
+{
+    garlic_ctx *ctx = p->ctx;
+    int rc;
+    if ((rc = set_device(ctx))) return rc;
+    if (W <= 1) return fail(GARLIC_ERR_INVALID, "SNP window size must be > 1 (got %d)", W);
+    if (!p->have_map || !p->have_freq || !p->have_geno)
+        return fail(GARLIC_ERR_STATE, "panel needs map, freq and genotypes before computing LOD");
+    if (ind_begin < 0 || ind_count < 1 || (int64_t)ind_begin + ind_count > p->nind)
+        return fail(GARLIC_ERR_INVALID, "individual range [%d,+%d) outside panel of %d", ind_begin,
+                    ind_count, p->nind);
+    if (!out) return fail(GARLIC_ERR_INVALID, "out is NULL");
+    if (pitch_align < 1) return fail(GARLIC_ERR_INVALID, "pitch_align must be >= 1");
+
+    if ((rc = ensure_segments(p, max_gap))) return rc;
+    if ((rc = ensure_term_table(p, error))) return rc;
+
+    Layout L = make_layout(p, pitch_align, ind_count);
+    for (int c = 0; c < p->nchr; c++)
+        if (3 * L.pitch[c] * 8 + 512 >= (int64_t)1 << 32)
+            return fail(GARLIC_ERR_INVALID, "chromosome %d too long for 32-bit row offsets", c);
+
+    std::vector<Run> runs;
+    std::vector<FillItem> fill;
+    int64_t n_valid = 0;
+    plan_runs(p, W, runs, fill, n_valid);
+
+    // Work list: longest runs first (they bound the tail), each run's 64-individual blocks
+    // adjacent, and runs dealt round-robin to the 8 XCD groups (workgroups i and i+8 share an
+    // XCD's L2, so all waves of a run read its genotype rows and term table through one L2).
+    std::vector<int> order(runs.size());
+    for (size_t i = 0; i < runs.size(); i++) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+        return (runs[x].b - runs[x].a) > (runs[y].b - runs[y].a);
+    });
+    const int nblk = (ind_count + WAVE - 1) / WAVE;
+    constexpr int NXCD = 8;
+    std::vector<std::vector<ChainItem>> group(NXCD);
+    for (size_t i = 0; i < order.size(); i++) {
+        const Run &r = runs[order[i]];
+        // lightest group first keeps the 8 lists the same length
+        int g = 0;
+        for (int x = 1; x < NXCD; x++)
+            if (group[x].size() < group[g].size()) g = x;
+        for (int k = 0; k < nblk; k++) group[g].push_back(ChainItem{r.chr, r.a, r.b, k * WAVE});
+    }
+    size_t depth = 0;
+    for (auto &g : group) depth = std::max(depth, g.size());
+    std::vector<ChainItem> items(depth * NXCD, ChainItem{-1, 0, 0, 0});
+    for (int x = 0; x < NXCD; x++)
+        for (size_t i = 0; i < group[x].size(); i++) items[i * NXCD + x] = group[x][i];
+
+    std::vector<ChrDev> chrs(p->nchr);
+    for (int c = 0; c < p->nchr; c++)
+        chrs[c] = ChrDev{p->chr_off[c], L.base[c], L.pitch[c], p->chr_nloci[c], 0};
+
+    if ((rc = p->d_chrs.reserve(chrs.size()))) return rc;
+    if ((rc = p->d_items.reserve(std::max<size_t>(items.size(), 1)))) return rc;
+    if ((rc = p->d_fill.reserve(std::max<size_t>(fill.size(), 1)))) return rc;
+
+    double *d_out = out;
+    if (where == GARLIC_HOST) {
+        if ((rc = p->d_out.reserve((size_t)L.total))) return rc;
+        d_out = p->d_out.p;
+    }
+    const bool aligned16 = (pitch_align % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
+
+    HIP_TRY(hipEventRecord(ctx->ev_begin, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(p->d_chrs.p, chrs.data(), sizeof(ChrDev) * chrs.size(),
+                           hipMemcpyHostToDevice, ctx->stream));
+    if (!items.empty())
+        HIP_TRY(hipMemcpyAsync(p->d_items.p, items.data(), sizeof(ChainItem) * items.size(),
+                               hipMemcpyHostToDevice, ctx->stream));
+    if (!fill.empty())
+        HIP_TRY(hipMemcpyAsync(p->d_fill.p, fill.data(), sizeof(FillItem) * fill.size(),
+                               hipMemcpyHostToDevice, ctx->stream));
+    if (!fill.empty()) {
+        dim3 grid((unsigned)fill.size(), (unsigned)((ind_count + FILL_ROWS - 1) / FILL_ROWS));
+        hipLaunchKernelGGL(fill_missing_kernel, grid, dim3(256), 0, ctx->stream, p->d_fill.p,
+                           p->d_chrs.p, ind_count, d_out);
+    }
+    HIP_TRY(hipEventRecord(ctx->ev_k0, ctx->stream));
+    if (!items.empty()) {
+        ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p, p->d_chrs.p, d_out,
+                    p->nind_pad,   ind_begin,  ind_count,    W};
+        if (aligned16)
+            hipLaunchKernelGGL(lod_chain_kernel<true>, dim3((unsigned)items.size()), dim3(WAVE),
+                               0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(lod_chain_kernel<false>, dim3((unsigned)items.size()), dim3(WAVE),
+                               0, ctx->stream, a);
+    }
+    HIP_TRY(hipEventRecord(ctx->ev_k1, ctx->stream));
+    HIP_TRY(hipGetLastError());
+    if (where == GARLIC_HOST)
+        HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)L.total, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev_end, ctx->stream));
+    // The work list lives in host vectors and per-panel device scratch: finish before returning.
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+
+    garlic_call_stats &st = p->stats;
+    st.n_segments = (int64_t)p->boundaries.size();
+    st.n_runs = (int64_t)runs.size();
+    st.n_chain_items = (int64_t)runs.size() * nblk;
+    st.n_valid_windows = n_valid;
+    st.n_missing = p->nloci - n_valid;
+    (void)hipEventElapsedTime(&st.chain_kernel_ms, ctx->ev_k0, ctx->ev_k1);
+    (void)hipEventElapsedTime(&st.total_ms, ctx->ev_begin, ctx->ev_end);
+    return GARLIC_OK;
+}
+
+} // namespace
+
+// =================================================================================== C ABI
+extern "C" {
+
+int garlic_hip_abi_version(void) { return GARLIC_HIP_ABI_VERSION; }
+
+const char *garlic_hip_last_error(void) { return g_last_error.c_str(); }
+
+int garlic_hip_device_count(int32_t *count)
+{
+    if (!count) return fail(GARLIC_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(GARLIC_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return GARLIC_OK;
+}
+
+int garlic_ctx_create(int32_t device, void *hip_stream, garlic_ctx **out)
+{
+    if (!out) return fail(GARLIC_ERR_INVALID, "ctx out pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1)
+        return fail(GARLIC_ERR_HIP, "no HIP device available (%s); libgarlic_hip has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n)
+        return fail(GARLIC_ERR_INVALID, "device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(GARLIC_ERR_HIP, "device %d is %s; this library is built for gfx950 only", device,
+                    prop.gcnArchName);
+    garlic_ctx *ctx = new garlic_ctx;
+    ctx->device = device;
+    if (hip_stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    } else {
+        hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (se != hipSuccess) {
+            delete ctx;
+            return fail(GARLIC_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se));
+        }
+        ctx->own_stream = true;
+    }
+    hipEvent_t *evs[4] = {&ctx->ev_begin, &ctx->ev_k0, &ctx->ev_k1, &ctx->ev_end};
+    for (auto ev : evs) {
+        hipError_t ee = hipEventCreate(ev);
+        if (ee != hipSuccess) {
+            delete ctx;
+            return fail(GARLIC_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(ee));
+        }
+    }
+    *out = ctx;
+    return GARLIC_OK;
+}
+
+int garlic_ctx_destroy(garlic_ctx *ctx)
+{
+    if (!ctx) return GARLIC_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (hipEvent_t ev : {ctx->ev_begin, ctx->ev_k0, ctx->ev_k1, ctx->ev_end})
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return GARLIC_OK;
+}
+
+int garlic_ctx_synchronize(garlic_ctx *ctx)
+{
+    if (!ctx) return fail(GARLIC_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return GARLIC_OK;
+}
+
+int garlic_panel_create(garlic_ctx *ctx, int32_t nchr, const int32_t *chr_nloci, int32_t nind,
+                        garlic_panel **out)
+{
+    if (!out) return fail(GARLIC_ERR_INVALID, "panel out pointer is NULL");
+    *out = nullptr;
+    if (!ctx) return fail(GARLIC_ERR_INVALID, "ctx is NULL");
+    // initWinData refuses nind < 1 or nloci < 1 (src/garlic-data.cpp:1610-1620)
+    if (nchr < 1 || !chr_nloci || nind < 1)
+        return fail(GARLIC_ERR_INVALID, "need nchr >= 1, chr_nloci and nind >= 1");
+    int rc;
+    if ((rc = set_device(ctx))) return rc;
+    garlic_panel *p = new garlic_panel;
+    p->ctx = ctx;
+    p->nchr = nchr;
+    p->nind = nind;
+    p->chr_nloci.assign(chr_nloci, chr_nloci + nchr);
+    p->chr_off.resize(nchr + 1);
+    p->chr_off[0] = 0;
+    for (int c = 0; c < nchr; c++) {
+        if (chr_nloci[c] < 1) {
+            delete p;
+            return fail(GARLIC_ERR_INVALID, "chromosome %d has %d loci; must be positive", c,
+                        chr_nloci[c]);
+        }
+        p->chr_off[c + 1] = p->chr_off[c] + chr_nloci[c];
+    }
+    p->nloci = p->chr_off[nchr];
+    p->nind_pad = ((int64_t)nind + 63 + 63) / 64 * 64;
+    p->nwordrows = ((GOFF + p->nloci + GPAD_BACK) >> 4) + 2;
+    auto cleanup = [&](int code) { garlic_panel_destroy(p); return code; };
+    if ((rc = p->d_packed.reserve((size_t)(p->nwordrows * p->nind_pad)))) return cleanup(rc);
+    if ((rc = p->d_chr_off.reserve(nchr + 1))) return cleanup(rc);
+    // every 2-bit code starts out "missing" (3): pad rows/columns contribute +0.0 and are never stored
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, ctx->stream, p->d_packed.p,
+                       p->nwordrows * p->nind_pad, 0xFFFFFFFFu);
+    hipError_t e = hipMemcpyAsync(p->d_chr_off.p, p->chr_off.data(), sizeof(int64_t) * (nchr + 1),
+                                  hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess)
+        return cleanup(fail(GARLIC_ERR_HIP, "panel init: %s", hipGetErrorString(e)));
+    *out = p;
+    return GARLIC_OK;
+}
+
+int garlic_panel_destroy(garlic_panel *p)
+{
+    if (!p) return GARLIC_OK;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    p->d_packed.release(); p->d_pos.release(); p->d_cs.release(); p->d_ce.release();
+    p->d_chr_off.release(); p->d_tab.release(); p->d_blk_counts.release();
+    p->d_blk_offsets.release(); p->d_total.release(); p->d_boundaries.release();
+    p->d_items.release(); p->d_fill.release(); p->d_chrs.release(); p->d_stage16.release();
+    p->d_out.release();
+    delete p;
+    return GARLIC_OK;
+}
+
+int garlic_panel_set_map(garlic_panel *p, const int32_t *pos, const double *gpos,
+                         const int32_t *centro_start, const int32_t *centro_end)
+{
+    if (!p || !pos || !centro_start || !centro_end)
+        return fail(GARLIC_ERR_INVALID, "panel, pos, centro_start and centro_end are required");
+    int rc;
+    if ((rc = set_device(p->ctx))) return rc;
+    p->pos.assign(pos, pos + p->nloci);
+    p->cs.assign(centro_start, centro_start + p->nchr);
+    p->ce.assign(centro_end, centro_end + p->nchr);
+    p->have_gpos = gpos != nullptr;
+    if (gpos) p->gpos.assign(gpos, gpos + p->nloci);
+    if ((rc = p->d_pos.reserve((size_t)p->nloci))) return rc;
+    if ((rc = p->d_cs.reserve(p->nchr))) return rc;
+    if ((rc = p->d_ce.reserve(p->nchr))) return rc;
+    hipStream_t s = p->ctx->stream;
+    HIP_TRY(hipMemcpyAsync(p->d_pos.p, pos, sizeof(int32_t) * p->nloci, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(p->d_cs.p, centro_start, sizeof(int32_t) * p->nchr, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(p->d_ce.p, centro_end, sizeof(int32_t) * p->nchr, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    p->have_map = true;
+    p->seg_valid = false;
+    return GARLIC_OK;
+}
+
+int garlic_panel_set_freq(garlic_panel *p, const double *freq)
+{
+    if (!p || !freq) return fail(GARLIC_ERR_INVALID, "panel and freq are required");
+    p->freq.assign(freq, freq + p->nloci);
+    p->have_freq = true;
+    p->tab_valid = false;
+    return GARLIC_OK;
+}
+
+int garlic_panel_set_genotypes(garlic_panel *p, const int16_t *geno, int64_t ld, int64_t locus_begin,
+                               int64_t locus_count, int32_t where)
+{
+    if (!p || !geno) return fail(GARLIC_ERR_INVALID, "panel and geno are required");
+    if (ld < p->nind) return fail(GARLIC_ERR_INVALID, "ld %lld < nind %d", (long long)ld, p->nind);
+    if (locus_begin < 0 || locus_count < 1 || locus_begin + locus_count > p->nloci)
+        return fail(GARLIC_ERR_INVALID, "locus range [%lld,+%lld) outside panel of %lld loci",
+                    (long long)locus_begin, (long long)locus_count, (long long)p->nloci);
+    int rc;
+    if ((rc = set_device(p->ctx))) return rc;
+    hipStream_t s = p->ctx->stream;
+    // host data goes through a bounded staging buffer, a slab of SNP rows at a time
+    const int64_t slab_rows = (where == GARLIC_HOST)
+                                  ? std::max<int64_t>(16, ((int64_t)256 << 20) / (2 * ld))
+                                  : locus_count;
+    for (int64_t done = 0; done < locus_count; done += slab_rows) {
+        const int64_t rows = std::min(slab_rows, locus_count - done);
+        const int64_t l0 = locus_begin + done;
+        const int16_t *src = geno + done * ld;
+        if (where == GARLIC_HOST) {
+            if ((rc = p->d_stage16.reserve((size_t)(rows * ld)))) return rc;
+            HIP_TRY(hipMemcpyAsync(p->d_stage16.p, src, sizeof(int16_t) * rows * ld,
+                                   hipMemcpyHostToDevice, s));
+            src = p->d_stage16.p;
+        }
+        const int64_t w_lo = (GOFF + l0) >> 4;
+        const int64_t w_hi = ((GOFF + l0 + rows - 1) >> 4) + 1;
+        dim3 block(256);
+        for (int64_t w = w_lo; w < w_hi; w += 65535) {
+            const int64_t wn = std::min<int64_t>(65535, w_hi - w);
+            dim3 grid((unsigned)((p->nind_pad + 255) / 256), (unsigned)wn);
+            hipLaunchKernelGGL(pack_genotypes_kernel, grid, block, 0, s, src, ld, l0, rows, p->nind,
+                               p->nind_pad, p->d_packed.p, w, w + wn);
+        }
+        if (where == GARLIC_HOST) HIP_TRY(hipStreamSynchronize(s)); // staging buffer is reused
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    p->have_geno = true;
+    return GARLIC_OK;
+}
+
+int garlic_panel_set_gl(garlic_panel *, const double *, int64_t, int64_t, int64_t, int32_t)
+{
+    return fail(GARLIC_ERR_STATE, "TGLS per-genotype likelihoods are not implemented in this build");
+}
+
+int garlic_panel_set_ld(garlic_panel *, int32_t, const double *, int32_t)
+{
+    return fail(GARLIC_ERR_STATE, "LD weights (wLOD) are not implemented in this build");
+}
+
+int garlic_lod_out_layout(garlic_panel *p, int32_t pitch_align, int32_t nind_out, int64_t *chr_base,
+                          int64_t *chr_pitch, int64_t *total)
+{
+    if (!p) return fail(GARLIC_ERR_INVALID, "panel is NULL");
+    if (pitch_align < 1 || nind_out < 1)
+        return fail(GARLIC_ERR_INVALID, "pitch_align and nind_out must be >= 1");
+    Layout L = make_layout(p, pitch_align, nind_out);
+    for (int c = 0; c < p->nchr; c++) {
+        if (chr_base) chr_base[c] = L.base[c];
+        if (chr_pitch) chr_pitch[c] = L.pitch[c];
+    }
+    if (total) *total = L.total;
+    return GARLIC_OK;
+}
+
+int garlic_lod_windows(garlic_panel *p, int32_t winsize, double error, int32_t max_gap,
+                       int32_t use_gl, int32_t ind_begin, int32_t ind_count, int32_t pitch_align,
+                       double *out, int32_t where)
+{
+    if (!p) return fail(GARLIC_ERR_INVALID, "panel is NULL");
+    if (use_gl) return fail(GARLIC_ERR_STATE, "TGLS per-genotype likelihoods are not implemented in this build");
+    return launch_lod(p, winsize, error, max_gap, ind_begin, ind_count, pitch_align, out, where);
+}
+
+int garlic_wlod_windows(garlic_panel *, int32_t, double, int32_t, int32_t, int32_t, double, int32_t,
+                        int32_t, int32_t, double *, int32_t)
+{
+    return fail(GARLIC_ERR_STATE, "wLOD is not implemented in this build");
+}
+
+int garlic_last_call_stats(garlic_panel *p, garlic_call_stats *stats)
+{
+    if (!p || !stats) return fail(GARLIC_ERR_INVALID, "panel and stats are required");
+    *stats = p->stats;
+    return GARLIC_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,438 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels for GARLIC's Phase-I window LOD scores.
+//
+// What the reference computes (src/garlic-roh.cpp:18-132, restated in SURVEY.md 8(a')):
+//   * a pair of neighbouring SNPs (k-1,k) "breaks" when it is wider than MAX_GAP or touches the
+//     centromere (garlic-roh.cpp:60-61,82-83,109-110); SNPs between two breaks form a *segment*;
+//   * inside a segment [p,q] the windows starting at p .. q-W+1 are scored, every other window
+//     of the chromosome is MISSING (-9999);
+//   * per individual the first window of a segment is the left-to-right sum of its W per-SNP
+//     terms, every following window is  (previous - leaving term) + entering term  -- two
+//     separately rounded FP64 operations (garlic-roh.cpp:92-100).  That rolling sum is order
+//     dependent, so bit-identity forces a sequential replay per (individual, segment): the SNP
+//     axis is NOT scanned in parallel.  Parallelism = individuals x segments.
+//
+// Mapping onto the machine:
+//   lane  = one individual, wavefront = 64 consecutive individuals of one segment (one workgroup
+//           = one wave, so waves never wait on each other);
+//   HBM   -> 2-bit genotypes, 16 SNPs per 32-bit word, individual-minor: a wave reads one
+//           256-byte row per 16 SNPs (coalesced), twice (entering and leaving SNP streams);
+//   LDS   <- the per-SNP term table {lod(g=0), lod(1), lod(2), 0.0} (host libm log10, see
+//           garlic_hip.hip) for the 32 SNPs of the current tile, for both streams; a lane picks
+//           its term with one ds_read_b64 at  row*32 + genotype*8;
+//   LDS   <- a 64 x 32 transpose tile: lanes write their score column-wise, the wave reads it back
+//           row-wise so every global store instruction writes 4 individuals x 256 contiguous
+//           bytes of the individual-major output (WinData layout, src/garlic-data.h:83);
+//   no MFMA: there is no contraction here, only a dependent add chain and byte movement.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace garlic {
+
+constexpr int WAVE = 64;
+constexpr int TILE = 32;          // window starts per tile (= 256 B of one output row)
+constexpr int TPITCH = 34;        // doubles per LDS tile row: 272 B keeps ds_read_b128 16-B aligned
+constexpr int GOFF = 32;          // pad SNP rows in front of the packed genotypes / term table
+constexpr int GPAD_BACK = 96;     // pad SNP rows behind (prefetch over-reads stay in bounds)
+constexpr double MISSING_D = -9999.0;
+
+struct ChrDev {
+    int64_t loc_base;   // global locus index of the chromosome's first SNP
+    int64_t out_base;   // offset (doubles) of the chromosome block in the output
+    int64_t out_pitch;  // row pitch (doubles)
+    int32_t nloci;
+    int32_t pad;
+};
+
+struct ChainItem {   // one wavefront of work: a run of valid windows x 64 individuals
+    int32_t chr;     // -1: padding item
+    int32_t a;       // first valid window start (chromosome-local)
+    int32_t b;       // last valid window start
+    int32_t ind0;    // first individual (relative to the call's ind_begin)
+};
+
+struct FillItem {    // a stretch of MISSING windows [lo, hi) of one chromosome
+    int32_t chr;
+    int32_t lo;
+    int32_t hi;
+    int32_t pad;
+};
+
+// ------------------------------------------------------------------------------------------
+// Genotype packing: int16 [locus][ind] (HapData::data, src/garlic-data.h:35) -> 2-bit codes.
+// code 0/1/2 = genotype, 3 = anything else (missing, -9): lod() returns log10(1/1) = +0.0 for
+// those (garlic-roh.cpp:379-383), which is entry 3 of the term table.
+// One thread = one (word row, individual); consecutive lanes = consecutive individuals, so both
+// the 16 strided reads and the write are coalesced.
+__global__ void pack_genotypes_kernel(const int16_t *__restrict__ geno, int64_t ld,
+                                      int64_t locus_begin, int64_t locus_count, int32_t nind,
+                                      int64_t nind_pad, uint32_t *__restrict__ packed,
+                                      int64_t word_lo, int64_t word_hi)
+{
+    int64_t ind = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t w = word_lo + blockIdx.y;
+    if (ind >= nind_pad || w >= word_hi) return;
+    uint32_t *dst = packed + w * nind_pad + ind;
+    // SNPs of this word that the caller did not supply keep their previous bits
+    uint32_t word = *dst;
+    if (ind >= nind) { *dst = 0xFFFFFFFFu; return; }
+    int64_t g0 = w * 16 - GOFF; // global locus of bit position 0
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        int64_t l = g0 + q - locus_begin;
+        if (l >= 0 && l < locus_count) {
+            int v = geno[l * ld + ind];
+            uint32_t code = (v == 0) ? 0u : (v == 1) ? 1u : (v == 2) ? 2u : 3u;
+            word = (word & ~(3u << (2 * q))) | (code << (2 * q));
+        }
+    }
+    *dst = word;
+}
+
+__global__ void fill_u32_kernel(uint32_t *p, int64_t n, uint32_t v)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Segment boundaries: integer work, done with wavefront scans.
+// boundary(G) = G is the first SNP of its chromosome, or the pair (G-1,G) breaks a window.
+__device__ __forceinline__ int in_gap(int qs, int qe, int ts, int te)
+{   // garlic-roh.cpp:11-16
+    return (ts <= qs && te >= qs) || (ts <= qe && te >= qe) || (ts >= qs && te <= qe);
+}
+
+__device__ __forceinline__ int find_chr(const int64_t *chr_off, int nchr, int64_t G)
+{   // largest c with chr_off[c] <= G
+    int lo = 0, hi = nchr - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (chr_off[mid] <= G) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int boundary_flag(const int32_t *pos, const int64_t *chr_off,
+                                             const int32_t *cs, const int32_t *ce, int nchr,
+                                             int64_t nloci, int32_t max_gap, int64_t G)
+{
+    if (G >= nloci) return 0;
+    int c = find_chr(chr_off, nchr, G);
+    if (G == chr_off[c]) return 1;
+    int p0 = pos[G - 1], p1 = pos[G];
+    return (p1 - p0 > max_gap) || in_gap(p0, p1, cs[c], ce[c]);
+}
+
+// inclusive prefix sum across the 64 lanes of a wavefront (__shfl_up ladder, no LDS)
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+    int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        int n = __shfl_up(v, d, WAVE);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+constexpr int SEG_BLOCK = 256;
+constexpr int SEG_ITEMS = 8; // SNPs per thread -> 2048 SNPs per workgroup
+
+__global__ void __launch_bounds__(SEG_BLOCK)
+seg_count_kernel(const int32_t *pos, const int64_t *chr_off, const int32_t *cs, const int32_t *ce,
+                 int nchr, int64_t nloci, int32_t max_gap, int32_t *block_counts)
+{
+    __shared__ int wsum[SEG_BLOCK / WAVE];
+    int64_t base = (int64_t)blockIdx.x * SEG_BLOCK * SEG_ITEMS;
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < SEG_ITEMS; k++)
+        cnt += boundary_flag(pos, chr_off, cs, ce, nchr, nloci, max_gap,
+                             base + (int64_t)k * SEG_BLOCK + threadIdx.x);
+    int inc = wave_inclusive_scan(cnt);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < SEG_BLOCK / WAVE; w++) t += wsum[w];
+        block_counts[blockIdx.x] = t;
+    }
+}
+
+// single wavefront: exclusive scan of the per-workgroup counts (nblocks is small)
+__global__ void __launch_bounds__(WAVE)
+seg_scan_kernel(const int32_t *block_counts, int nblocks, int32_t *block_offsets, int32_t *total)
+{
+    int carry = 0;
+    for (int base = 0; base < nblocks; base += WAVE) {
+        int i = base + threadIdx.x;
+        int v = (i < nblocks) ? block_counts[i] : 0;
+        int inc = wave_inclusive_scan(v);
+        if (i < nblocks) block_offsets[i] = carry + inc - v;
+        carry += __shfl(inc, WAVE - 1, WAVE);
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+// ordered compaction: boundaries[] receives the global loci of all segment starts, ascending
+__global__ void __launch_bounds__(SEG_BLOCK)
+seg_compact_kernel(const int32_t *pos, const int64_t *chr_off, const int32_t *cs,
+                   const int32_t *ce, int nchr, int64_t nloci, int32_t max_gap,
+                   const int32_t *block_offsets, int64_t *boundaries)
+{
+    __shared__ int wsum[SEG_BLOCK / WAVE];
+    __shared__ int running;
+    if (threadIdx.x == 0) running = block_offsets[blockIdx.x];
+    int64_t base = (int64_t)blockIdx.x * SEG_BLOCK * SEG_ITEMS;
+    __syncthreads();
+    for (int k = 0; k < SEG_ITEMS; k++) {
+        int64_t G = base + (int64_t)k * SEG_BLOCK + threadIdx.x;
+        int f = boundary_flag(pos, chr_off, cs, ce, nchr, nloci, max_gap, G);
+        int inc = wave_inclusive_scan(f);
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); w++) woff += wsum[w];
+        int start = running;
+        if (f) boundaries[start + woff + inc - 1] = G;
+        __syncthreads();
+        if (threadIdx.x == SEG_BLOCK - 1) running = start + woff + inc;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// MISSING stretches (the reference pre-fills WinData with -9999, src/garlic-data.cpp:1633; here
+// every output element is written exactly once, so no memset pass over the whole output).
+// grid.x = fill item, grid.y = group of rows; lanes run along the SNP axis (contiguous bytes).
+constexpr int FILL_ROWS = 16;
+__global__ void __launch_bounds__(256)
+fill_missing_kernel(const FillItem *items, const ChrDev *chrs, int32_t nind, double *out)
+{
+    FillItem it = items[blockIdx.x];
+    ChrDev c = chrs[it.chr];
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int row0 = blockIdx.y * FILL_ROWS;
+    for (int r = row0 + wave; r < row0 + FILL_ROWS && r < nind; r += 4) {
+        double *row = out + c.out_base + (int64_t)r * c.out_pitch;
+        for (int l = it.lo + lane; l < it.hi; l += WAVE) row[l] = MISSING_D;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The chain kernel.
+struct ChainArgs {
+    const uint32_t *packed;   // [word row][nind_pad], word row w holds global loci 16w-GOFF ..
+    const double *tab;        // [GOFF + nloci + pad][4] per-SNP terms
+    const ChainItem *items;
+    const ChrDev *chrs;
+    double *out;
+    int64_t nind_pad;
+    int32_t ind_begin;        // first individual of this call inside the panel shard
+    int32_t ind_count;        // rows in the output
+    int32_t winsize;
+};
+
+// LDS carve-up (bytes), one wave per workgroup
+constexpr uint32_t LDS_TAB_LEAD = 0;                       // 32 rows x 32 B
+constexpr uint32_t LDS_TAB_TRAIL = 1024;                   // 32 rows x 32 B
+constexpr uint32_t LDS_TILE = 2048;                        // 64 x TPITCH doubles
+constexpr uint32_t LDS_BYTES = LDS_TILE + WAVE * TPITCH * 8;
+
+// Everything a tile needs from global memory: 3 genotype words per stream (48 SNPs, of which the
+// 32 starting at bit offset `shift` are used) and 16 B of the 32-row term chunk per lane.
+struct TileIn {
+    uint32_t lc, l1, l2;   // entering-SNP stream
+    uint32_t tc, t1, t2;   // leaving-SNP stream
+    double2 tabl, tabt;
+};
+
+struct Streams {
+    const uint32_t *plead, *ptrail;   // this lane's column, word row of the current tile
+    const double2 *tlead, *ttrail;    // this lane's 16 B of the current tile's term rows
+    int64_t npad;
+    int sh_lead, sh_trail;
+};
+
+__device__ __forceinline__ void load_tile_full(const Streams &st, TileIn &in)
+{
+    in.lc = st.plead[0]; in.l1 = st.plead[st.npad]; in.l2 = st.plead[2 * st.npad];
+    in.tc = st.ptrail[0]; in.t1 = st.ptrail[st.npad]; in.t2 = st.ptrail[2 * st.npad];
+    in.tabl = st.tlead[0]; in.tabt = st.ttrail[0];
+}
+
+// next tile = two genotype words and 32 term rows further along both streams
+__device__ __forceinline__ void advance(Streams &st)
+{
+    st.plead += 2 * st.npad; st.ptrail += 2 * st.npad; st.tlead += 64; st.ttrail += 64;
+}
+
+// The 32 dependent steps of one tile.  EDGE: tile straddles the run's first or last window.
+template <bool EDGE>
+__device__ __forceinline__ void tile_steps(unsigned char *smem, double &acc, const TileIn &in,
+                                           const Streams &st, int s0, int a, int b, int lane)
+{
+    // stage this tile's term rows (LDS ops of one wave execute in program order, so the reads
+    // of the previous tile are already done)
+    *reinterpret_cast<double2 *>(smem + LDS_TAB_LEAD + lane * 16) = in.tabl;
+    *reinterpret_cast<double2 *>(smem + LDS_TAB_TRAIL + lane * 16) = in.tabt;
+    const uint32_t lead_lo = __builtin_amdgcn_alignbit(in.l1, in.lc, st.sh_lead);
+    const uint32_t lead_hi = __builtin_amdgcn_alignbit(in.l2, in.l1, st.sh_lead);
+    const uint32_t trail_lo = __builtin_amdgcn_alignbit(in.t1, in.tc, st.sh_trail);
+    const uint32_t trail_hi = __builtin_amdgcn_alignbit(in.t2, in.t1, st.sh_trail);
+    const uint32_t tile_lane = LDS_TILE + (uint32_t)lane * (TPITCH * 8);
+#pragma unroll
+    for (int j = 0; j < TILE; j++) {
+        const uint32_t lw = (j < 16) ? lead_lo : lead_hi;
+        const uint32_t tw = (j < 16) ? trail_lo : trail_hi;
+        const uint32_t g1 = (lw >> (2 * (j & 15))) & 3u;
+        const uint32_t g0 = (tw >> (2 * (j & 15))) & 3u;
+        double t_in = *reinterpret_cast<const double *>(smem + LDS_TAB_LEAD + j * 32 + g1 * 8);
+        double t_out = *reinterpret_cast<const double *>(smem + LDS_TAB_TRAIL + j * 32 + g0 * 8);
+        if (EDGE) {
+            const int s = s0 + j;
+            // the first window of a run is a plain sum (no leaving term); steps outside [a,b]
+            // leave the accumulator untouched (x - 0.0 + 0.0 == x for every x that can occur:
+            // the accumulator starts at +0.0 and can never become -0.0)
+            if (!(s > a && s <= b)) t_out = 0.0;
+            if (!(s >= a && s <= b)) t_in = 0.0;
+        }
+        acc = (acc - t_out) + t_in; // two roundings, as garlic-roh.cpp:98-100
+        *reinterpret_cast<double *>(smem + tile_lane + j * 8) = acc;
+    }
+}
+
+// Transposed write-out of a tile: store q covers individuals 4q..4q+3, 16 lanes x 16 B = 256
+// contiguous bytes of each row.  Rows past the shard's last individual are clamped onto the last
+// valid row: those lanes re-store that row's own values (same address, same data), which keeps
+// the stores unconditional -- an exec-masked store sits behind a skip branch, and a branchy
+// tile makes the compiler's counted vmcnt at the loop head collapse to vmcnt(0).
+template <bool EDGE, bool ALIGNED16>
+__device__ __forceinline__ void tile_store(const unsigned char *smem, int s0, int a, int b, int lane,
+                                           int rows_valid, double *out_tile, int64_t pitch)
+{
+    const int rsub = lane >> 4, csub = lane & 15;
+#pragma unroll
+    for (int q = 0; q < WAVE / 4; q++) {
+        const int r = min(4 * q + rsub, rows_valid - 1);
+        const double2 v = *reinterpret_cast<const double2 *>(
+            smem + LDS_TILE + (uint32_t)r * (TPITCH * 8) + csub * 16);
+        double *dst = out_tile + (int64_t)r * pitch + 2 * csub;
+        if (EDGE) {
+            const int s = s0 + 2 * csub;
+            if (s >= a && s <= b) dst[0] = v.x;
+            if (s + 1 >= a && s + 1 <= b) dst[1] = v.y;
+        } else if (!ALIGNED16) {
+            dst[0] = v.x;
+            dst[1] = v.y;
+        } else {
+            *reinterpret_cast<double2 *>(dst) = v;
+        }
+    }
+}
+
+template <bool ALIGNED16>
+__global__ void __launch_bounds__(WAVE)
+lod_chain_kernel(ChainArgs p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    const ChainItem it = p.items[blockIdx.x];
+    if (it.chr < 0) return;
+    const ChrDev c = p.chrs[it.chr];
+    const int lane = threadIdx.x;
+    const int W = p.winsize;
+    const int a = it.a, b = it.b;
+    const int rows_valid = min(WAVE, p.ind_count - it.ind0);
+    // lanes past the shard read the padded columns (code 3 -> term 0.0) and never store
+    const int64_t col = (int64_t)p.ind_begin + it.ind0 + lane;
+    const uint32_t *gcol = p.packed + col;
+    const int64_t npad = p.nind_pad;
+    const int64_t Gbase = c.loc_base + GOFF; // global (padded) index of chromosome-local locus 0
+
+    // ---- first window of the run: sum of W terms left to right (garlic-roh.cpp:57-71); the
+    //      first W-1 of them here, the W-th enters in the first tile below.
+    double acc = 0.0;
+    {
+        int l = a;
+        const int lend = a + W - 1;
+        while (l < lend) {
+            const int64_t G = Gbase + l;
+            const int off = (int)(G & 15);
+            const uint32_t word = gcol[(G >> 4) * npad];
+            const int n = min(16 - off, lend - l);
+            double t[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int qq = min(q, n - 1);
+                const uint32_t g = (word >> (2 * (off + qq))) & 3u;
+                t[q] = p.tab[(G + qq) * 4 + g];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc += (q < n) ? t[q] : 0.0;
+            l += n;
+        }
+    }
+
+    // ---- tiles of 32 window starts, aligned to 32 inside the chromosome
+    int s0 = a & ~(TILE - 1);
+    Streams st;
+    {
+        // entering-SNP stream starts at local locus s0+W-1, leaving-SNP stream at s0-1
+        const int64_t Glead = Gbase + s0 + W - 1;
+        const int64_t Gtrail = Gbase + s0 - 1;
+        st.npad = npad;
+        st.sh_lead = 2 * (int)(Glead & 15);
+        st.sh_trail = 2 * (int)(Gtrail & 15);
+        st.plead = gcol + (Glead >> 4) * npad;
+        st.ptrail = gcol + (Gtrail >> 4) * npad;
+        st.tlead = reinterpret_cast<const double2 *>(p.tab + Glead * 4) + lane;
+        st.ttrail = reinterpret_cast<const double2 *>(p.tab + Gtrail * 4) + lane;
+    }
+    double *out_tile = p.out + c.out_base + (int64_t)it.ind0 * c.out_pitch + s0;
+    const int64_t pitch = c.out_pitch;
+    TileIn in;
+
+    // head tile: always the masked variant -- the run's first window has no leaving term even
+    // when the run starts exactly on a tile boundary
+    {
+        load_tile_full(st, in);
+        tile_steps<true>(smem, acc, in, st, s0, a, b, lane);
+        tile_store<true, ALIGNED16>(smem, s0, a, b, lane, rows_valid, out_tile, pitch);
+        advance(st);
+        s0 += TILE;
+        out_tile += TILE;
+    }
+
+    // full tiles: loads for tile k+1 are issued before the 16 stores of tile k, so the wait at
+    // the top of the loop is a counted vmcnt that leaves those stores in flight.
+    if (s0 + TILE - 1 <= b) {
+        load_tile_full(st, in);
+        // make the loop start with nothing pending on these registers (otherwise the merged
+        // wait state at the loop header degenerates to vmcnt(0) and drains the stores)
+        asm volatile("" : "+v"(in.lc), "+v"(in.l1), "+v"(in.l2), "+v"(in.tc), "+v"(in.t1), "+v"(in.t2));
+        asm volatile("" : "+v"(in.tabl.x), "+v"(in.tabl.y), "+v"(in.tabt.x), "+v"(in.tabt.y));
+        do {
+            TileIn cur = in;
+            advance(st);
+            in.lc = cur.l2; in.tc = cur.t2;
+            in.l1 = st.plead[npad]; in.l2 = st.plead[2 * npad];
+            in.t1 = st.ptrail[npad]; in.t2 = st.ptrail[2 * npad];
+            in.tabl = st.tlead[0]; in.tabt = st.ttrail[0];
+            tile_steps<false>(smem, acc, cur, st, s0, a, b, lane);
+            tile_store<false, ALIGNED16>(smem, s0, a, b, lane, rows_valid, out_tile, pitch);
+            s0 += TILE;
+            out_tile += TILE;
+        } while (s0 + TILE - 1 <= b);
+    }
+
+    // tail tile
+    if (s0 <= b) {
+        load_tile_full(st, in);
+        tile_steps<true>(smem, acc, in, st, s0, a, b, lane);
+        tile_store<true, ALIGNED16>(smem, s0, a, b, lane, rows_valid, out_tile, pitch);
+    }
+}
+
+} // namespace garlic

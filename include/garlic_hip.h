@@ -1,0 +1,136 @@
+/*
+ * garlic_hip.h -- C ABI of libgarlic_hip.so: GARLIC Phase-I window LOD scores on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the one hot path this project replaces.  The reference
+ * (szpiech/garlic v1.1.6a) has no FFI layer; the boundary is the pair of C++ entry points
+ *
+ *     calcLODWindows   src/garlic-roh.h:96-102   (body src/garlic-roh.cpp:279-309, calcLOD :18-132)
+ *     calcwLODWindows  src/garlic-roh.h:104-112  (body src/garlic-roh.cpp:311-347, calcwLOD :144-277)
+ *
+ * and the structs they borrow (src/garlic-data.h:32-108).  Every function below takes plain
+ * pointers and sizes; the C++ adapter in garlic_amd/host mirrors the reference signatures on top
+ * (INTEGRATION.md shows the few lines a GARLIC maintainer would add).
+ *
+ * Conventions
+ *   - Every call returns GARLIC_OK (0) or a GARLIC_ERR_* code; garlic_hip_last_error() gives the
+ *     text for the calling thread.  The reference throws `int 0` (src/garlic-data.cpp:1619); the
+ *     adapter converts non-zero to `throw 0`.
+ *   - `where` says whether a caller buffer is host (GARLIC_HOST) or device (GARLIC_DEVICE) memory.
+ *   - Loci of all chromosomes are concatenated in file order ("global locus index"); chromosome c
+ *     owns [chr_off[c], chr_off[c+1]).
+ *   - Genotypes are the reference's codes (src/garlic-data.cpp:109-129): 0,1,2 = copies of the
+ *     counted allele, anything else (-9) = missing.
+ *   - LOD output is individual-major like WinData::data (src/garlic-data.h:83): element
+ *     (chr c, ind i, locus l) lives at  chr_base[c] + i*chr_pitch[c] + l  (in doubles), see
+ *     garlic_lod_out_layout().  Windows that hold no score are exactly -9999.0
+ *     (MISSING, src/garlic-data.h:24); every element is written by the call, no pre-fill needed.
+ *   - Results are bit-identical to the reference's doubles on the same inputs and host libm.
+ *   - A context is bound to one device and one HIP stream; calls on one context must not overlap
+ *     in time, different contexts are independent (one per GPU for individual sharding).
+ */
+#ifndef GARLIC_HIP_H
+#define GARLIC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GARLIC_HIP_ABI_VERSION 1
+
+#define GARLIC_OK 0
+#define GARLIC_ERR_INVALID 1  /* bad argument (e.g. winsize <= 1: src/garlic-cli.cpp:433-442) */
+#define GARLIC_ERR_HIP 2      /* HIP runtime failure / no gfx950 device */
+#define GARLIC_ERR_STATE 3    /* inputs missing for the requested computation */
+#define GARLIC_ERR_NOMEM 4
+
+#define GARLIC_HOST 0
+#define GARLIC_DEVICE 1
+
+#define GARLIC_MISSING (-9999.0)
+
+#define GARLIC_GL_GQ 0 /* --gl-type GQ, src/garlic-data.cpp:1557 */
+#define GARLIC_GL_GL 1 /* --gl-type GL, src/garlic-data.cpp:1562 */
+#define GARLIC_GL_PL 2 /* --gl-type PL, src/garlic-data.cpp:1566 */
+
+typedef struct garlic_ctx garlic_ctx;
+typedef struct garlic_panel garlic_panel;
+
+int garlic_hip_abi_version(void);
+const char *garlic_hip_last_error(void);
+int garlic_hip_device_count(int32_t *count);
+
+/* Context: device ordinal + stream.  hip_stream == NULL: the context creates its own stream;
+ * otherwise a hipStream_t owned by the caller (e.g. torch's current stream). */
+int garlic_ctx_create(int32_t device, void *hip_stream, garlic_ctx **ctx);
+int garlic_ctx_destroy(garlic_ctx *ctx);
+int garlic_ctx_synchronize(garlic_ctx *ctx);
+
+/* Panel = what calcLODWindows borrows: HapData / MapData / FreqData (/ GenoLikeData / LDData)
+ * of every chromosome, for the nind individuals this context owns (a shard of the TFAM order).
+ * chr_nloci[c] = MapData::nloci of chromosome c (src/garlic-data.h:58). */
+int garlic_panel_create(garlic_ctx *ctx, int32_t nchr, const int32_t *chr_nloci, int32_t nind,
+                        garlic_panel **panel);
+int garlic_panel_destroy(garlic_panel *panel);
+
+/* MapData::physicalPos / geneticPos (src/garlic-data.h:53-54) concatenated over chromosomes
+ * (host arrays), and centromere::centromereStart/End per chromosome
+ * (src/garlic-roh.cpp:36-37; unknown chromosome => 0,0).  gpos may be NULL (unweighted). */
+int garlic_panel_set_map(garlic_panel *panel, const int32_t *pos, const double *gpos,
+                         const int32_t *centro_start, const int32_t *centro_end);
+
+/* FreqData::freq concatenated (host array, src/garlic-data.h:71). */
+int garlic_panel_set_freq(garlic_panel *panel, const double *freq);
+
+/* HapData::data rows (src/garlic-data.h:35) for global loci [locus_begin, locus_begin+locus_count):
+ * geno[(l - locus_begin) * ld + i] is individual i of this shard (ld >= nind lets a shard read a
+ * column block of the full matrix).  May be called repeatedly to stream a panel in chunks.
+ * Device side: 2-bit packed, 16 loci per 32-bit word, individual-minor. */
+int garlic_panel_set_genotypes(garlic_panel *panel, const int16_t *geno, int64_t ld,
+                               int64_t locus_begin, int64_t locus_count, int32_t where);
+
+/* GenoLikeData::data (src/garlic-data.h:91): per-genotype error probabilities, already converted
+ * as readTGLSData does (src/garlic-data.cpp:1557-1576); same addressing as genotypes. */
+int garlic_panel_set_gl(garlic_panel *panel, const double *gl, int64_t ld, int64_t locus_begin,
+                        int64_t locus_count, int32_t where);
+
+/* LDData::LD (src/garlic-data.h:105) for winsize: ld[l * winsize + k], l global locus. */
+int garlic_panel_set_ld(garlic_panel *panel, int32_t winsize, const double *ld, int32_t where);
+
+/* Output addressing for this panel: pitch_align = 1 gives the reference's dense rows
+ * (chr_pitch[c] = chr_nloci[c]); a larger value rounds every row pitch and chromosome base up to
+ * that many doubles (32 = 256-byte aligned rows, what the kernels like best).  total = number of
+ * doubles a full output needs for nind_out individuals. */
+int garlic_lod_out_layout(garlic_panel *panel, int32_t pitch_align, int32_t nind_out,
+                          int64_t *chr_base, int64_t *chr_pitch, int64_t *total);
+
+/* calcLODWindows (src/garlic-roh.cpp:279): unweighted window LOD scores of individuals
+ * [ind_begin, ind_begin + ind_count) for one window size.  use_gl != 0 takes the per-genotype
+ * error from the panel's GL data (USE_GL, src/garlic-roh.cpp:68) instead of `error`.
+ * out has garlic_lod_out_layout(pitch_align, ind_count) doubles. */
+int garlic_lod_windows(garlic_panel *panel, int32_t winsize, double error, int32_t max_gap,
+                       int32_t use_gl, int32_t ind_begin, int32_t ind_count, int32_t pitch_align,
+                       double *out, int32_t where);
+
+/* calcwLODWindows (src/garlic-roh.cpp:311): gap-weighted wLOD; needs gpos and LD for winsize. */
+int garlic_wlod_windows(garlic_panel *panel, int32_t winsize, double error, int32_t max_gap,
+                        int32_t use_gl, int32_t M, double mu, int32_t ind_begin, int32_t ind_count,
+                        int32_t pitch_align, double *out, int32_t where);
+
+/* Introspection used by tests and the bench (device work of the last garlic_*_windows call). */
+typedef struct garlic_call_stats {
+    int64_t n_segments;      /* gap/centromere-free SNP segments over all chromosomes */
+    int64_t n_runs;          /* segments long enough to hold a window (maximal valid runs) */
+    int64_t n_chain_items;   /* (run, 64-individual block) work items = wavefronts launched */
+    int64_t n_valid_windows; /* scored windows per individual */
+    int64_t n_missing;       /* MISSING windows per individual */
+    float chain_kernel_ms;   /* HIP-event time of the dominant kernel on the context stream */
+    float total_ms;          /* HIP-event time of the whole call's device work */
+} garlic_call_stats;
+int garlic_last_call_stats(garlic_panel *panel, garlic_call_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GARLIC_HIP_H */
