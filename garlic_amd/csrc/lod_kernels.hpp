@@ -33,7 +33,7 @@ constexpr int WAVE = 64;
 constexpr int TILE = 32;          // window starts per tile (= 256 B of one output row)
 constexpr int TPITCH = 34;        // doubles per LDS tile row: 272 B keeps ds_read_b128 16-B aligned
 constexpr int GOFF = 32;          // pad SNP rows in front of the packed genotypes / term table
-constexpr int GPAD_BACK = 96;     // pad SNP rows behind (prefetch over-reads stay in bounds)
+constexpr int GPAD_BACK = 256;    // pad SNP rows behind (prefetch over-reads stay in bounds)
 constexpr double MISSING_D = -9999.0;
 
 struct ChrDev {
@@ -235,62 +235,121 @@ struct ChainArgs {
     int32_t winsize;
 };
 
-// LDS carve-up (bytes), one wave per workgroup
-constexpr uint32_t LDS_TAB_LEAD = 0;                       // 32 rows x 32 B
-constexpr uint32_t LDS_TAB_TRAIL = 1024;                   // 32 rows x 32 B
-constexpr uint32_t LDS_TILE = 2048;                        // 64 x TPITCH doubles
-constexpr uint32_t LDS_BYTES = LDS_TILE + WAVE * TPITCH * 8;
+// LDS map (bytes), one wave per workgroup.
+//   4 input slots, one per tile in flight.  A slot holds what a tile needs from global memory:
+//     for each of the two SNP streams (entering / leaving the window) the genotype words +1 and
+//     +2 of every lane (word +0 is carried over in a register from the previous tile) and the
+//     32 term rows {lod(0),lod(1),lod(2),0.0} of the tile's SNPs;
+//   then the 64 x 32 transpose tile.
+constexpr int NSLOT = 4;
+constexpr uint32_t SLOT_BYTES = 3072;
+constexpr uint32_t SL_LW1 = 0, SL_LW2 = 256, SL_TW1 = 512, SL_TW2 = 768;
+constexpr uint32_t SL_LTAB = 1024, SL_TTAB = 2048;
+constexpr uint32_t LDS_SLOTS_BYTES = NSLOT * SLOT_BYTES;
+constexpr uint32_t LDS_TILE_BYTES = WAVE * TPITCH * 8;
 
-// Everything a tile needs from global memory: 3 genotype words per stream (48 SNPs, of which the
-// 32 starting at bit offset `shift` are used) and 16 B of the 32-row term chunk per lane.
-struct TileIn {
-    uint32_t lc, l1, l2;   // entering-SNP stream
-    uint32_t tc, t1, t2;   // leaving-SNP stream
-    double2 tabl, tabt;
-};
-
+// Wave-uniform stream state (lives in SGPRs).
 struct Streams {
-    const uint32_t *plead, *ptrail;   // this lane's column, word row of the current tile
-    const double2 *tlead, *ttrail;    // this lane's 16 B of the current tile's term rows
+    const uint32_t *lead_row, *trail_row;  // packed + word_row(current tile) * npad + first column
+    const double *lead_tab, *trail_tab;    // term row of the current tile's first SNP
     int64_t npad;
-    int sh_lead, sh_trail;
+    int sh_lead, sh_trail;                 // bit offset of the tile's first SNP in its word
 };
 
-__device__ __forceinline__ void load_tile_full(const Streams &st, TileIn &in)
-{
-    in.lc = st.plead[0]; in.l1 = st.plead[st.npad]; in.l2 = st.plead[2 * st.npad];
-    in.tc = st.ptrail[0]; in.t1 = st.ptrail[st.npad]; in.t2 = st.ptrail[2 * st.npad];
-    in.tabl = st.tlead[0]; in.tabt = st.ttrail[0];
+__device__ __forceinline__ void advance(Streams &st)
+{   // next tile = two genotype words and 32 term rows further along both streams
+    st.lead_row += 2 * st.npad; st.trail_row += 2 * st.npad;
+    st.lead_tab += 4 * TILE; st.trail_tab += 4 * TILE;
 }
 
-// next tile = two genotype words and 32 term rows further along both streams
-__device__ __forceinline__ void advance(Streams &st)
+// LDS-DMA: 64 lanes x 4 B (or 16 B) from  base + lane_off  straight into LDS at  lds_addr +
+// lane * size, no VGPR destination.  Issued from inline asm on purpose: the compiler must not
+// know about these loads (it would guard every later LDS read with vmcnt(0) and drain the
+// store queue); the waits are hand-counted below.  s_nop: an SALU write of M0 needs one wait
+// state before an LDS-DMA instruction reads it (gfx9 family), and nothing pads inline asm.
+__device__ __forceinline__ void glds_b32(uint32_t lds_addr, uint32_t lane_off, const void *base)
 {
-    st.plead += 2 * st.npad; st.ptrail += 2 * st.npad; st.tlead += 64; st.ttrail += 64;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+                 :: "s"(lds_addr), "v"(lane_off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void glds_b128(uint32_t lds_addr, uint32_t lane_off, const void *base)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :: "s"(lds_addr), "v"(lane_off), "s"(base) : "memory");
+}
+
+// 6 LDS-DMA requests for the tile `ahead` tiles after the current one, into slot SLOT
+template <int SLOT>
+__device__ __forceinline__ void fill_dma(const Streams &st, int ahead, uint32_t lds0, int lane)
+{
+    const uint32_t slot = lds0 + SLOT * SLOT_BYTES;
+    const uint32_t *lw = st.lead_row + (int64_t)(2 * ahead + 1) * st.npad;
+    const uint32_t *tw = st.trail_row + (int64_t)(2 * ahead + 1) * st.npad;
+    glds_b32(slot + SL_LW1, lane * 4, lw);
+    glds_b32(slot + SL_LW2, lane * 4, lw + st.npad);
+    glds_b32(slot + SL_TW1, lane * 4, tw);
+    glds_b32(slot + SL_TW2, lane * 4, tw + st.npad);
+    glds_b128(slot + SL_LTAB, lane * 16, st.lead_tab + 4 * TILE * ahead);
+    glds_b128(slot + SL_TTAB, lane * 16, st.trail_tab + 4 * TILE * ahead);
+}
+
+// same content through registers (compiler-managed waits): head / leftover tiles
+__device__ __forceinline__ void fill_regs(unsigned char *smem, const Streams &st, int lane)
+{
+    const uint32_t l1 = st.lead_row[st.npad + lane], l2 = st.lead_row[2 * st.npad + lane];
+    const uint32_t t1 = st.trail_row[st.npad + lane], t2 = st.trail_row[2 * st.npad + lane];
+    const double2 tl = reinterpret_cast<const double2 *>(st.lead_tab)[lane];
+    const double2 tt = reinterpret_cast<const double2 *>(st.trail_tab)[lane];
+    *reinterpret_cast<uint32_t *>(smem + SL_LW1 + lane * 4) = l1;
+    *reinterpret_cast<uint32_t *>(smem + SL_LW2 + lane * 4) = l2;
+    *reinterpret_cast<uint32_t *>(smem + SL_TW1 + lane * 4) = t1;
+    *reinterpret_cast<uint32_t *>(smem + SL_TW2 + lane * 4) = t2;
+    *reinterpret_cast<double2 *>(smem + SL_LTAB + lane * 16) = tl;
+    *reinterpret_cast<double2 *>(smem + SL_TTAB + lane * 16) = tt;
+}
+
+// Genotype bits of a tile's 32 steps, both streams (16 SNPs per word).
+struct TileBits {
+    uint32_t lead_lo, lead_hi, trail_lo, trail_hi;
+};
+
+// lc/tc: genotype word +0 of each stream (carried); funnel-shift the 3 words of a stream to the
+// tile's first SNP.
+template <int SLOT>
+__device__ __forceinline__ TileBits tile_consume(const unsigned char *smem, uint32_t &lc,
+                                                 uint32_t &tc, const Streams &st, int lane)
+{
+    const unsigned char *slot = smem + SLOT * SLOT_BYTES;
+    const uint32_t l1 = *reinterpret_cast<const uint32_t *>(slot + SL_LW1 + lane * 4);
+    const uint32_t l2 = *reinterpret_cast<const uint32_t *>(slot + SL_LW2 + lane * 4);
+    const uint32_t t1 = *reinterpret_cast<const uint32_t *>(slot + SL_TW1 + lane * 4);
+    const uint32_t t2 = *reinterpret_cast<const uint32_t *>(slot + SL_TW2 + lane * 4);
+    TileBits tb;
+    tb.lead_lo = __builtin_amdgcn_alignbit(l1, lc, st.sh_lead);
+    tb.lead_hi = __builtin_amdgcn_alignbit(l2, l1, st.sh_lead);
+    tb.trail_lo = __builtin_amdgcn_alignbit(t1, tc, st.sh_trail);
+    tb.trail_hi = __builtin_amdgcn_alignbit(t2, t1, st.sh_trail);
+    lc = l2;
+    tc = t2;
+    return tb;
 }
 
 // The 32 dependent steps of one tile.  EDGE: tile straddles the run's first or last window.
-template <bool EDGE>
-__device__ __forceinline__ void tile_steps(unsigned char *smem, double &acc, const TileIn &in,
-                                           const Streams &st, int s0, int a, int b, int lane)
+template <bool EDGE, int SLOT>
+__device__ __forceinline__ void tile_steps(const unsigned char *smem, unsigned char *tile,
+                                           double &acc, const TileBits &tb, int s0, int a, int b,
+                                           int lane)
 {
-    // stage this tile's term rows (LDS ops of one wave execute in program order, so the reads
-    // of the previous tile are already done)
-    *reinterpret_cast<double2 *>(smem + LDS_TAB_LEAD + lane * 16) = in.tabl;
-    *reinterpret_cast<double2 *>(smem + LDS_TAB_TRAIL + lane * 16) = in.tabt;
-    const uint32_t lead_lo = __builtin_amdgcn_alignbit(in.l1, in.lc, st.sh_lead);
-    const uint32_t lead_hi = __builtin_amdgcn_alignbit(in.l2, in.l1, st.sh_lead);
-    const uint32_t trail_lo = __builtin_amdgcn_alignbit(in.t1, in.tc, st.sh_trail);
-    const uint32_t trail_hi = __builtin_amdgcn_alignbit(in.t2, in.t1, st.sh_trail);
-    const uint32_t tile_lane = LDS_TILE + (uint32_t)lane * (TPITCH * 8);
+    const unsigned char *slot = smem + SLOT * SLOT_BYTES;
+    const uint32_t tile_lane = (uint32_t)lane * (TPITCH * 8);
 #pragma unroll
     for (int j = 0; j < TILE; j++) {
-        const uint32_t lw = (j < 16) ? lead_lo : lead_hi;
-        const uint32_t tw = (j < 16) ? trail_lo : trail_hi;
+        const uint32_t lw = (j < 16) ? tb.lead_lo : tb.lead_hi;
+        const uint32_t tw = (j < 16) ? tb.trail_lo : tb.trail_hi;
         const uint32_t g1 = (lw >> (2 * (j & 15))) & 3u;
         const uint32_t g0 = (tw >> (2 * (j & 15))) & 3u;
-        double t_in = *reinterpret_cast<const double *>(smem + LDS_TAB_LEAD + j * 32 + g1 * 8);
-        double t_out = *reinterpret_cast<const double *>(smem + LDS_TAB_TRAIL + j * 32 + g0 * 8);
+        double t_in = *reinterpret_cast<const double *>(slot + SL_LTAB + j * 32 + g1 * 8);
+        double t_out = *reinterpret_cast<const double *>(slot + SL_TTAB + j * 32 + g0 * 8);
         if (EDGE) {
             const int s = s0 + j;
             // the first window of a run is a plain sum (no leaving term); steps outside [a,b]
@@ -300,26 +359,30 @@ __device__ __forceinline__ void tile_steps(unsigned char *smem, double &acc, con
             if (!(s >= a && s <= b)) t_in = 0.0;
         }
         acc = (acc - t_out) + t_in; // two roundings, as garlic-roh.cpp:98-100
-        *reinterpret_cast<double *>(smem + tile_lane + j * 8) = acc;
+        *reinterpret_cast<double *>(tile + tile_lane + j * 8) = acc;
     }
 }
 
 // Transposed write-out of a tile: store q covers individuals 4q..4q+3, 16 lanes x 16 B = 256
-// contiguous bytes of each row.  Rows past the shard's last individual are clamped onto the last
-// valid row: those lanes re-store that row's own values (same address, same data), which keeps
-// the stores unconditional -- an exec-masked store sits behind a skip branch, and a branchy
-// tile makes the compiler's counted vmcnt at the loop head collapse to vmcnt(0).
+// contiguous bytes of each row.  Every store is unconditional (the hand-counted vmcnt needs a
+// fixed number of stores per tile): a 4-row group wholly past the shard's last individual
+// re-stores group 0, a lane past the last row of a partial group re-stores that group's last
+// valid row -- same address, same data as the lane that owns it.
+// Address = wave-uniform row-group base (SGPR pair) + 32-bit lane offset.
 template <bool EDGE, bool ALIGNED16>
-__device__ __forceinline__ void tile_store(const unsigned char *smem, int s0, int a, int b, int lane,
+__device__ __forceinline__ void tile_store(const unsigned char *tile, int s0, int a, int b, int lane,
                                            int rows_valid, double *out_tile, int64_t pitch)
 {
     const int rsub = lane >> 4, csub = lane & 15;
 #pragma unroll
     for (int q = 0; q < WAVE / 4; q++) {
-        const int r = min(4 * q + rsub, rows_valid - 1);
+        const int qe = (4 * q < rows_valid) ? q : 0;                 // uniform
+        const int re = min(rsub, rows_valid - 1 - 4 * qe);           // per lane, 0..3
         const double2 v = *reinterpret_cast<const double2 *>(
-            smem + LDS_TILE + (uint32_t)r * (TPITCH * 8) + csub * 16);
-        double *dst = out_tile + (int64_t)r * pitch + 2 * csub;
+            tile + (uint32_t)(4 * qe + re) * (TPITCH * 8) + csub * 16);
+        char *base = reinterpret_cast<char *>(out_tile + (int64_t)(4 * qe) * pitch);
+        const uint32_t off = (uint32_t)re * (uint32_t)(pitch * 8) + (uint32_t)csub * 16u;
+        double *dst = reinterpret_cast<double *>(base + off);
         if (EDGE) {
             const int s = s0 + 2 * csub;
             if (s >= a && s <= b) dst[0] = v.x;
@@ -333,11 +396,16 @@ __device__ __forceinline__ void tile_store(const unsigned char *smem, int s0, in
     }
 }
 
+// stores in flight: 3 tiles x 16 store instructions + 2 x 6 younger LDS-DMA requests
+#define GARLIC_WAIT_TILE_INPUTS() asm volatile("s_waitcnt vmcnt(60)" ::: "memory")
+#define GARLIC_WAIT_ALL_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
 template <bool ALIGNED16>
 __global__ void __launch_bounds__(WAVE)
 lod_chain_kernel(ChainArgs p)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_SLOTS_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char tile[LDS_TILE_BYTES];
     const ChainItem it = p.items[blockIdx.x];
     if (it.chr < 0) return;
     const ChrDev c = p.chrs[it.chr];
@@ -345,11 +413,12 @@ lod_chain_kernel(ChainArgs p)
     const int W = p.winsize;
     const int a = it.a, b = it.b;
     const int rows_valid = min(WAVE, p.ind_count - it.ind0);
-    // lanes past the shard read the padded columns (code 3 -> term 0.0) and never store
-    const int64_t col = (int64_t)p.ind_begin + it.ind0 + lane;
-    const uint32_t *gcol = p.packed + col;
+    // lanes past the shard read the padded columns (code 3 -> term 0.0)
+    const int64_t col0 = (int64_t)p.ind_begin + it.ind0;
+    const uint32_t *gcol = p.packed + col0 + lane;
     const int64_t npad = p.nind_pad;
     const int64_t Gbase = c.loc_base + GOFF; // global (padded) index of chromosome-local locus 0
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
     // ---- first window of the run: sum of W terms left to right (garlic-roh.cpp:57-71); the
     //      first W-1 of them here, the W-th enters in the first tile below.
@@ -385,53 +454,68 @@ lod_chain_kernel(ChainArgs p)
         st.npad = npad;
         st.sh_lead = 2 * (int)(Glead & 15);
         st.sh_trail = 2 * (int)(Gtrail & 15);
-        st.plead = gcol + (Glead >> 4) * npad;
-        st.ptrail = gcol + (Gtrail >> 4) * npad;
-        st.tlead = reinterpret_cast<const double2 *>(p.tab + Glead * 4) + lane;
-        st.ttrail = reinterpret_cast<const double2 *>(p.tab + Gtrail * 4) + lane;
+        st.lead_row = p.packed + col0 + (Glead >> 4) * npad;
+        st.trail_row = p.packed + col0 + (Gtrail >> 4) * npad;
+        st.lead_tab = p.tab + Glead * 4;
+        st.trail_tab = p.tab + Gtrail * 4;
     }
     double *out_tile = p.out + c.out_base + (int64_t)it.ind0 * c.out_pitch + s0;
     const int64_t pitch = c.out_pitch;
-    TileIn in;
+    uint32_t lc, tc;
 
-    // head tile: always the masked variant -- the run's first window has no leaving term even
-    // when the run starts exactly on a tile boundary
-    {
-        load_tile_full(st, in);
-        tile_steps<true>(smem, acc, in, st, s0, a, b, lane);
-        tile_store<true, ALIGNED16>(smem, s0, a, b, lane, rows_valid, out_tile, pitch);
-        advance(st);
-        s0 += TILE;
-        out_tile += TILE;
-    }
-
-    // full tiles: loads for tile k+1 are issued before the 16 stores of tile k, so the wait at
-    // the top of the loop is a counted vmcnt that leaves those stores in flight.
-    if (s0 + TILE - 1 <= b) {
-        load_tile_full(st, in);
-        // make the loop start with nothing pending on these registers (otherwise the merged
-        // wait state at the loop header degenerates to vmcnt(0) and drains the stores)
-        asm volatile("" : "+v"(in.lc), "+v"(in.l1), "+v"(in.l2), "+v"(in.tc), "+v"(in.t1), "+v"(in.t2));
-        asm volatile("" : "+v"(in.tabl.x), "+v"(in.tabl.y), "+v"(in.tabt.x), "+v"(in.tabt.y));
-        do {
-            TileIn cur = in;
+    // phase 0: the head tile alone, masked variant (the run's first window has no leaving term,
+    //          even when the run starts exactly on a tile boundary);
+    //          then the bulk: groups of 4 full tiles in the pipelined loop;
+    // phase 1: whatever is left (at most 3 full tiles and the partial tail tile), masked variant.
+    for (int phase = 0; phase < 2; phase++) {
+        const int last = (phase == 0) ? s0 : b;
+        while (s0 <= last && s0 <= b) {
+            lc = st.lead_row[lane];
+            tc = st.trail_row[lane];
+            fill_regs(smem, st, lane);
+            const TileBits tb = tile_consume<0>(smem, lc, tc, st, lane);
+            tile_steps<true, 0>(smem, tile, acc, tb, s0, a, b, lane);
+            tile_store<true, ALIGNED16>(tile, s0, a, b, lane, rows_valid, out_tile, pitch);
             advance(st);
-            in.lc = cur.l2; in.tc = cur.t2;
-            in.l1 = st.plead[npad]; in.l2 = st.plead[2 * npad];
-            in.t1 = st.ptrail[npad]; in.t2 = st.ptrail[2 * npad];
-            in.tabl = st.tlead[0]; in.tabt = st.ttrail[0];
-            tile_steps<false>(smem, acc, cur, st, s0, a, b, lane);
-            tile_store<false, ALIGNED16>(smem, s0, a, b, lane, rows_valid, out_tile, pitch);
             s0 += TILE;
             out_tile += TILE;
-        } while (s0 + TILE - 1 <= b);
-    }
+        }
+        if (phase == 1 || !ALIGNED16) continue;
 
-    // tail tile
-    if (s0 <= b) {
-        load_tile_full(st, in);
-        tile_steps<true>(smem, acc, in, st, s0, a, b, lane);
-        tile_store<true, ALIGNED16>(smem, s0, a, b, lane, rows_valid, out_tile, pitch);
+        // Full tiles.  A wave's vector-memory operations retire in issue order, so a load only
+        // "completes" once every older store has been acknowledged.  The inputs of tile k+3 are
+        // therefore requested (LDS-DMA into a 4-slot ring) BEFORE the 16 stores of tile k, and
+        // the wait at the top of a tile is the counted vmcnt(60): it leaves the 48 stores of
+        // the last 3 tiles (48 KB per wave) and the 12 younger requests in flight.
+        int groups = (b + 1 - s0) / (NSLOT * TILE);
+        if (groups > 0) {
+            lc = st.lead_row[lane];
+            tc = st.trail_row[lane];
+            asm volatile("" : "+v"(lc), "+v"(tc)); // compiler-visible loads waited for here
+            fill_dma<0>(st, 0, lds0, lane);
+            fill_dma<1>(st, 1, lds0, lane);
+            fill_dma<2>(st, 2, lds0, lane);
+            GARLIC_WAIT_ALL_VMEM();
+#define GARLIC_FULL_TILE(SLOT, NEXT)                                                             \
+            {                                                                                    \
+                GARLIC_WAIT_TILE_INPUTS();                                                       \
+                const TileBits tb = tile_consume<SLOT>(smem, lc, tc, st, lane);                  \
+                fill_dma<NEXT>(st, 3, lds0, lane);                                               \
+                tile_steps<false, SLOT>(smem, tile, acc, tb, s0, a, b, lane);                    \
+                tile_store<false, true>(tile, s0, a, b, lane, rows_valid, out_tile, pitch);      \
+                advance(st);                                                                     \
+                s0 += TILE;                                                                      \
+                out_tile += TILE;                                                                \
+            }
+            do {
+                GARLIC_FULL_TILE(0, 3)
+                GARLIC_FULL_TILE(1, 0)
+                GARLIC_FULL_TILE(2, 1)
+                GARLIC_FULL_TILE(3, 2)
+            } while (--groups > 0);
+#undef GARLIC_FULL_TILE
+            GARLIC_WAIT_ALL_VMEM(); // prefetches beyond the last tile land before slot 0 is reused
+        }
     }
 }
 
