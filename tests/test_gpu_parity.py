@@ -66,3 +66,58 @@ def test_individual_subrange(gpu_ctx):
     data = make_multichr(rng, [1200, 800], 150, max_gap)
     out, _ = run_gpu(gpu_ctx, *data, 40, 0.001, max_gap, pitch_align=32, ind_begin=37, ind_count=70)
     check_against_oracle(out, *data, 40, 0.001, max_gap, lo=37, hi=107)
+
+
+def test_golden_unweighted(gpu_ctx):
+    """The committed reference outputs (tests/golden/unweighted.npz), all chromosomes in one panel:
+    >max_gap holes, a centromere that contains SNPs, an unknown chromosome (centromere 0,0),
+    missing genotypes, freq in {0,1}, nloci < W and nloci == W."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "unweighted.npz"))
+    nchr = int(d["nchr"])
+    genos = [d[f"geno{c}"] for c in range(nchr)]
+    freqs = [d[f"freq{c}"] for c in range(nchr)]
+    poss = [d[f"pos{c}"] for c in range(nchr)]
+    css = [int(d[f"centro{c}"][0]) for c in range(nchr)]
+    ces = [int(d[f"centro{c}"][1]) for c in range(nchr)]
+    for W in d["winsizes"]:
+        for pa in (1, 32):
+            out, _ = run_gpu(gpu_ctx, genos, freqs, poss, css, ces, int(W), float(d["error"]),
+                             int(d["max_gap"]), pitch_align=pa)
+            for c in range(nchr):
+                assert ol.bits_equal(np.ascontiguousarray(out[c]), d[f"win{c}_W{W}"]), (int(W), pa, c)
+
+
+def test_invalid_arguments(gpu_ctx):
+    rng = np.random.default_rng(1)
+    g, f, p, cs, ce = ol.random_panel(rng, 200, 8)
+    with abi.Panel(gpu_ctx, [200], 8) as panel:
+        with pytest.raises(abi.GarlicError) as e:          # inputs missing
+            panel.lod_windows(10, 0.001, 200000)
+        assert e.value.code == abi.ERR_STATE
+        panel.set_map(p, [cs], [ce])
+        panel.set_freq(f)
+        panel.set_genotypes(g)
+        with pytest.raises(abi.GarlicError) as e:          # winsize must be > 1 (garlic-cli.cpp:433)
+            panel.lod_windows(1, 0.001, 200000)
+        assert e.value.code == abi.ERR_INVALID
+        with pytest.raises(abi.GarlicError):
+            panel.lod_windows(10, 0.001, 200000, ind_begin=4, ind_count=8)
+    with pytest.raises(abi.GarlicError):                   # initWinData refuses empty shapes
+        abi.Panel(gpu_ctx, [0], 8)
+
+
+def test_chunked_genotype_upload_and_repeat_calls(gpu_ctx):
+    rng = np.random.default_rng(11)
+    max_gap = 200000
+    data = make_multichr(rng, [700, 500], 70, max_gap)
+    genos, freqs, poss, css, ces = data
+    allg = np.concatenate(genos, axis=0)
+    with abi.Panel(gpu_ctx, [700, 500], 70) as panel:
+        panel.set_map(np.concatenate(poss), css, ces)
+        panel.set_freq(np.concatenate(freqs))
+        for l0 in range(0, 1200, 133):                      # ragged chunks, unaligned to 16 SNPs
+            panel.set_genotypes(allg[l0:l0 + 133], locus_begin=l0)
+        for W, err in ((20, 0.001), (50, 0.001), (20, 0.01), (20, 0.001)):
+            out = panel.lod_windows(W, err, max_gap, pitch_align=32)
+            check_against_oracle(out, *data, W, err, max_gap)

@@ -1,0 +1,60 @@
+"""CPU, build container only: the oracle against the real reference (oracle/_ref) on random panels.
+Skipped where oracle/_ref was never built (it cannot be rebuilt without /root/reference)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.skipif(not ol.have_ref(), reason="oracle/_ref/libgarlic_ref.so not built")
+
+
+def test_lod_inGap_decay_scalars():
+    rng = np.random.default_rng(0)
+    o, r = ol.oracle(), ol.ref()
+    for _ in range(2000):
+        g = int(rng.choice([0, 1, 2, -9, 3]))
+        f = float(rng.choice([0.0, 1.0, rng.uniform(0, 1)]))
+        e = float(rng.choice([1e-16, 1e-3, rng.uniform(0, 1), 1.0]))
+        assert np.float64(o.oracle_lod(g, f, e)).view(np.uint64) == np.float64(r.ref_lod(g, f, e)).view(np.uint64)
+        q = [int(x) for x in rng.integers(0, 50, size=4)]
+        assert o.oracle_in_gap(*q) == r.ref_inGap(*q)
+        iv = float(rng.uniform(0, 1e6))
+        assert o.oracle_nomut(7.0, 1e-9, iv) == r.ref_nomut(7.0, 1e-9, iv)
+        assert o.oracle_norec(7.0, iv * 1e-6) == r.ref_norec(7.0, iv * 1e-6)
+
+
+def test_unweighted_random_panels():
+    rng = np.random.default_rng(1)
+    total = 0
+    for _ in range(120):
+        nloci, nind, W = int(rng.integers(1, 400)), int(rng.integers(1, 9)), int(rng.integers(2, 70))
+        mg = int(rng.choice([200000, 3000, 50000]))
+        geno, freq, pos, cS, cE = ol.random_panel(rng, nloci, nind, max_gap=mg)
+        known = bool(rng.integers(0, 2))
+        if not known:
+            cS = cE = 0
+        gl = rng.choice([1e-16, 1e-3, 0.01, 0.5, 1.0, 10 ** -2.7], size=geno.shape) if rng.integers(0, 2) else None
+        a = ol.oracle_calc_lod(geno, freq, pos, cS, cE, W, 0.001, mg, gl=gl)
+        b = ol.ref_calc_lod(geno, freq, pos, cS, cE, W, 0.001, mg, gl=gl, centro_known=known)
+        assert ol.bits_equal(a, b)
+        assert ((b != ol.MISSING) == ol.oracle_mask(pos, cS, cE, W, mg)[None, :].astype(bool)).all()
+        total += a.size
+    assert total > 50000
+
+
+def test_wlod_random_panels():
+    rng = np.random.default_rng(2)
+    for _ in range(40):
+        nloci, nind, W = int(rng.integers(2, 300)), int(rng.integers(2, 9)), int(rng.integers(2, 40))
+        geno, freq, pos, cS, cE = ol.random_panel(rng, nloci, nind)
+        gpos = pos * 1e-6 * rng.uniform(0.8, 1.2)
+        hom, ld = ol.ref_hr2_ld(geno, W, threads=int(rng.integers(1, 4)))
+        assert ol.bits_equal(hom, ol.oracle_geno_freq(geno))
+        assert ol.bits_equal(ld, ol.oracle_hr2_ld(geno, W))
+        ld = np.where(np.isfinite(ld) & (ld > 0), ld, 1.0)
+        gl = rng.choice([1e-16, 1e-3, 0.5, 1.0], size=geno.shape) if rng.integers(0, 2) else None
+        a = ol.oracle_calc_wlod(geno, freq, pos, gpos, ld, cS, cE, W, 0.001, 200000, 1e-9, 7, gl=gl,
+                                threads=int(rng.integers(1, 6)))
+        b = ol.ref_calc_wlod(geno, freq, pos, gpos, ld, cS, cE, W, 0.001, 200000, 1e-9, 7, gl=gl,
+                             threads=int(rng.integers(1, 6)))
+        assert ol.bits_equal(a, b)
