@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -131,6 +132,7 @@ struct garlic_panel {
     // per-call scratch
     DevBuf<ChainItem> d_items;
     DevBuf<FillItem> d_fill;
+    DevBuf<int32_t> d_counter;
     DevBuf<ChrDev> d_chrs;
     DevBuf<int16_t> d_stage16;
     DevBuf<double> d_out;
@@ -217,12 +219,15 @@ Layout make_layout(const garlic_panel *p, int32_t pitch_align, int32_t nind_out)
     L.pitch.resize(p->nchr);
     int64_t off = 0;
     const int64_t al = std::max(1, pitch_align);
+    // pitch_align >= 2: rows are also padded to a multiple of 64 individuals, so every wavefront
+    // stores 64 full rows (the pad rows belong to the caller's buffer and are never read back)
+    const int64_t rows = (pitch_align >= 2) ? ((int64_t)nind_out + 63) / 64 * 64 : nind_out;
     for (int c = 0; c < p->nchr; c++) {
         int64_t pitch = ((int64_t)p->chr_nloci[c] + al - 1) / al * al;
         off = (off + al - 1) / al * al;
         L.base[c] = off;
         L.pitch[c] = pitch;
-        off += pitch * nind_out;
+        off += pitch * rows;
     }
     L.total = off;
     return L;
@@ -290,38 +295,40 @@ int launch_lod(garlic_panel *p, int32_t W, double error, int32_t max_gap, int32_
     int64_t n_valid = 0;
     plan_runs(p, W, runs, fill, n_valid);
 
-    // Work list: longest runs first (they bound the tail), each run's 64-individual blocks
-    // adjacent, and runs dealt round-robin to the 8 XCD groups (workgroups i and i+8 share an
-    // XCD's L2, so all waves of a run read its genotype rows and term table through one L2).
+    // Work list: (run, 64-individual block) items, longest runs first (LPT); the persistent waves
+    // of lod_chain_kernel pull them from a device counter.
     std::vector<int> order(runs.size());
     for (size_t i = 0; i < runs.size(); i++) order[i] = (int)i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
         return (runs[x].b - runs[x].a) > (runs[y].b - runs[y].a);
     });
     const int nblk = (ind_count + WAVE - 1) / WAVE;
-    constexpr int NXCD = 8;
-    std::vector<std::vector<ChainItem>> group(NXCD);
+    std::vector<ChainItem> items;
+    items.reserve(runs.size() * nblk);
     for (size_t i = 0; i < order.size(); i++) {
         const Run &r = runs[order[i]];
-        // lightest group first keeps the 8 lists the same length
-        int g = 0;
-        for (int x = 1; x < NXCD; x++)
-            if (group[x].size() < group[g].size()) g = x;
-        for (int k = 0; k < nblk; k++) group[g].push_back(ChainItem{r.chr, r.a, r.b, k * WAVE});
+        for (int k = 0; k < nblk; k++) items.push_back(ChainItem{r.chr, r.a, r.b, k * WAVE});
     }
-    size_t depth = 0;
-    for (auto &g : group) depth = std::max(depth, g.size());
-    std::vector<ChainItem> items(depth * NXCD, ChainItem{-1, 0, 0, 0});
-    for (int x = 0; x < NXCD; x++)
-        for (size_t i = 0; i < group[x].size(); i++) items[i * NXCD + x] = group[x][i];
+    // Number of persistent waves.  Measured on MI355X (1M SNPs): with about 4 items per CU or
+    // fewer, ONE wave per CU is fastest -- two waves on a CU slow each other down (LDS store path)
+    // and every extra wave dilutes the HBM bandwidth the longest runs get while the short ones
+    // are still running, so the makespan becomes the longest run crawling at 1/n of the bandwidth
+    // and later alone at its latency-bound pace; LPT packing behind 256 waves keeps every wave busy
+    // to the end instead.  With many more items than CUs, filling the LDS (5 waves per CU) wins.
+    int workers = ((int64_t)items.size() >= 10 * 256) ? 5 * 256 : 256;
+    if (const char *e = getenv("GARLIC_WORKERS")) workers = std::max(1, atoi(e));
+    workers = std::min<int>(workers, (int)items.size());
+    workers = std::min(workers, 256 * 5); // LDS: 5 waves per CU are resident
 
     std::vector<ChrDev> chrs(p->nchr);
     for (int c = 0; c < p->nchr; c++)
-        chrs[c] = ChrDev{p->chr_off[c], L.base[c], L.pitch[c], p->chr_nloci[c], 0};
+        chrs[c] = ChrDev{p->chr_off[c], L.base[c], L.pitch[c], p->chr_nloci[c],
+                         (pitch_align >= 2 && 64 * L.pitch[c] * 8 + 512 < ((int64_t)1 << 32)) ? 1 : 0};
 
     if ((rc = p->d_chrs.reserve(chrs.size()))) return rc;
     if ((rc = p->d_items.reserve(std::max<size_t>(items.size(), 1)))) return rc;
     if ((rc = p->d_fill.reserve(std::max<size_t>(fill.size(), 1)))) return rc;
+    if ((rc = p->d_counter.reserve(1))) return rc;
 
     double *d_out = out;
     if (where == GARLIC_HOST) {
@@ -344,16 +351,17 @@ int launch_lod(garlic_panel *p, int32_t W, double error, int32_t max_gap, int32_
         hipLaunchKernelGGL(fill_missing_kernel, grid, dim3(256), 0, ctx->stream, p->d_fill.p,
                            p->d_chrs.p, ind_count, d_out);
     }
+    if (!items.empty()) HIP_TRY(hipMemsetAsync(p->d_counter.p, 0, sizeof(int32_t), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev_k0, ctx->stream));
     if (!items.empty()) {
-        ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p, p->d_chrs.p, d_out,
-                    p->nind_pad,   ind_begin,  ind_count,    W};
+        ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p,     p->d_chrs.p,     d_out, p->nind_pad,
+                    ind_begin,     ind_count,  W,               (int32_t)items.size(), p->d_counter.p};
         if (aligned16)
-            hipLaunchKernelGGL(lod_chain_kernel<true>, dim3((unsigned)items.size()), dim3(WAVE),
-                               0, ctx->stream, a);
+            hipLaunchKernelGGL(lod_chain_kernel<true>, dim3((unsigned)workers), dim3(WAVE), 0,
+                               ctx->stream, a);
         else
-            hipLaunchKernelGGL(lod_chain_kernel<false>, dim3((unsigned)items.size()), dim3(WAVE),
-                               0, ctx->stream, a);
+            hipLaunchKernelGGL(lod_chain_kernel<false>, dim3((unsigned)workers), dim3(WAVE), 0,
+                               ctx->stream, a);
     }
     HIP_TRY(hipEventRecord(ctx->ev_k1, ctx->stream));
     HIP_TRY(hipGetLastError());
@@ -510,7 +518,7 @@ int garlic_panel_destroy(garlic_panel *p)
     p->d_packed.release(); p->d_pos.release(); p->d_cs.release(); p->d_ce.release();
     p->d_chr_off.release(); p->d_tab.release(); p->d_blk_counts.release();
     p->d_blk_offsets.release(); p->d_total.release(); p->d_boundaries.release();
-    p->d_items.release(); p->d_fill.release(); p->d_chrs.release(); p->d_stage16.release();
+    p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release();
     p->d_out.release();
     delete p;
     return GARLIC_OK;

@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "chain_loop_gfx950.inc"
+
 namespace garlic {
 
 constexpr int WAVE = 64;
@@ -41,7 +43,7 @@ struct ChrDev {
     int64_t out_base;   // offset (doubles) of the chromosome block in the output
     int64_t out_pitch;  // row pitch (doubles)
     int32_t nloci;
-    int32_t pad;
+    int32_t fast;       // layout allows the hand-scheduled loop (even pitch, 64-row padding, 32-bit row offsets)
 };
 
 struct ChainItem {   // one wavefront of work: a run of valid windows x 64 individuals
@@ -233,6 +235,8 @@ struct ChainArgs {
     int32_t ind_begin;        // first individual of this call inside the panel shard
     int32_t ind_count;        // rows in the output
     int32_t winsize;
+    int32_t n_items;          // work-list length
+    int32_t *next_item;       // device counter (zeroed per launch): the persistent waves' queue head
 };
 
 // LDS map (bytes), one wave per workgroup.
@@ -245,8 +249,8 @@ constexpr int NSLOT = 4;
 constexpr uint32_t SLOT_BYTES = 3072;
 constexpr uint32_t SL_LW1 = 0, SL_LW2 = 256, SL_TW1 = 512, SL_TW2 = 768;
 constexpr uint32_t SL_LTAB = 1024, SL_TTAB = 2048;
-constexpr uint32_t LDS_SLOTS_BYTES = NSLOT * SLOT_BYTES;
-constexpr uint32_t LDS_TILE_BYTES = WAVE * TPITCH * 8;
+constexpr uint32_t LDS_TILE = NSLOT * SLOT_BYTES;               // transpose tile, 64 rows x 272 B
+constexpr uint32_t LDS_BYTES = LDS_TILE + WAVE * TPITCH * 8;
 
 // Wave-uniform stream state (lives in SGPRs).
 struct Streams {
@@ -396,20 +400,27 @@ __device__ __forceinline__ void tile_store(const unsigned char *tile, int s0, in
     }
 }
 
-// stores in flight: 3 tiles x 16 store instructions + 2 x 6 younger LDS-DMA requests
-#define GARLIC_WAIT_TILE_INPUTS() asm volatile("s_waitcnt vmcnt(60)" ::: "memory")
-#define GARLIC_WAIT_ALL_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-
 template <bool ALIGNED16>
 __global__ void __launch_bounds__(WAVE)
 lod_chain_kernel(ChainArgs p)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_SLOTS_BYTES];
-    __shared__ __attribute__((aligned(16))) unsigned char tile[LDS_TILE_BYTES];
-    const ChainItem it = p.items[blockIdx.x];
-    if (it.chr < 0) return;
-    const ChrDev c = p.chrs[it.chr];
+    // one LDS object at offset 0: the hand-scheduled loop addresses it with absolute offsets
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    unsigned char *tile = smem + LDS_TILE;
     const int lane = threadIdx.x;
+    // Persistent wave: pulls (run, 64-individual block) items, longest runs first, from one
+    // device-wide counter.  The host launches only about as many waves as it takes to saturate
+    // HBM (see launch_lod): with every item resident at once all waves share the bandwidth
+    // equally, the short runs finish early and the long ones are left running alone at their
+    // latency-bound pace; with few waves the long runs run at full speed from the start and the
+    // short ones are packed behind each other.
+    for (;;) {
+    int item_idx = 0;
+    if (lane == 0) item_idx = atomicAdd(p.next_item, 1);
+    item_idx = __builtin_amdgcn_readfirstlane(item_idx);
+    if (item_idx >= p.n_items) return;
+    const ChainItem it = p.items[item_idx];
+    const ChrDev c = p.chrs[it.chr];
     const int W = p.winsize;
     const int a = it.a, b = it.b;
     const int rows_valid = min(WAVE, p.ind_count - it.ind0);
@@ -465,8 +476,9 @@ lod_chain_kernel(ChainArgs p)
 
     // phase 0: the head tile alone, masked variant (the run's first window has no leaving term,
     //          even when the run starts exactly on a tile boundary);
-    //          then the bulk: groups of 4 full tiles in the pipelined loop;
-    // phase 1: whatever is left (at most 3 full tiles and the partial tail tile), masked variant.
+    //          then the bulk: all full tiles in the hand-scheduled loop;
+    // phase 1: whatever is left (the partial tail tile; everything when the layout is not
+    //          eligible for the fast loop), masked variant.
     for (int phase = 0; phase < 2; phase++) {
         const int last = (phase == 0) ? s0 : b;
         while (s0 <= last && s0 <= b) {
@@ -480,43 +492,45 @@ lod_chain_kernel(ChainArgs p)
             s0 += TILE;
             out_tile += TILE;
         }
-        if (phase == 1 || !ALIGNED16) continue;
+        if (phase == 1 || !ALIGNED16 || !c.fast) continue;
 
-        // Full tiles.  A wave's vector-memory operations retire in issue order, so a load only
-        // "completes" once every older store has been acknowledged.  The inputs of tile k+3 are
-        // therefore requested (LDS-DMA into a 4-slot ring) BEFORE the 16 stores of tile k, and
-        // the wait at the top of a tile is the counted vmcnt(60): it leaves the 48 stores of
-        // the last 3 tiles (48 KB per wave) and the 12 younger requests in flight.
-        int groups = (b + 1 - s0) / (NSLOT * TILE);
-        if (groups > 0) {
+        // Bulk: every full tile of the run in one hand-scheduled block (chain_loop_gfx950.inc,
+        // generated by tools/gen_chain_asm.py).  A wave's vector-memory operations retire in issue
+        // order, so an input load only "completes" once every older store has been acknowledged;
+        // the inputs of tile k+4 are therefore requested (LDS-DMA into the 4-slot ring) before the
+        // stores of tile k, and the wait for tile k+1's inputs is the counted vmcnt(60) that leaves
+        // the 48 stores of 3 tiles in flight.
+        int ntiles = (b + 1 - s0) / TILE;
+        if (ntiles >= 2) {
             lc = st.lead_row[lane];
             tc = st.trail_row[lane];
-            asm volatile("" : "+v"(lc), "+v"(tc)); // compiler-visible loads waited for here
+            asm volatile("" : "+v"(lc), "+v"(tc)); // compiler-visible loads are waited for here
             fill_dma<0>(st, 0, lds0, lane);
             fill_dma<1>(st, 1, lds0, lane);
             fill_dma<2>(st, 2, lds0, lane);
-            GARLIC_WAIT_ALL_VMEM();
-#define GARLIC_FULL_TILE(SLOT, NEXT)                                                             \
-            {                                                                                    \
-                GARLIC_WAIT_TILE_INPUTS();                                                       \
-                const TileBits tb = tile_consume<SLOT>(smem, lc, tc, st, lane);                  \
-                fill_dma<NEXT>(st, 3, lds0, lane);                                               \
-                tile_steps<false, SLOT>(smem, tile, acc, tb, s0, a, b, lane);                    \
-                tile_store<false, true>(tile, s0, a, b, lane, rows_valid, out_tile, pitch);      \
-                advance(st);                                                                     \
-                s0 += TILE;                                                                      \
-                out_tile += TILE;                                                                \
-            }
-            do {
-                GARLIC_FULL_TILE(0, 3)
-                GARLIC_FULL_TILE(1, 0)
-                GARLIC_FULL_TILE(2, 1)
-                GARLIC_FULL_TILE(3, 2)
-            } while (--groups > 0);
-#undef GARLIC_FULL_TILE
-            GARLIC_WAIT_ALL_VMEM(); // prefetches beyond the last tile land before slot 0 is reused
+            fill_dma<3>(st, 3, lds0, lane);
+            const uint32_t *pl = st.lead_row + 2 * NSLOT * npad;   // tile 4: prefetched in the loop
+            const uint32_t *pt = st.trail_row + 2 * NSLOT * npad;
+            const double *tl = st.lead_tab + 4 * TILE * NSLOT;
+            const double *tt = st.trail_tab + 4 * TILE * NSLOT;
+            const uint64_t rowinc = (uint64_t)(2 * npad) * 4;
+            asm volatile(GARLIC_CHAIN_LOOP_ASM
+                         : [acc] "+v"(acc)
+                         : [lc] "v"(lc), [tc] "v"(tc), [lane] "v"(lane), [plead] "s"(pl),
+                           [ptrail] "s"(pt), [pltab] "s"(tl), [pttab] "s"(tt), [rowinc] "s"(rowinc),
+                           [out] "s"(out_tile), [ntiles] "s"(ntiles), [shl] "s"(st.sh_lead),
+                           [sht] "s"(st.sh_trail), [npad4] "s"((uint32_t)(npad * 4)),
+                           [pitch8] "s"((uint32_t)(pitch * 8))
+                         : GARLIC_CHAIN_LOOP_CLOBBERS);
+            st.lead_row += (int64_t)(2 * ntiles) * npad;
+            st.trail_row += (int64_t)(2 * ntiles) * npad;
+            st.lead_tab += (int64_t)(4 * TILE) * ntiles;
+            st.trail_tab += (int64_t)(4 * TILE) * ntiles;
+            s0 += ntiles * TILE;
+            out_tile += (int64_t)ntiles * TILE;
         }
     }
+    } // next item
 }
 
 } // namespace garlic

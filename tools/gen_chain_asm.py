@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Generates garlic_amd/csrc/chain_loop_gfx950.inc: the hand-scheduled steady-state loop of the LOD
+chain kernel (one inline-asm block, gfx950 / wave64).
+
+Why hand-scheduled: one wavefront issues roughly one instruction every 4 cycles and C2-sized
+panels only offer about one wavefront per SIMD, so the longest SNP run is an instruction-count and
+latency problem.  hipcc serialises  ds_read -> s_waitcnt -> v_add_f64  per step (one LDS round
+trip per window) and each transposed row read against its store; here every LDS read is issued
+one 8-step batch (or 16 instructions) ahead of its use and all waits are counted.
+
+Per tile (32 window starts x 64 individuals), software pipeline over 8-step batches g:
+    A(g)  2 VALU per term: byte offset (genotype*8) of the entering / leaving term in its table row
+    R(g)  16 ds_read_b64 of the batch's terms into one of two 32-VGPR buffers
+    C(g)  the dependent FP64 chain  acc = (acc - t_out) + t_in  (two roundings, reference
+          src/garlic-roh.cpp:98-100) + one ds_write_b128 per two steps into the transpose tile
+  iteration g:  wait R(g) | issue R(g+1) | C(g) interleaved with A(g+2)
+  tile level:   vmcnt(60) + genotype-word reads of tile k+1 in batch 1, funnel shift in batch 2,
+                LDS-DMA prefetch of tile k+4 into the slot tile k just finished in batch 3,
+                then 16 x (ds_read_b128 -> global_store_dwordx4): 4 rows x 256 B per store.
+VMEM ops retire in order per wave: the inputs of tile k+1 were requested 3 tiles earlier, before
+48 stores and 12 younger requests, hence vmcnt(60) leaves 3 tiles of stores in flight.
+
+LDS map (must match lod_kernels.hpp): 4 slots x 3072 B at offset 0, transpose tile at 12288.
+"""
+import os
+
+NSLOT = 4
+SLOT = 3072
+SL_LW1, SL_LW2, SL_TW1, SL_TW2, SL_LTAB, SL_TTAB = 0, 256, 512, 768, 1024, 2048
+TILE_BASE = NSLOT * SLOT
+TPITCH_B = 34 * 8
+
+# ---- fixed VGPRs (clobbered by the block)
+V_BUF = [100, 132]          # two term buffers, 16 x 64-bit each
+V_ADDR = 164                # 16 LDS byte offsets
+V_ACC = 180                 # 4 VGPRs: P0 = [180:181], P1 = [182:183]
+V_LL, V_LH, V_TL, V_TH = 184, 185, 186, 187
+V_WL1, V_WL2, V_WT1, V_WT2 = 188, 189, 190, 191
+V_LANE4, V_LANE16, V_VOFFA, V_VOFFB, V_TWR, V_TRD = 192, 193, 194, 195, 196, 197
+V_STOFF = 198               # 16 store offsets
+V_ST = 24                   # 64 VGPRs of store data: v24..v87
+V_LC, V_TC = 214, 215
+# ---- fixed SGPRs
+S_PLEAD, S_PTRAIL, S_PLTAB, S_PTTAB = 40, 42, 44, 46
+S_ROWINC = 48               # 2*npad*4 bytes
+S_OUT = 50
+S_CNT = 52
+S_SHL, S_SHT = 53, 54
+S_TMP = 55
+
+CLOBBER_V = sorted(set(list(range(V_ST, V_ST + 64)) + list(range(100, 216))))
+CLOBBER_S = list(range(40, 56))
+
+
+class Gen:
+    def __init__(self):
+        self.out = []
+        self.issued = 0
+        self.complete = 0
+
+    def emit(self, s):
+        self.out.append(s)
+
+    def lds(self, s):
+        self.out.append(s)
+        self.issued += 1
+        return self.issued
+
+    def wait_lds(self, op):
+        if op <= self.complete:
+            return
+        n = min(self.issued - op, 15)
+        self.emit(f"s_waitcnt lgkmcnt({n})")
+        self.complete = self.issued - n
+
+    def reset_lds(self):
+        assert self.complete == self.issued, "LDS queue must be drained at a tile boundary"
+        self.issued = self.complete = 0
+
+
+def pair(r):
+    return f"v[{r}:{r + 1}]"
+
+
+def quad(r):
+    return f"v[{r}:{r + 3}]"
+
+
+def addr_ops(j):
+    """the 4 VALU ops producing the LDS byte offsets of step j's leaving/entering terms"""
+    k = j % 16
+    lw, tw = (V_LL, V_TL) if j < 16 else (V_LH, V_TH)
+    i = j % 8
+    at, al = V_ADDR + 2 * i, V_ADDR + 2 * i + 1
+    ops = []
+    for dst, src in ((at, tw), (al, lw)):
+        if k == 0:
+            ops.append(f"v_lshlrev_b32_e32 v{dst}, 3, v{src}")
+        elif k == 1:
+            ops.append(f"v_lshlrev_b32_e32 v{dst}, 1, v{src}")
+        else:
+            ops.append(f"v_lshrrev_b32_e32 v{dst}, {2 * k - 3}, v{src}")
+        ops.append(f"v_and_b32_e32 v{dst}, 24, v{dst}")
+    return ops
+
+
+def gen_A(g, n):
+    for i in range(8):
+        for op in addr_ops(8 * n + i):
+            g.emit(op)
+
+
+def gen_R(g, slot, n):
+    """issue the 16 term reads of batch n of a tile living in `slot`; returns id of the last"""
+    buf = V_BUF[n % 2]
+    last = 0
+    for i in range(8):
+        j = 8 * n + i
+        g.lds(f"ds_read_b64 {pair(buf + 4 * i)}, v{V_ADDR + 2 * i} offset:{slot * SLOT + SL_TTAB + 32 * j}")
+        last = g.lds(f"ds_read_b64 {pair(buf + 4 * i + 2)}, v{V_ADDR + 2 * i + 1} offset:{slot * SLOT + SL_LTAB + 32 * j}")
+    return last
+
+
+def gen_C(g, n, a_ops):
+    """chain of batch n, the next-but-one batch's address ops woven in (2 after every add)"""
+    buf = V_BUF[n % 2]
+    a_ops = list(a_ops)
+    P0, P1 = V_ACC, V_ACC + 2
+    for i in range(8):
+        j = 8 * n + i
+        dst, prev = (P0, P1) if j % 2 == 0 else (P1, P0)
+        g.emit(f"v_add_f64 {pair(dst)}, {pair(prev)}, -{pair(buf + 4 * i)}")
+        for _ in range(2):
+            if a_ops:
+                g.emit(a_ops.pop(0))
+        g.emit(f"v_add_f64 {pair(dst)}, {pair(dst)}, {pair(buf + 4 * i + 2)}")
+        for _ in range(2):
+            if a_ops:
+                g.emit(a_ops.pop(0))
+        if j % 2 == 1:
+            g.lds(f"ds_write_b128 v{V_TWR}, {quad(V_ACC)} offset:{8 * (j - 1)}")
+    assert not a_ops
+
+
+def all_addr_ops(n):
+    ops = []
+    for i in range(8):
+        ops += addr_ops(8 * n + i)
+    return ops
+
+
+def gen_words(g, slot):
+    b = (slot * SLOT) // 256
+    g.lds(f"ds_read2st64_b32 v[{V_WL1}:{V_WL2}], v{V_LANE4} offset0:{b + SL_LW1 // 256} offset1:{b + SL_LW2 // 256}")
+    return g.lds(f"ds_read2st64_b32 v[{V_WT1}:{V_WT2}], v{V_LANE4} offset0:{b + SL_TW1 // 256} offset1:{b + SL_TW2 // 256}")
+
+
+def gen_funnel(g):
+    g.emit(f"v_alignbit_b32 v{V_LL}, v{V_WL1}, v{V_LC}, s{S_SHL}")
+    g.emit(f"v_alignbit_b32 v{V_LH}, v{V_WL2}, v{V_WL1}, s{S_SHL}")
+    g.emit(f"v_alignbit_b32 v{V_TL}, v{V_WT1}, v{V_TC}, s{S_SHT}")
+    g.emit(f"v_alignbit_b32 v{V_TH}, v{V_WT2}, v{V_WT1}, s{S_SHT}")
+    g.emit(f"v_mov_b32_e32 v{V_LC}, v{V_WL2}")
+    g.emit(f"v_mov_b32_e32 v{V_TC}, v{V_WT2}")
+
+
+def gen_prefetch(g, slot):
+    """6 LDS-DMA requests for the tile 4 ahead into `slot`, then advance the prefetch pointers.
+    An SALU write of M0 needs a wait state before the LDS-DMA reads it: the pointer adds sit there."""
+    base = slot * SLOT
+    seq = [
+        (base + SL_LW1, f"global_load_lds_dword v{V_VOFFA}, s[{S_PLEAD}:{S_PLEAD + 1}]", None),
+        (base + SL_LW2, f"global_load_lds_dword v{V_VOFFB}, s[{S_PLEAD}:{S_PLEAD + 1}]", None),
+        (base + SL_TW1, f"global_load_lds_dword v{V_VOFFA}, s[{S_PTRAIL}:{S_PTRAIL + 1}]", None),
+        (base + SL_TW2, f"global_load_lds_dword v{V_VOFFB}, s[{S_PTRAIL}:{S_PTRAIL + 1}]", None),
+        (base + SL_LTAB, f"global_load_lds_dwordx4 v{V_LANE16}, s[{S_PLTAB}:{S_PLTAB + 1}]", None),
+        (base + SL_TTAB, f"global_load_lds_dwordx4 v{V_LANE16}, s[{S_PTTAB}:{S_PTTAB + 1}]", None),
+    ]
+    for m0, ld, _ in seq:
+        g.emit(f"s_mov_b32 m0, {m0}")
+        g.emit("s_nop 0")
+        g.emit(ld)
+    for p, inc in ((S_PLEAD, None), (S_PTRAIL, None), (S_PLTAB, 1024), (S_PTTAB, 1024)):
+        if inc is None:
+            g.emit(f"s_add_u32 s{p}, s{p}, s{S_ROWINC}")
+            g.emit(f"s_addc_u32 s{p + 1}, s{p + 1}, s{S_ROWINC + 1}")
+        else:
+            g.emit(f"s_add_u32 s{p}, s{p}, {inc}")
+            g.emit(f"s_addc_u32 s{p + 1}, s{p + 1}, 0")
+
+
+def gen_stores(g):
+    ids = []
+    for q in range(16):
+        ids.append(g.lds(f"ds_read_b128 {quad(V_ST + 4 * q)}, v{V_TRD} offset:{q * 4 * TPITCH_B}"))
+    for q in range(16):
+        g.wait_lds(ids[q])
+        g.emit(f"global_store_dwordx4 v{V_STOFF + q}, {quad(V_ST + 4 * q)}, s[{S_OUT}:{S_OUT + 1}]")
+    g.emit(f"s_add_u32 s{S_OUT}, s{S_OUT}, 256")
+    g.emit(f"s_addc_u32 s{S_OUT + 1}, s{S_OUT + 1}, 0")
+
+
+def gen_tile(g, slot):
+    nxt = (slot + 1) % NSLOT
+    g.emit(f"; ---- tile in slot {slot}")
+    g.reset_lds()
+    # batch 0: R(k,0) finished at the previous boundary
+    r1 = gen_R(g, slot, 1)
+    gen_C(g, 0, all_addr_ops(2))
+    # batch 1
+    g.emit("s_waitcnt vmcnt(60)")
+    words = gen_words(g, nxt)
+    g.wait_lds(r1)
+    r2 = gen_R(g, slot, 2)
+    gen_C(g, 1, all_addr_ops(3))
+    # batch 2: bits of tile k+1 replace those of tile k (A(k,3) is done)
+    g.wait_lds(r2)
+    assert words <= g.complete
+    gen_funnel(g)
+    r3 = gen_R(g, slot, 3)
+    gen_C(g, 2, all_addr_ops(0))
+    # batch 3: slot k is free once R(k,3) has landed
+    g.wait_lds(r3)
+    gen_prefetch(g, slot)
+    gen_R(g, nxt, 0)
+    gen_C(g, 3, all_addr_ops(1))
+    gen_stores(g)
+    assert g.complete == g.issued
+
+
+def gen_all():
+    g = Gen()
+    e = g.emit
+    e("; ---- setup: operands -> fixed registers")
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    e(f"s_mov_b64 s[{S_PLEAD}:{S_PLEAD + 1}], %[plead]")
+    e(f"s_mov_b64 s[{S_PTRAIL}:{S_PTRAIL + 1}], %[ptrail]")
+    e(f"s_mov_b64 s[{S_PLTAB}:{S_PLTAB + 1}], %[pltab]")
+    e(f"s_mov_b64 s[{S_PTTAB}:{S_PTTAB + 1}], %[pttab]")
+    e(f"s_mov_b64 s[{S_ROWINC}:{S_ROWINC + 1}], %[rowinc]")
+    e(f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], %[out]")
+    e(f"s_mov_b32 s{S_CNT}, %[ntiles]")
+    e(f"s_mov_b32 s{S_SHL}, %[shl]")
+    e(f"s_mov_b32 s{S_SHT}, %[sht]")
+    e(f"v_mov_b64 {pair(V_ACC + 2)}, %[acc]")
+    e(f"v_mov_b32_e32 v{V_LC}, %[lc]")
+    e(f"v_mov_b32_e32 v{V_TC}, %[tc]")
+    e(f"v_lshlrev_b32_e32 v{V_LANE4}, 2, %[lane]")
+    e(f"v_lshlrev_b32_e32 v{V_LANE16}, 4, %[lane]")
+    e(f"v_add_u32_e32 v{V_VOFFA}, %[npad4], v{V_LANE4}")
+    e(f"v_add_u32_e32 v{V_VOFFB}, %[npad4], v{V_VOFFA}")
+    # transpose tile: write address lane*272, read address (lane>>4)*272 + (lane&15)*16
+    e(f"v_mul_u32_u24_e32 v{V_TWR}, {TPITCH_B}, %[lane]")
+    e(f"v_add_u32_e32 v{V_TWR}, {TILE_BASE}, v{V_TWR}")
+    e(f"v_lshrrev_b32_e32 v{V_TRD}, 4, %[lane]")
+    e(f"v_and_b32_e32 v{V_STOFF}, 15, %[lane]")
+    e(f"v_lshlrev_b32_e32 v{V_STOFF}, 4, v{V_STOFF}")
+    # store offset of row group 0: (lane>>4)*pitch8 + (lane&15)*16 ; next groups += 4*pitch8
+    e(f"v_mul_u32_u24_e32 v{V_STOFF + 1}, {TPITCH_B}, v{V_TRD}")
+    e(f"v_add_u32_e32 v{V_STOFF + 1}, v{V_STOFF + 1}, v{V_STOFF}")
+    e(f"v_mul_lo_u32 v{V_TRD}, v{V_TRD}, %[pitch8]")
+    e(f"v_add_u32_e32 v{V_STOFF}, v{V_TRD}, v{V_STOFF}")
+    e(f"v_add_u32_e32 v{V_TRD}, {TILE_BASE}, v{V_STOFF + 1}")
+    e(f"s_lshl_b32 s{S_TMP}, %[pitch8], 2")
+    for q in range(1, 16):
+        e(f"v_add_u32_e32 v{V_STOFF + q}, s{S_TMP}, v{V_STOFF + q - 1}")
+    # ---- pipeline prologue for the first tile (slot 0)
+    e("; ---- prologue")
+    w = gen_words(g, 0)
+    g.wait_lds(w)
+    gen_funnel(g)
+    gen_A(g, 0)
+    r0 = gen_R(g, 0, 0)
+    gen_A(g, 1)
+    g.wait_lds(r0)
+    e("LOOP_%=:")
+    for slot in range(NSLOT):
+        gen_tile(g, slot)
+        e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+        e(f"s_cmp_eq_u32 s{S_CNT}, 0")
+        if slot < NSLOT - 1:
+            e("s_cbranch_scc1 DONE_%=")
+        else:
+            e("s_cbranch_scc0 LOOP_%=")
+    e("DONE_%=:")
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    e(f"v_mov_b64 %[acc], {pair(V_ACC + 2)}")
+    return g.out
+
+
+def main():
+    lines = gen_all()
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "..", "garlic_amd", "csrc", "chain_loop_gfx950.inc")
+    with open(path, "w") as f:
+        f.write("// GENERATED by tools/gen_chain_asm.py -- do not edit; see that file for the schedule.\n")
+        f.write("// One inline-asm block: steady-state loop of lod_chain_kernel (gfx950, wave64).\n")
+        f.write("#define GARLIC_CHAIN_LOOP_ASM \\\n")
+        for ln in lines:
+            if ln.startswith(";"):
+                continue
+            f.write('    "%s\\n\\t" \\\n' % ln)
+        f.write('    ""\n')
+        f.write("#define GARLIC_CHAIN_LOOP_CLOBBERS \\\n    ")
+        regs = ['"v%d"' % r for r in CLOBBER_V] + ['"s%d"' % r for r in CLOBBER_S]
+        regs += ['"memory"', '"scc"', '"vcc"']
+        chunks = [", ".join(regs[i:i + 12]) for i in range(0, len(regs), 12)]
+        f.write(", \\\n    ".join(chunks) + "\n")
+    n_instr = sum(1 for ln in lines if not ln.startswith(";") and not ln.endswith(":"))
+    print(f"wrote {path}: {n_instr} instructions")
+
+
+if __name__ == "__main__":
+    main()
