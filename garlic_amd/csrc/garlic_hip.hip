@@ -309,16 +309,12 @@ int launch_lod(garlic_panel *p, int32_t W, double error, int32_t max_gap, int32_
         const Run &r = runs[order[i]];
         for (int k = 0; k < nblk; k++) items.push_back(ChainItem{r.chr, r.a, r.b, k * WAVE});
     }
-    // Number of persistent waves.  Measured on MI355X (1M SNPs): with about 4 items per CU or
-    // fewer, ONE wave per CU is fastest -- two waves on a CU slow each other down (LDS store path)
-    // and every extra wave dilutes the HBM bandwidth the longest runs get while the short ones
-    // are still running, so the makespan becomes the longest run crawling at 1/n of the bandwidth
-    // and later alone at its latency-bound pace; LPT packing behind 256 waves keeps every wave busy
-    // to the end instead.  With many more items than CUs, filling the LDS (5 waves per CU) wins.
-    int workers = ((int64_t)items.size() >= 10 * 256) ? 5 * 256 : 256;
+    // Persistent workgroups (2 waves each: CHAIN + POST), one per CU by default; items are pulled
+    // longest first, so the short runs pack behind the long ones instead of competing with them
+    // for HBM bandwidth.  (LDS would allow 3 workgroups per CU.)
+    int workers = 256;
     if (const char *e = getenv("GARLIC_WORKERS")) workers = std::max(1, atoi(e));
     workers = std::min<int>(workers, (int)items.size());
-    workers = std::min(workers, 256 * 5); // LDS: 5 waves per CU are resident
 
     std::vector<ChrDev> chrs(p->nchr);
     for (int c = 0; c < p->nchr; c++)
@@ -357,10 +353,10 @@ int launch_lod(garlic_panel *p, int32_t W, double error, int32_t max_gap, int32_
         ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p,     p->d_chrs.p,     d_out, p->nind_pad,
                     ind_begin,     ind_count,  W,               (int32_t)items.size(), p->d_counter.p};
         if (aligned16)
-            hipLaunchKernelGGL(lod_chain_kernel<true>, dim3((unsigned)workers), dim3(WAVE), 0,
+            hipLaunchKernelGGL(lod_chain_kernel<true>, dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
                                ctx->stream, a);
         else
-            hipLaunchKernelGGL(lod_chain_kernel<false>, dim3((unsigned)workers), dim3(WAVE), 0,
+            hipLaunchKernelGGL(lod_chain_kernel<false>, dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
                                ctx->stream, a);
     }
     HIP_TRY(hipEventRecord(ctx->ev_k1, ctx->stream));

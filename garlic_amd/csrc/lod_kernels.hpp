@@ -239,18 +239,21 @@ struct ChainArgs {
     int32_t *next_item;       // device counter (zeroed per launch): the persistent waves' queue head
 };
 
-// LDS map (bytes), one wave per workgroup.
-//   4 input slots, one per tile in flight.  A slot holds what a tile needs from global memory:
-//     for each of the two SNP streams (entering / leaving the window) the genotype words +1 and
-//     +2 of every lane (word +0 is carried over in a register from the previous tile) and the
-//     32 term rows {lod(0),lod(1),lod(2),0.0} of the tile's SNPs;
-//   then the 64 x 32 transpose tile.
-constexpr int NSLOT = 4;
+// LDS map (bytes).  One workgroup = 2 waves (CHAIN + POST roles) working on one item; the hand-scheduled loop
+// (chain_loop_gfx950.inc, see tools/gen_chain_asm.py for the full map) owns everything from 4096
+// on; the compiler-generated "generic" tile path used for a run's first and last tiles keeps its
+// inputs in the slot at 0 and transposes through TILE buffer 0.
+//   slot: for each of the two SNP streams (entering / leaving the window) the genotype words +1
+//   and +2 of every lane (word +0 is carried in a register) and the 32 term rows
+//   {lod(0),lod(1),lod(2),0.0} of the tile's SNPs.
+constexpr int NSLOT = 1;
 constexpr uint32_t SLOT_BYTES = 3072;
 constexpr uint32_t SL_LW1 = 0, SL_LW2 = 256, SL_TW1 = 512, SL_TW2 = 768;
 constexpr uint32_t SL_LTAB = 1024, SL_TTAB = 2048;
-constexpr uint32_t LDS_TILE = NSLOT * SLOT_BYTES;               // transpose tile, 64 rows x 272 B
-constexpr uint32_t LDS_BYTES = LDS_TILE + WAVE * TPITCH * 8;
+constexpr uint32_t LDS_ITEM = 3072;                              // broadcast word for the item index
+constexpr uint32_t LDS_TILE = 22528;                             // TILE buffer 0 of the asm loop
+constexpr uint32_t LDS_BYTES = GARLIC_CHAIN_LDS_TOTAL;
+constexpr int CHAIN_THREADS = 128;
 
 // Wave-uniform stream state (lives in SGPRs).
 struct Streams {
@@ -264,37 +267,6 @@ __device__ __forceinline__ void advance(Streams &st)
 {   // next tile = two genotype words and 32 term rows further along both streams
     st.lead_row += 2 * st.npad; st.trail_row += 2 * st.npad;
     st.lead_tab += 4 * TILE; st.trail_tab += 4 * TILE;
-}
-
-// LDS-DMA: 64 lanes x 4 B (or 16 B) from  base + lane_off  straight into LDS at  lds_addr +
-// lane * size, no VGPR destination.  Issued from inline asm on purpose: the compiler must not
-// know about these loads (it would guard every later LDS read with vmcnt(0) and drain the
-// store queue); the waits are hand-counted below.  s_nop: an SALU write of M0 needs one wait
-// state before an LDS-DMA instruction reads it (gfx9 family), and nothing pads inline asm.
-__device__ __forceinline__ void glds_b32(uint32_t lds_addr, uint32_t lane_off, const void *base)
-{
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
-                 :: "s"(lds_addr), "v"(lane_off), "s"(base) : "memory");
-}
-__device__ __forceinline__ void glds_b128(uint32_t lds_addr, uint32_t lane_off, const void *base)
-{
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                 :: "s"(lds_addr), "v"(lane_off), "s"(base) : "memory");
-}
-
-// 6 LDS-DMA requests for the tile `ahead` tiles after the current one, into slot SLOT
-template <int SLOT>
-__device__ __forceinline__ void fill_dma(const Streams &st, int ahead, uint32_t lds0, int lane)
-{
-    const uint32_t slot = lds0 + SLOT * SLOT_BYTES;
-    const uint32_t *lw = st.lead_row + (int64_t)(2 * ahead + 1) * st.npad;
-    const uint32_t *tw = st.trail_row + (int64_t)(2 * ahead + 1) * st.npad;
-    glds_b32(slot + SL_LW1, lane * 4, lw);
-    glds_b32(slot + SL_LW2, lane * 4, lw + st.npad);
-    glds_b32(slot + SL_TW1, lane * 4, tw);
-    glds_b32(slot + SL_TW2, lane * 4, tw + st.npad);
-    glds_b128(slot + SL_LTAB, lane * 16, st.lead_tab + 4 * TILE * ahead);
-    glds_b128(slot + SL_TTAB, lane * 16, st.trail_tab + 4 * TILE * ahead);
 }
 
 // same content through registers (compiler-managed waits): head / leftover tiles
@@ -401,23 +373,25 @@ __device__ __forceinline__ void tile_store(const unsigned char *tile, int s0, in
 }
 
 template <bool ALIGNED16>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(CHAIN_THREADS)
 lod_chain_kernel(ChainArgs p)
 {
     // one LDS object at offset 0: the hand-scheduled loop addresses it with absolute offsets
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     unsigned char *tile = smem + LDS_TILE;
-    const int lane = threadIdx.x;
-    // Persistent wave: pulls (run, 64-individual block) items, longest runs first, from one
-    // device-wide counter.  The host launches only about as many waves as it takes to saturate
-    // HBM (see launch_lod): with every item resident at once all waves share the bandwidth
-    // equally, the short runs finish early and the long ones are left running alone at their
-    // latency-bound pace; with few waves the long runs run at full speed from the start and the
-    // short ones are packed behind each other.
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Persistent workgroup: pulls (run, 64-individual block) items, longest runs
+    // first, from one device-wide counter.  Wave 2 owns the accumulator: it sums the run's first
+    // window and runs the first / last (partial) tiles through the compiler-generated path; all
+    // full tiles go through the 2-role hand-scheduled loop.
     for (;;) {
-    int item_idx = 0;
-    if (lane == 0) item_idx = atomicAdd(p.next_item, 1);
-    item_idx = __builtin_amdgcn_readfirstlane(item_idx);
+    if (threadIdx.x == 0)
+        *reinterpret_cast<volatile int *>(smem + LDS_ITEM) = atomicAdd(p.next_item, 1);
+    __syncthreads();
+    const int item_idx =
+        __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(smem + LDS_ITEM));
+    __syncthreads();
     if (item_idx >= p.n_items) return;
     const ChainItem it = p.items[item_idx];
     const ChrDev c = p.chrs[it.chr];
@@ -429,12 +403,11 @@ lod_chain_kernel(ChainArgs p)
     const uint32_t *gcol = p.packed + col0 + lane;
     const int64_t npad = p.nind_pad;
     const int64_t Gbase = c.loc_base + GOFF; // global (padded) index of chromosome-local locus 0
-    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 
     // ---- first window of the run: sum of W terms left to right (garlic-roh.cpp:57-71); the
     //      first W-1 of them here, the W-th enters in the first tile below.
     double acc = 0.0;
-    {
+    if (wave == 0) {
         int l = a;
         const int lend = a + W - 1;
         while (l < lend) {
@@ -472,55 +445,48 @@ lod_chain_kernel(ChainArgs p)
     }
     double *out_tile = p.out + c.out_base + (int64_t)it.ind0 * c.out_pitch + s0;
     const int64_t pitch = c.out_pitch;
-    uint32_t lc, tc;
 
     // phase 0: the head tile alone, masked variant (the run's first window has no leaving term,
-    //          even when the run starts exactly on a tile boundary);
-    //          then the bulk: all full tiles in the hand-scheduled loop;
+    //          even when the run starts exactly on a tile boundary); then all full tiles in the
+    //          hand-scheduled loop;
     // phase 1: whatever is left (the partial tail tile; everything when the layout is not
     //          eligible for the fast loop), masked variant.
     for (int phase = 0; phase < 2; phase++) {
         const int last = (phase == 0) ? s0 : b;
         while (s0 <= last && s0 <= b) {
-            lc = st.lead_row[lane];
-            tc = st.trail_row[lane];
-            fill_regs(smem, st, lane);
-            const TileBits tb = tile_consume<0>(smem, lc, tc, st, lane);
-            tile_steps<true, 0>(smem, tile, acc, tb, s0, a, b, lane);
-            tile_store<true, ALIGNED16>(tile, s0, a, b, lane, rows_valid, out_tile, pitch);
+            if (wave == 0) {
+                uint32_t lc = st.lead_row[lane];
+                uint32_t tc = st.trail_row[lane];
+                fill_regs(smem, st, lane);
+                const TileBits tb = tile_consume<0>(smem, lc, tc, st, lane);
+                tile_steps<true, 0>(smem, tile, acc, tb, s0, a, b, lane);
+                tile_store<true, ALIGNED16>(tile, s0, a, b, lane, rows_valid, out_tile, pitch);
+            }
             advance(st);
             s0 += TILE;
             out_tile += TILE;
         }
         if (phase == 1 || !ALIGNED16 || !c.fast) continue;
 
-        // Bulk: every full tile of the run in one hand-scheduled block (chain_loop_gfx950.inc,
-        // generated by tools/gen_chain_asm.py).  A wave's vector-memory operations retire in issue
-        // order, so an input load only "completes" once every older store has been acknowledged;
-        // the inputs of tile k+4 are therefore requested (LDS-DMA into the 4-slot ring) before the
-        // stores of tile k, and the wait for tile k+1's inputs is the counted vmcnt(60) that leaves
-        // the 48 stores of 3 tiles in flight.
         int ntiles = (b + 1 - s0) / TILE;
         if (ntiles >= 2) {
-            lc = st.lead_row[lane];
-            tc = st.trail_row[lane];
-            asm volatile("" : "+v"(lc), "+v"(tc)); // compiler-visible loads are waited for here
-            fill_dma<0>(st, 0, lds0, lane);
-            fill_dma<1>(st, 1, lds0, lane);
-            fill_dma<2>(st, 2, lds0, lane);
-            fill_dma<3>(st, 3, lds0, lane);
-            const uint32_t *pl = st.lead_row + 2 * NSLOT * npad;   // tile 4: prefetched in the loop
-            const uint32_t *pt = st.trail_row + 2 * NSLOT * npad;
-            const double *tl = st.lead_tab + 4 * TILE * NSLOT;
-            const double *tt = st.trail_tab + 4 * TILE * NSLOT;
             const uint64_t rowinc = (uint64_t)(2 * npad) * 4;
+            uint32_t lc = 0, tc = 0; // genotype word +0 of the first full tile (CHAIN role only)
+            if (wave == 0) {
+                lc = st.lead_row[lane];
+                tc = st.trail_row[lane];
+            }
+            // both waves enter together; the block starts by draining each wave's own memory
+            // operations, its stage barriers order the LDS hand-offs (TILE buffer 0 above
+            // included: the loop first writes it two barriers in)
             asm volatile(GARLIC_CHAIN_LOOP_ASM
                          : [acc] "+v"(acc)
-                         : [lc] "v"(lc), [tc] "v"(tc), [lane] "v"(lane), [plead] "s"(pl),
-                           [ptrail] "s"(pt), [pltab] "s"(tl), [pttab] "s"(tt), [rowinc] "s"(rowinc),
-                           [out] "s"(out_tile), [ntiles] "s"(ntiles), [shl] "s"(st.sh_lead),
-                           [sht] "s"(st.sh_trail), [npad4] "s"((uint32_t)(npad * 4)),
-                           [pitch8] "s"((uint32_t)(pitch * 8))
+                         : [wave] "s"(wave), [lane] "v"(lane), [lc] "v"(lc), [tc] "v"(tc),
+                           [plead] "s"(st.lead_row),
+                           [ptrail] "s"(st.trail_row), [pltab] "s"(st.lead_tab),
+                           [pttab] "s"(st.trail_tab), [rowinc] "s"(rowinc), [out] "s"(out_tile),
+                           [ntiles] "s"(ntiles), [shl] "s"(st.sh_lead), [sht] "s"(st.sh_trail),
+                           [npad4] "s"((uint32_t)(npad * 4)), [pitch8] "s"((uint32_t)(pitch * 8))
                          : GARLIC_CHAIN_LOOP_CLOBBERS);
             st.lead_row += (int64_t)(2 * ntiles) * npad;
             st.trail_row += (int64_t)(2 * ntiles) * npad;
@@ -528,6 +494,7 @@ lod_chain_kernel(ChainArgs p)
             st.trail_tab += (int64_t)(4 * TILE) * ntiles;
             s0 += ntiles * TILE;
             out_tile += (int64_t)ntiles * TILE;
+            __syncthreads(); // the tail tile reuses LDS regions the loop's roles were reading
         }
     }
     } // next item

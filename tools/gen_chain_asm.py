@@ -1,34 +1,52 @@
 #!/usr/bin/env python3
 """Generates garlic_amd/csrc/chain_loop_gfx950.inc: the hand-scheduled steady-state loop of the LOD
-chain kernel (one inline-asm block, gfx950 / wave64).
+chain kernel -- ONE inline-asm block executed by the 2 wavefronts of a workgroup, each in its own
+role (gfx950, wave64; one workgroup = one (SNP run, 64 individuals) item at a time).
 
-Why hand-scheduled: one wavefront issues roughly one instruction every 4 cycles and C2-sized
-panels only offer about one wavefront per SIMD, so the longest SNP run is an instruction-count and
-latency problem.  hipcc serialises  ds_read -> s_waitcnt -> v_add_f64  per step (one LDS round
-trip per window) and each transposed row read against its store; here every LDS read is issued
-one 8-step batch (or 16 instructions) ahead of its use and all waits are counted.
+Why hand-scheduled, why two roles: a single wavefront issues about one instruction every 4 cycles,
+and a ds_write_b128 / global_store_dwordx4 blocks it for ~28 / ~38 cycles (tools/ubench/
+issue_rates.hip).  A C2-sized panel has only ~4 items per CU, so the job is bound by the
+instruction stream of the longest SNP run, not by HBM.  hipcc serialises ds_read -> s_waitcnt ->
+v_add_f64 per step; here every LDS read is issued an 8-step batch ahead and all waits are counted.
+Splitting further (separate look-up waves handing terms over through LDS) was measured SLOWER:
+the extra LDS traffic saturates the CU's LDS pipeline.
 
-Per tile (32 window starts x 64 individuals), software pipeline over 8-step batches g:
-    A(g)  2 VALU per term: byte offset (genotype*8) of the entering / leaving term in its table row
-    R(g)  16 ds_read_b64 of the batch's terms into one of two 32-VGPR buffers
-    C(g)  the dependent FP64 chain  acc = (acc - t_out) + t_in  (two roundings, reference
-          src/garlic-roh.cpp:98-100) + one ds_write_b128 per two steps into the transpose tile
-  iteration g:  wait R(g) | issue R(g+1) | C(g) interleaved with A(g+2)
-  tile level:   vmcnt(60) + genotype-word reads of tile k+1 in batch 1, funnel shift in batch 2,
-                LDS-DMA prefetch of tile k+4 into the slot tile k just finished in batch 3,
-                then 16 x (ds_read_b128 -> global_store_dwordx4): 4 rows x 256 B per store.
-VMEM ops retire in order per wave: the inputs of tile k+1 were requested 3 tiles earlier, before
-48 stores and 12 younger requests, hence vmcnt(60) leaves 3 tiles of stores in flight.
+  wave 0  CHAIN  2-bit extract (2 VALU per term), term look-up (ds_read_b64), the dependent FP64
+                 chain acc = (acc - t_out) + t_in (two roundings, reference
+                 src/garlic-roh.cpp:98-100), acc -> transpose tile (ds_write_b128 per 2 steps)
+                 -- no vector-memory instruction at all: a request of its own would queue behind
+                 POST's stores in the CU's memory pipeline and stall the chain (measured: +30 %)
+  wave 1  POST   LDS-DMA prefetch of CHAIN's genotype words / term rows (6-slot ring, requested
+                 5 tiles ahead, confirmed landed 2 tiles ahead); transposed write-out of the
+                 previous tile: 16 x (ds_read_b128 -> global_store_dwordx4), 4 rows x 256 B each
 
-LDS map (must match lod_kernels.hpp): 4 slots x 3072 B at offset 0, transpose tile at 12288.
+CHAIN per tile (32 window starts x 64 individuals), software pipeline over 8-step batches g:
+    A(g)  byte offsets (genotype*8) of the batch's entering / leaving terms in their table rows
+    R(g)  16 ds_read_b64 into one of two 32-VGPR buffers
+    C(g)  the chain + tile writes, with A(g+2) woven in
+  iteration g:  wait R(g) | issue R(g+1) | C(g) (+) A(g+2);   one s_barrier per tile; the
+  transpose tile is double buffered (CHAIN writes tile k while POST stores tile k-1).
+POST's vector-memory operations retire in issue order; per stage it waits vmcnt(60) (= the 3 x 16
+stores and 2 x 6 requests younger than the tile-after-next's inputs stay in flight), requests the
+inputs 5 tiles ahead, then stores.
+
+LDS map (bytes; must match lod_kernels.hpp):
+      0  generic-path slot (3072) + item word           (not touched here)
+   4096  ring: 6 slots x 3072 {lead w+1, lead w+2, trail w+1, trail w+2 (256 each),
+                               lead term rows 1024, trail term rows 1024}
+  22528  TILE[2][64 rows x 272 B]
 """
 import os
+ABL = os.environ.get("GARLIC_ABLATE", "")
 
-NSLOT = 4
+NSLOT = 6
+RING = 4096
 SLOT = 3072
 SL_LW1, SL_LW2, SL_TW1, SL_TW2, SL_LTAB, SL_TTAB = 0, 256, 512, 768, 1024, 2048
-TILE_BASE = NSLOT * SLOT
+TILE_BASE = RING + NSLOT * SLOT
+TILE_BUF = 64 * 34 * 8
 TPITCH_B = 34 * 8
+LDS_TOTAL = TILE_BASE + 2 * TILE_BUF
 
 # ---- fixed VGPRs (clobbered by the block)
 V_BUF = [100, 132]          # two term buffers, 16 x 64-bit each
@@ -116,12 +134,12 @@ def gen_R(g, slot, n):
     last = 0
     for i in range(8):
         j = 8 * n + i
-        g.lds(f"ds_read_b64 {pair(buf + 4 * i)}, v{V_ADDR + 2 * i} offset:{slot * SLOT + SL_TTAB + 32 * j}")
-        last = g.lds(f"ds_read_b64 {pair(buf + 4 * i + 2)}, v{V_ADDR + 2 * i + 1} offset:{slot * SLOT + SL_LTAB + 32 * j}")
+        g.lds(f"ds_read_b64 {pair(buf + 4 * i)}, v{V_ADDR + 2 * i} offset:{RING + slot * SLOT + SL_TTAB + 32 * j}")
+        last = g.lds(f"ds_read_b64 {pair(buf + 4 * i + 2)}, v{V_ADDR + 2 * i + 1} offset:{RING + slot * SLOT + SL_LTAB + 32 * j}")
     return last
 
 
-def gen_C(g, n, a_ops):
+def gen_C(g, n, a_ops, tbuf):
     """chain of batch n, the next-but-one batch's address ops woven in (2 after every add)"""
     buf = V_BUF[n % 2]
     a_ops = list(a_ops)
@@ -138,7 +156,8 @@ def gen_C(g, n, a_ops):
             if a_ops:
                 g.emit(a_ops.pop(0))
         if j % 2 == 1:
-            g.lds(f"ds_write_b128 v{V_TWR}, {quad(V_ACC)} offset:{8 * (j - 1)}")
+            if "chainwrite" not in ABL:
+                g.lds(f"ds_write_b128 v{V_TWR}, {quad(V_ACC)} offset:{tbuf * TILE_BUF + 8 * (j - 1)}")
     assert not a_ops
 
 
@@ -150,7 +169,7 @@ def all_addr_ops(n):
 
 
 def gen_words(g, slot):
-    b = (slot * SLOT) // 256
+    b = (RING + slot * SLOT) // 256
     g.lds(f"ds_read2st64_b32 v[{V_WL1}:{V_WL2}], v{V_LANE4} offset0:{b + SL_LW1 // 256} offset1:{b + SL_LW2 // 256}")
     return g.lds(f"ds_read2st64_b32 v[{V_WT1}:{V_WT2}], v{V_LANE4} offset0:{b + SL_TW1 // 256} offset1:{b + SL_TW2 // 256}")
 
@@ -167,7 +186,7 @@ def gen_funnel(g):
 def gen_prefetch(g, slot):
     """6 LDS-DMA requests for the tile 4 ahead into `slot`, then advance the prefetch pointers.
     An SALU write of M0 needs a wait state before the LDS-DMA reads it: the pointer adds sit there."""
-    base = slot * SLOT
+    base = RING + slot * SLOT
     seq = [
         (base + SL_LW1, f"global_load_lds_dword v{V_VOFFA}, s[{S_PLEAD}:{S_PLEAD + 1}]", None),
         (base + SL_LW2, f"global_load_lds_dword v{V_VOFFB}, s[{S_PLEAD}:{S_PLEAD + 1}]", None),
@@ -189,56 +208,40 @@ def gen_prefetch(g, slot):
             g.emit(f"s_addc_u32 s{p + 1}, s{p + 1}, 0")
 
 
-def gen_stores(g):
-    ids = []
-    for q in range(16):
-        ids.append(g.lds(f"ds_read_b128 {quad(V_ST + 4 * q)}, v{V_TRD} offset:{q * 4 * TPITCH_B}"))
-    for q in range(16):
-        g.wait_lds(ids[q])
-        g.emit(f"global_store_dwordx4 v{V_STOFF + q}, {quad(V_ST + 4 * q)}, s[{S_OUT}:{S_OUT + 1}]")
-    g.emit(f"s_add_u32 s{S_OUT}, s{S_OUT}, 256")
-    g.emit(f"s_addc_u32 s{S_OUT + 1}, s{S_OUT + 1}, 0")
-
-
 def gen_tile(g, slot):
     nxt = (slot + 1) % NSLOT
+    tbuf = slot % 2
+    if "nochain" in ABL:
+        g.emit("s_barrier")
+        return
     g.emit(f"; ---- tile in slot {slot}")
     g.reset_lds()
     # batch 0: R(k,0) finished at the previous boundary
     r1 = gen_R(g, slot, 1)
-    gen_C(g, 0, all_addr_ops(2))
-    # batch 1
-    g.emit("s_waitcnt vmcnt(60)")
+    gen_C(g, 0, all_addr_ops(2), tbuf)
+    # batch 1 (POST confirmed the next tile's inputs before the previous barrier)
     words = gen_words(g, nxt)
     g.wait_lds(r1)
     r2 = gen_R(g, slot, 2)
-    gen_C(g, 1, all_addr_ops(3))
+    gen_C(g, 1, all_addr_ops(3), tbuf)
     # batch 2: bits of tile k+1 replace those of tile k (A(k,3) is done)
     g.wait_lds(r2)
     assert words <= g.complete
     gen_funnel(g)
     r3 = gen_R(g, slot, 3)
-    gen_C(g, 2, all_addr_ops(0))
+    gen_C(g, 2, all_addr_ops(0), tbuf)
     # batch 3: slot k is free once R(k,3) has landed
     g.wait_lds(r3)
-    gen_prefetch(g, slot)
     gen_R(g, nxt, 0)
-    gen_C(g, 3, all_addr_ops(1))
-    gen_stores(g)
-    assert g.complete == g.issued
+    gen_C(g, 3, all_addr_ops(1), tbuf)
+    g.emit("s_waitcnt lgkmcnt(0)")
+    g.complete = g.issued
+    g.emit("s_barrier")
 
 
-def gen_all():
-    g = Gen()
+def gen_chain(g):
     e = g.emit
-    e("; ---- setup: operands -> fixed registers")
-    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    e(f"s_mov_b64 s[{S_PLEAD}:{S_PLEAD + 1}], %[plead]")
-    e(f"s_mov_b64 s[{S_PTRAIL}:{S_PTRAIL + 1}], %[ptrail]")
-    e(f"s_mov_b64 s[{S_PLTAB}:{S_PLTAB + 1}], %[pltab]")
-    e(f"s_mov_b64 s[{S_PTTAB}:{S_PTTAB + 1}], %[pttab]")
-    e(f"s_mov_b64 s[{S_ROWINC}:{S_ROWINC + 1}], %[rowinc]")
-    e(f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], %[out]")
+    e("ROLE_CHAIN_%=:")
     e(f"s_mov_b32 s{S_CNT}, %[ntiles]")
     e(f"s_mov_b32 s{S_SHL}, %[shl]")
     e(f"s_mov_b32 s{S_SHT}, %[sht]")
@@ -246,16 +249,72 @@ def gen_all():
     e(f"v_mov_b32_e32 v{V_LC}, %[lc]")
     e(f"v_mov_b32_e32 v{V_TC}, %[tc]")
     e(f"v_lshlrev_b32_e32 v{V_LANE4}, 2, %[lane]")
+    e(f"v_mul_u32_u24_e32 v{V_TWR}, {TPITCH_B}, %[lane]")
+    e(f"v_add_u32_e32 v{V_TWR}, {TILE_BASE}, v{V_TWR}")
+    e("s_barrier")  # POST has filled the ring with the first 5 tiles
+    # pipeline prologue for the first tile (slot 0)
+    w = gen_words(g, 0)
+    g.wait_lds(w)
+    gen_funnel(g)
+    gen_A(g, 0)
+    r0 = gen_R(g, 0, 0)
+    gen_A(g, 1)
+    g.wait_lds(r0)
+    e("CHAIN_LOOP_%=:")
+    for slot in range(NSLOT):
+        gen_tile(g, slot)
+        e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+        e(f"s_cmp_eq_u32 s{S_CNT}, 0")
+        if slot < NSLOT - 1:
+            e("s_cbranch_scc1 CHAIN_DONE_%=")
+        else:
+            e("s_cbranch_scc0 CHAIN_LOOP_%=")
+    e("CHAIN_DONE_%=:")
+    e("s_barrier")  # POST stores the last tile
+    e(f"v_mov_b64 %[acc], {pair(V_ACC + 2)}")
+    e("s_branch DONE_%=")
+
+
+def post_stage(g, slot_next, tbuf, store=True, drain=False):
+    """one POST stage: confirm the inputs CHAIN touches next stage, request the tile 5 ahead into the
+    slot CHAIN released last stage, store the tile CHAIN finished last stage"""
+    g.reset_lds()
+    g.emit("s_waitcnt vmcnt(60)")
+    gen_prefetch(g, slot_next)
+    if drain:
+        g.emit("s_waitcnt vmcnt(0)")
+    if store and "nopost" not in ABL:
+        ids = []
+        for q in range(16):
+            ids.append(g.lds(f"ds_read_b128 {quad(V_ST + 4 * q)}, v{V_TRD} offset:{tbuf * TILE_BUF + q * 4 * TPITCH_B}"))
+        for q in range(16):
+            g.wait_lds(ids[q])
+            if "poststore" not in ABL:
+                g.emit(f"global_store_dwordx4 v{V_STOFF + q}, {quad(V_ST + 4 * q)}, s[{S_OUT}:{S_OUT + 1}]")
+        g.emit(f"s_add_u32 s{S_OUT}, s{S_OUT}, 256")
+        g.emit(f"s_addc_u32 s{S_OUT + 1}, s{S_OUT + 1}, 0")
+    assert g.complete == g.issued
+    g.emit("s_barrier")
+
+
+def gen_post(g):
+    e = g.emit
+    e("ROLE_POST_%=:")
+    e(f"s_mov_b64 s[{S_PLEAD}:{S_PLEAD + 1}], %[plead]")
+    e(f"s_mov_b64 s[{S_PTRAIL}:{S_PTRAIL + 1}], %[ptrail]")
+    e(f"s_mov_b64 s[{S_PLTAB}:{S_PLTAB + 1}], %[pltab]")
+    e(f"s_mov_b64 s[{S_PTTAB}:{S_PTTAB + 1}], %[pttab]")
+    e(f"s_mov_b64 s[{S_ROWINC}:{S_ROWINC + 1}], %[rowinc]")
+    e(f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], %[out]")
+    e(f"s_mov_b32 s{S_CNT}, %[ntiles]")
+    e(f"v_lshlrev_b32_e32 v{V_LANE4}, 2, %[lane]")
     e(f"v_lshlrev_b32_e32 v{V_LANE16}, 4, %[lane]")
     e(f"v_add_u32_e32 v{V_VOFFA}, %[npad4], v{V_LANE4}")
     e(f"v_add_u32_e32 v{V_VOFFB}, %[npad4], v{V_VOFFA}")
-    # transpose tile: write address lane*272, read address (lane>>4)*272 + (lane&15)*16
-    e(f"v_mul_u32_u24_e32 v{V_TWR}, {TPITCH_B}, %[lane]")
-    e(f"v_add_u32_e32 v{V_TWR}, {TILE_BASE}, v{V_TWR}")
+    # tile read address (lane>>4)*272 + (lane&15)*16 ; store offset (lane>>4)*pitch8 + (lane&15)*16
     e(f"v_lshrrev_b32_e32 v{V_TRD}, 4, %[lane]")
     e(f"v_and_b32_e32 v{V_STOFF}, 15, %[lane]")
     e(f"v_lshlrev_b32_e32 v{V_STOFF}, 4, v{V_STOFF}")
-    # store offset of row group 0: (lane>>4)*pitch8 + (lane&15)*16 ; next groups += 4*pitch8
     e(f"v_mul_u32_u24_e32 v{V_STOFF + 1}, {TPITCH_B}, v{V_TRD}")
     e(f"v_add_u32_e32 v{V_STOFF + 1}, v{V_STOFF + 1}, v{V_STOFF}")
     e(f"v_mul_lo_u32 v{V_TRD}, v{V_TRD}, %[pitch8]")
@@ -264,27 +323,39 @@ def gen_all():
     e(f"s_lshl_b32 s{S_TMP}, %[pitch8], 2")
     for q in range(1, 16):
         e(f"v_add_u32_e32 v{V_STOFF + q}, s{S_TMP}, v{V_STOFF + q - 1}")
-    # ---- pipeline prologue for the first tile (slot 0)
-    e("; ---- prologue")
-    w = gen_words(g, 0)
-    g.wait_lds(w)
-    gen_funnel(g)
-    gen_A(g, 0)
-    r0 = gen_R(g, 0, 0)
-    gen_A(g, 1)
-    g.wait_lds(r0)
-    e("LOOP_%=:")
-    for slot in range(NSLOT):
-        gen_tile(g, slot)
+    # ring: tiles 0..4 -> slots 0..4, all landed before CHAIN starts
+    for slot in range(NSLOT - 1):
+        gen_prefetch(g, slot)
+    e("s_waitcnt vmcnt(0)")
+    e("s_barrier")
+    # stage 0 (CHAIN runs tile 0): request tile 5 into slot 5 and let it land (the counted wait of
+    # the steady state only confirms a request once 60 younger operations exist); nothing to store
+    post_stage(g, NSLOT - 1, 0, store=False, drain=True)
+    e("POST_LOOP_%=:")
+    # stage s = 1..: CHAIN runs tile s; request tile s+5 into slot (s-1)%6, store tile s-1
+    for idx in range(NSLOT):
+        post_stage(g, idx % NSLOT, idx % 2)
         e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
         e(f"s_cmp_eq_u32 s{S_CNT}, 0")
-        if slot < NSLOT - 1:
-            e("s_cbranch_scc1 DONE_%=")
+        if idx < NSLOT - 1:
+            e("s_cbranch_scc1 POST_DONE_%=")
         else:
-            e("s_cbranch_scc0 LOOP_%=")
-    e("DONE_%=:")
+            e("s_cbranch_scc0 POST_LOOP_%=")
+    e("POST_DONE_%=:")
+    e("s_waitcnt vmcnt(0)")  # run-ahead requests land before the ring is reused
+    e("s_branch DONE_%=")
+
+
+def gen_all():
+    g = Gen()
+    e = g.emit
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    e(f"v_mov_b64 %[acc], {pair(V_ACC + 2)}")
+    e("s_cmp_eq_u32 %[wave], 0")
+    e("s_cbranch_scc0 ROLE_POST_%=")
+    gen_chain(g)
+    gen_post(g)
+    e("DONE_%=:")
+    e("s_waitcnt lgkmcnt(0)")
     return g.out
 
 
@@ -294,7 +365,8 @@ def main():
     path = os.path.join(here, "..", "garlic_amd", "csrc", "chain_loop_gfx950.inc")
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_chain_asm.py -- do not edit; see that file for the schedule.\n")
-        f.write("// One inline-asm block: steady-state loop of lod_chain_kernel (gfx950, wave64).\n")
+        f.write("// One inline-asm block: steady-state loop of lod_chain_kernel, 2 waves in 2 roles (gfx950).\n")
+        f.write(f"#define GARLIC_CHAIN_LDS_TOTAL {LDS_TOTAL}\n")
         f.write("#define GARLIC_CHAIN_LOOP_ASM \\\n")
         for ln in lines:
             if ln.startswith(";"):
