@@ -1,0 +1,745 @@
+// Host adapter: the reference's Phase-I interface on top of libgarlic_hip.so (see garlic_host.hpp).
+#include "garlic_host.hpp"
+
+#include "../../include/garlic_hip.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+#include <thread>
+
+namespace garlic_host {
+
+namespace {
+
+struct CentroRow {
+    const char *chr;
+    int start, end;
+};
+#include "centromere_tables.inc"
+
+[[noreturn]] void fail(const std::string &msg)
+{
+    std::cerr << "ERROR: " << msg << "\n";
+    throw 0; // the reference's error convention (src/garlic-data.cpp:1619; main catches `...`)
+}
+
+// line reader over plain or gzip files (the reference reads everything through gzstream)
+class LineReader {
+public:
+    explicit LineReader(const std::string &path) : f(gzopen(path.c_str(), "rb"))
+    {
+        if (!f) fail("Failed to open " + path);
+        gzbuffer(f, 1 << 20);
+    }
+    ~LineReader() { if (f) gzclose(f); }
+    bool next(std::string &line)
+    {
+        line.clear();
+        char buf[1 << 16];
+        while (gzgets(f, buf, sizeof buf)) {
+            size_t n = strlen(buf);
+            if (n && buf[n - 1] == '\n') {
+                line.append(buf, n - 1);
+                if (!line.empty() && line.back() == '\r') line.pop_back();
+                return true;
+            }
+            line.append(buf, n);
+        }
+        return !line.empty();
+    }
+
+private:
+    gzFile f;
+};
+
+int countFields(const std::string &s)
+{
+    int n = 0;
+    bool in = false;
+    for (char c : s) {
+        bool ws = (c == ' ' || c == '\t' || c == '\r' || c == '\n');
+        if (!ws && !in) n++;
+        in = !ws;
+    }
+    return n;
+}
+
+LodOptions g_options;
+
+void check(int rc, const char *what)
+{
+    if (rc != GARLIC_OK) fail(std::string(what) + ": " + garlic_hip_last_error());
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------- centromere
+std::string checkChrName(std::string chr)
+{
+    if (chr.empty() || chr[0] != 'c') chr = "chr" + chr;
+    return chr;
+}
+
+centromere::centromere(const std::string &arg, const std::string &file, const std::string &defaultFileName)
+{
+    const CentroRow *rows = nullptr;
+    size_t n = 0;
+    if (arg == "hg18") { rows = k_hg18; n = sizeof k_hg18 / sizeof *k_hg18; }
+    else if (arg == "hg19") { rows = k_hg19; n = sizeof k_hg19 / sizeof *k_hg19; }
+    else if (arg == "hg38") { rows = k_hg38; n = sizeof k_hg38 / sizeof *k_hg38; }
+    for (size_t i = 0; i < n; i++) set(rows[i].chr, rows[i].start, rows[i].end);
+    if (!rows && file != defaultFileName) readCustomCentromeres(file);
+}
+
+void centromere::set(const std::string &chr, int start, int end)
+{
+    gapStart[checkChrName(chr)] = start;
+    gapEnd[checkChrName(chr)] = end;
+}
+
+void centromere::readCustomCentromeres(const std::string &filename)
+{
+    LineReader in(filename);
+    std::string line;
+    int rows = 0;
+    while (in.next(line)) {
+        if (countFields(line) != 3) { std::cerr << "ERROR: Custom centromere file requires three columns.\n"; continue; }
+        std::stringstream ss(line);
+        std::string chr;
+        int s, e;
+        ss >> chr >> s >> e;
+        set(chr, s, e);
+        rows++;
+    }
+    std::cerr << "Loaded custom centromere limits for " << rows << " chromosomes.\n";
+}
+
+int centromere::centromereStart(const std::string &chr)
+{
+    auto it = gapStart.find(chr);
+    if (it == gapStart.end()) { // unknown chromosome: 0 and one warning (garlic-centromeres.cpp:33-45)
+        if (!warned[chr]++) std::cerr << "WARNING: No centromere information for chr: " << chr << "\n";
+        return 0;
+    }
+    return it->second;
+}
+
+int centromere::centromereEnd(const std::string &chr)
+{
+    auto it = gapEnd.find(chr);
+    if (it == gapEnd.end()) {
+        if (!warned[chr]++) std::cerr << "WARNING: No centromere information for chr: " << chr << "\n";
+        return 0;
+    }
+    return it->second;
+}
+
+// ------------------------------------------------------------------------- structs
+HapData *initHapData(unsigned int nind, unsigned int nloci)
+{
+    if (nind < 1 || nloci < 1) fail("Can not allocate HapData object: counts must be positive.");
+    HapData *d = new HapData;
+    d->nind = nind;
+    d->nloci = nloci;
+    d->data = new short *[nloci];
+    for (unsigned l = 0; l < nloci; l++) {
+        d->data[l] = new short[nind];
+        std::fill(d->data[l], d->data[l] + nind, (short)MISSING);
+    }
+    return d;
+}
+void releaseHapData(HapData *d)
+{
+    if (!d) return;
+    for (int l = 0; l < d->nloci; l++) delete[] d->data[l];
+    delete[] d->data;
+    delete d;
+}
+void releaseHapData(std::vector<HapData *> *v) { for (auto d : *v) releaseHapData(d); delete v; }
+
+MapData *initMapData(int nloci)
+{
+    if (nloci < 1) fail("number of loci must be positive.");
+    MapData *d = new MapData;
+    d->nloci = nloci;
+    d->physicalPos = new int[nloci];
+    d->geneticPos = new double[nloci];
+    d->locusName = new std::string[nloci];
+    d->allele = new char[nloci];
+    d->chr = "--";
+    for (int l = 0; l < nloci; l++) { d->physicalPos[l] = MISSING; d->geneticPos[l] = MISSING; d->locusName[l] = "--"; d->allele[l] = '-'; }
+    return d;
+}
+void releaseMapData(MapData *d)
+{
+    if (!d) return;
+    delete[] d->physicalPos; delete[] d->geneticPos; delete[] d->locusName; delete[] d->allele;
+    delete d;
+}
+void releaseMapData(std::vector<MapData *> *v) { for (auto d : *v) releaseMapData(d); delete v; }
+
+FreqData *initFreqData(int nloci)
+{
+    if (nloci < 1) fail("number of loci must be positive.");
+    FreqData *d = new FreqData;
+    d->nloci = nloci;
+    d->freq = new double[nloci];
+    std::fill(d->freq, d->freq + nloci, (double)MISSING);
+    return d;
+}
+void releaseFreqData(FreqData *d) { if (d) { delete[] d->freq; delete d; } }
+void releaseFreqData(std::vector<FreqData *> *v) { for (auto d : *v) releaseFreqData(d); delete v; }
+
+GenoLikeData *initGLData(unsigned int nind, unsigned int nloci)
+{
+    if (nind < 1 || nloci < 1) fail("Can not allocate GenoLikeData object: counts must be positive.");
+    GenoLikeData *d = new GenoLikeData;
+    d->nind = nind;
+    d->nloci = nloci;
+    d->data = new double *[nloci];
+    for (unsigned l = 0; l < nloci; l++) {
+        d->data[l] = new double[nind];
+        std::fill(d->data[l], d->data[l] + nind, (double)MISSING);
+    }
+    return d;
+}
+void releaseGLData(GenoLikeData *d)
+{
+    if (!d) return;
+    for (int l = 0; l < d->nloci; l++) delete[] d->data[l];
+    delete[] d->data;
+    delete d;
+}
+void releaseGLData(std::vector<GenoLikeData *> *v) { for (auto d : *v) releaseGLData(d); delete v; }
+
+LDData *initLDData(int nloci, int winsize)
+{
+    LDData *d = new LDData;
+    d->nloci = nloci;
+    d->winsize = winsize;
+    d->LD = new double *[nloci];
+    for (int l = 0; l < nloci; l++) {
+        d->LD[l] = new double[winsize];
+        std::fill(d->LD[l], d->LD[l] + winsize, 0.0);
+    }
+    return d;
+}
+void releaseLDData(LDData *d)
+{
+    if (!d) return;
+    for (int l = 0; l < d->nloci; l++) delete[] d->LD[l];
+    delete[] d->LD;
+    delete d;
+}
+
+WinData *initWinData(unsigned int nind, unsigned int nloci)
+{
+    if (nind < 1 || nloci < 1) {
+        std::cerr << "ERROR: Can't allocate WinData object.  Number of individuals (" << nind
+                  << ") and number of loci (" << nloci << ") must be positive.\n";
+        throw 0;
+    }
+    WinData *d = new WinData;
+    d->nind = nind;
+    d->nloci = nloci;
+    d->data = new double *[nind];
+    for (unsigned i = 0; i < nind; i++) d->data[i] = new double[nloci]; // filled by the device result
+    return d;
+}
+std::vector<WinData *> *initWinData(std::vector<MapData *> *maps, int nind)
+{
+    auto *v = new std::vector<WinData *>;
+    for (auto m : *maps) v->push_back(initWinData(nind, m->nloci));
+    return v;
+}
+void releaseWinData(WinData *d)
+{
+    if (!d) return;
+    for (int i = 0; i < d->nind; i++) delete[] d->data[i];
+    delete[] d->data;
+    delete d;
+}
+void releaseWinData(std::vector<WinData *> *v) { for (auto d : *v) releaseWinData(d); delete v; }
+void releaseDoubleData(DoubleData *d) { if (d) { delete[] d->data; delete d; } }
+void releaseIndData(IndData *d) { if (d) { delete[] d->indID; delete d; } }
+
+// ------------------------------------------------------------------------- ingest
+namespace {
+void flushChromosome(const std::string &chr, std::vector<short *> &hap, std::vector<double> &gpos,
+                     std::vector<double> &ppos, std::vector<std::string> &names, std::vector<char> &allele,
+                     std::vector<double> &freq, int numInd, std::vector<HapData *> *haps,
+                     std::vector<MapData *> *maps, std::vector<FreqData *> *freqs)
+{
+    const int n = (int)hap.size();
+    MapData *m = initMapData(n);
+    m->chr = checkChrName(chr);
+    HapData *h = new HapData;
+    h->nind = numInd;
+    h->nloci = n;
+    h->data = new short *[n];
+    FreqData *f = initFreqData(n);
+    for (int l = 0; l < n; l++) {
+        m->physicalPos[l] = (int)ppos[l]; // read as double, stored as int (garlic-data.cpp:41,229)
+        m->geneticPos[l] = gpos[l];
+        m->locusName[l] = names[l];
+        m->allele[l] = allele[l];
+        h->data[l] = hap[l];
+        f->freq[l] = freq[l];
+    }
+    maps->push_back(m);
+    haps->push_back(h);
+    freqs->push_back(f);
+    hap.clear(); gpos.clear(); ppos.clear(); names.clear(); allele.clear(); freq.clear();
+}
+} // namespace
+
+void loadTPEDData(const std::string &tpedfile, int &numLoci, int &numInd, std::vector<HapData *> **hapDataByChr,
+                  std::vector<MapData *> **mapDataByChr, std::vector<FreqData *> **freqDataByChr,
+                  char TPED_MISSING)
+{
+    LineReader in(tpedfile);
+    *hapDataByChr = new std::vector<HapData *>;
+    *mapDataByChr = new std::vector<MapData *>;
+    *freqDataByChr = new std::vector<FreqData *>;
+    std::vector<short *> hap;
+    std::vector<double> gpos, ppos, freq;
+    std::vector<std::string> names;
+    std::vector<char> allele;
+    std::string line, chr, prevChr, name;
+    numLoci = 0;
+    numInd = 0;
+    while (in.next(line)) {
+        if (line.empty()) continue;
+        numLoci++;
+        numInd = (countFields(line) - 4) / 2; // garlic-data.cpp:59-60
+        std::stringstream ss(line);
+        double g, p;
+        ss >> chr >> name >> g >> p;
+        if (numLoci == 1) prevChr = chr;
+        if (chr != prevChr) { // new chromosome when the chr string changes (garlic-data.cpp:68-91)
+            flushChromosome(prevChr, hap, gpos, ppos, names, allele, freq, numInd, *hapDataByChr,
+                            *mapDataByChr, *freqDataByChr);
+            prevChr = chr;
+        }
+        short *data = new short[numInd];
+        char one = TPED_MISSING; // the first non-missing allele on the line is the counted one
+        int nalleles = 0, total = 0;
+        for (int i = 0; i < numInd; i++) {
+            char a1 = TPED_MISSING, a2 = TPED_MISSING;
+            ss >> a1 >> a2; // alleles are single characters (garlic-data.cpp:47,111)
+            if (one == TPED_MISSING && a1 != TPED_MISSING) one = a1;
+            if (one == TPED_MISSING && a2 != TPED_MISSING) one = a2;
+            int v = 0;
+            for (char a : {a1, a2}) {
+                if (a == TPED_MISSING) v += -9;
+                else { total++; if (a == one) { v += 1; nalleles++; } }
+            }
+            data[i] = (short)(v < 0 ? -9 : v);
+        }
+        hap.push_back(data);
+        gpos.push_back(g);
+        ppos.push_back(p);
+        names.push_back(name);
+        allele.push_back(one);
+        freq.push_back(total == 0 ? 0.0 : double(nalleles) / double(total)); // garlic-data.cpp:140-141
+    }
+    if (numLoci == 0) fail("no loci in " + tpedfile);
+    flushChromosome(chr, hap, gpos, ppos, names, allele, freq, numInd, *hapDataByChr, *mapDataByChr,
+                    *freqDataByChr);
+}
+
+void scanIndData3(const std::string &filename, int &numInd, std::string &popName)
+{
+    LineReader in(filename);
+    std::map<std::string, int> seen;
+    std::string line, pop, ind;
+    int n = 0;
+    while (in.next(line)) {
+        n++;
+        if (countFields(line) < 2) fail("line " + std::to_string(n) + " of " + filename + " has fewer than 2 columns");
+        std::stringstream ss(line);
+        ss >> pop >> ind;
+        if (seen.count(ind)) fail("Found duplicate individual ID (" + ind + ") in " + filename);
+        seen[ind] = 1;
+        if (n == 1) popName = pop;
+        else if (pop != popName) fail("Found multiple population IDs (" + pop + ", " + popName + ") in " + filename);
+    }
+    numInd = n;
+}
+
+IndData *readIndData3(const std::string &filename, int numInd)
+{
+    if (numInd < 1) fail("Number of individuals must be positive");
+    LineReader in(filename);
+    IndData *d = new IndData;
+    d->nind = numInd;
+    d->indID = new std::string[numInd];
+    std::string line, pop, ind;
+    for (int i = 0; i < numInd && in.next(line); i++) {
+        std::stringstream ss(line);
+        ss >> pop >> ind;
+        d->indID[i] = ind;
+    }
+    d->pop = pop;
+    return d;
+}
+
+std::vector<GenoLikeData *> *readTGLSData(const std::string &filename, int /*expectedLoci*/, int expectedInd,
+                                          std::vector<MapData *> *maps, const std::string &GL_TYPE)
+{
+    if (GL_TYPE != "GQ" && GL_TYPE != "GL" && GL_TYPE != "PL") fail("Must choose GQ/GL/PL for genotype likelihood format");
+    LineReader in(filename);
+    auto *out = new std::vector<GenoLikeData *>;
+    std::string line, junk;
+    for (auto m : *maps) {
+        GenoLikeData *d = initGLData(expectedInd, m->nloci);
+        out->push_back(d);
+        for (int l = 0; l < m->nloci; l++) {
+            if (!in.next(line)) fail("too few lines in " + filename);
+            const int num = countFields(line);
+            if (num != expectedInd + 4) fail("Incorrect number of columns in tgls file: " + std::to_string(num));
+            std::stringstream ss(line);
+            ss >> junk >> junk >> junk >> junk;
+            for (int i = 0; i < expectedInd; i++) {
+                double gl;
+                ss >> gl;
+                // garlic-data.cpp:1557-1576, operation for operation
+                if (GL_TYPE == "GQ") { gl /= (-10.0); gl = (gl > -10) ? gl : -10; gl = pow(10, gl); }
+                else if (GL_TYPE == "GL") { gl = (gl > -10) ? gl : -10; gl = 1 - pow(10, gl); }
+                else { gl /= (-10.0); gl = (gl > -10) ? gl : -10; gl = 1 - pow(10, gl); }
+                if (gl <= 0) gl = 0.0000000000000001;
+                if (gl > 1) gl = 1;
+                d->data[l][i] = gl;
+            }
+        }
+    }
+    return out;
+}
+
+std::vector<FreqData *> *readFreqData(const std::string &freqfile, std::vector<MapData *> *maps)
+{
+    LineReader in(freqfile);
+    auto *out = new std::vector<FreqData *>;
+    std::string line, chrom, id;
+    in.next(line); // header
+    int lineNum = 1;
+    for (auto m : *maps) {
+        FreqData *f = initFreqData(m->nloci);
+        out->push_back(f);
+        for (int l = 0; l < m->nloci; l++) {
+            lineNum++;
+            if (!in.next(line)) fail("at line " + std::to_string(lineNum) + " in " + freqfile + ". Perhaps too few lines?");
+            if (countFields(line) < 5) fail("fewer than 5 columns in " + freqfile + " on line " + std::to_string(lineNum));
+            std::stringstream ss(line);
+            double pos;
+            char al;
+            ss >> chrom >> id >> pos >> al >> f->freq[l];
+            if (m->locusName[l] != id) fail("Loci appear mismatched in: " + freqfile + " at line " + std::to_string(lineNum));
+            if (m->allele[l] != al) f->freq[l] = 1 - f->freq[l]; // other allele counted (garlic-data.cpp:1422-1424)
+        }
+    }
+    return out;
+}
+
+void writeFreqData(const std::string &freqOutfile, std::vector<FreqData *> *freqs, std::vector<MapData *> *maps)
+{
+    const std::string path = freqOutfile + ".gz";
+    gzFile f = gzopen(path.c_str(), "wb");
+    if (!f) fail("Failed to open " + path);
+    gzprintf(f, "CHR\tSNP\tPOS\tALLELE\tFREQ\n");
+    for (size_t c = 0; c < maps->size(); c++)
+        for (int l = 0; l < maps->at(c)->nloci; l++) {
+            std::ostringstream v; // default ostream formatting = 6 significant digits, like the reference
+            v << freqs->at(c)->freq[l];
+            gzprintf(f, "%s\t%s\t%d\t%c\t%s\n", maps->at(c)->chr.c_str(), maps->at(c)->locusName[l].c_str(),
+                     maps->at(c)->physicalPos[l], maps->at(c)->allele[l], v.str().c_str());
+        }
+    gzclose(f);
+}
+
+namespace {
+// keeps the SNPs with keep[l] != 0 in map / hap / freq / GL together
+void filterSites(size_t c, const std::vector<char> &keep, std::vector<MapData *> *maps, std::vector<HapData *> *haps,
+                 std::vector<FreqData *> *freqs, std::vector<GenoLikeData *> *gls)
+{
+    int n = 0;
+    for (char k : keep) n += k != 0;
+    MapData *m = maps->at(c);
+    HapData *h = haps->at(c);
+    FreqData *f = freqs->at(c);
+    GenoLikeData *g = gls ? gls->at(c) : nullptr;
+    if (n == m->nloci) return;
+    if (n < 1) fail("no sites left on " + m->chr + " after filtering");
+    MapData *m2 = initMapData(n);
+    m2->chr = m->chr;
+    HapData *h2 = new HapData{new short *[n], h->nind, n};
+    FreqData *f2 = initFreqData(n);
+    GenoLikeData *g2 = g ? new GenoLikeData{new double *[n], g->nind, n} : nullptr;
+    int j = 0;
+    for (int l = 0; l < m->nloci; l++) {
+        if (!keep[l]) { delete[] h->data[l]; if (g) delete[] g->data[l]; continue; }
+        m2->physicalPos[j] = m->physicalPos[l]; m2->geneticPos[j] = m->geneticPos[l];
+        m2->locusName[j] = m->locusName[l]; m2->allele[j] = m->allele[l];
+        h2->data[j] = h->data[l];
+        f2->freq[j] = f->freq[l];
+        if (g) g2->data[j] = g->data[l];
+        j++;
+    }
+    delete[] h->data; delete h;
+    if (g) { delete[] g->data; delete g; (*gls)[c] = g2; }
+    releaseMapData(m); releaseFreqData(f);
+    (*maps)[c] = m2; (*haps)[c] = h2; (*freqs)[c] = f2;
+}
+} // namespace
+
+int filterMonomorphicSites(std::vector<MapData *> **maps, std::vector<HapData *> **haps,
+                           std::vector<FreqData *> **freqs, std::vector<GenoLikeData *> **gls, bool USE_GL)
+{
+    int total = 0;
+    for (size_t c = 0; c < (*maps)->size(); c++) {
+        const FreqData *f = (*freqs)->at(c);
+        std::vector<char> keep(f->nloci);
+        for (int l = 0; l < f->nloci; l++) keep[l] = (f->freq[l] > 0 && f->freq[l] < 1); // garlic-data.cpp:871-914
+        filterSites(c, keep, *maps, *haps, *freqs, USE_GL ? *gls : nullptr);
+        total += (*maps)->at(c)->nloci;
+    }
+    return total;
+}
+
+int loadAndInterpolateMap(const std::string &mapfile, std::vector<MapData *> *maps)
+{
+    // scaffold: 4 columns chr snpid gpos ppos (garlic-data.cpp:760-844)
+    std::map<std::string, std::vector<std::pair<int, double>>> scaf;
+    LineReader in(mapfile);
+    std::string line, chr, id;
+    while (in.next(line)) {
+        if (countFields(line) != 4) fail("map file requires four columns: " + mapfile);
+        std::stringstream ss(line);
+        double g, p;
+        ss >> chr >> id >> g >> p;
+        scaf[checkChrName(chr)].push_back({(int)p, g});
+    }
+    int interpolated = 0;
+    for (auto m : *maps) {
+        auto it = scaf.find(m->chr);
+        if (it == scaf.end()) fail("no genetic map for " + m->chr);
+        const auto &s = it->second;
+        size_t k = 0;
+        for (int l = 0; l < m->nloci; l++) {
+            const int q = m->physicalPos[l];
+            if (q < s.front().first || q > s.back().first)
+                fail("Sites outside of map scaffold must be filtered out before interpolation.");
+            while (k + 1 < s.size() && s[k + 1].first <= q) k++;
+            if (s[k].first == q) { m->geneticPos[l] = s[k].second; continue; } // exact hit (garlic-data.cpp:733-737)
+            const double x0 = s[k].first, y0 = s[k].second, x1 = s[k + 1].first, y1 = s[k + 1].second;
+            m->geneticPos[l] = (((y1 - y0) / (x1 - x0)) * q + (y0 - ((y1 - y0) / (x1 - x0)) * x0)); // :754-757
+            interpolated++;
+        }
+    }
+    return interpolated;
+}
+
+// ------------------------------------------------------------------------- the path
+void setLodOptions(const LodOptions &o) { g_options = o; }
+
+struct LodEngine::Impl {
+    struct Shard {
+        int device, ind_begin, nind;
+        garlic_ctx *ctx = nullptr;
+        garlic_panel *panel = nullptr;
+    };
+    std::vector<Shard> shards;
+    std::vector<int32_t> chr_nloci;
+    std::vector<MapData *> *maps;
+    int nind = 0;
+    bool use_gl = false;
+};
+
+LodEngine::LodEngine(std::vector<HapData *> *haps, std::vector<FreqData *> *freqs, std::vector<MapData *> *maps,
+                     std::vector<GenoLikeData *> *gls, centromere *centro, bool USE_GL,
+                     const std::vector<int> &devices)
+    : impl(new Impl)
+{
+    const int nchr = (int)maps->size();
+    impl->maps = maps;
+    impl->nind = haps->at(0)->nind;
+    impl->use_gl = USE_GL;
+    int64_t nloci = 0;
+    for (auto m : *maps) { impl->chr_nloci.push_back(m->nloci); nloci += m->nloci; }
+    std::vector<int32_t> pos(nloci), cs(nchr), ce(nchr);
+    std::vector<double> gpos(nloci), freq(nloci);
+    int64_t o = 0;
+    for (int c = 0; c < nchr; c++) {
+        const MapData *m = maps->at(c);
+        cs[c] = centro->centromereStart(m->chr);   // garlic-roh.cpp:36-37
+        ce[c] = centro->centromereEnd(m->chr);
+        for (int l = 0; l < m->nloci; l++, o++) {
+            pos[o] = m->physicalPos[l];
+            gpos[o] = m->geneticPos[l];
+            freq[o] = freqs->at(c)->freq[l];
+        }
+    }
+    std::vector<int> devs = devices.empty() ? std::vector<int>{0} : devices;
+    const int nd = std::min<int>((int)devs.size(), impl->nind);
+    const int per = (impl->nind + nd - 1) / nd; // contiguous blocks in TFAM order
+    for (int d = 0; d < nd; d++) {
+        Impl::Shard s;
+        s.device = devs[d];
+        s.ind_begin = d * per;
+        s.nind = std::min(per, impl->nind - s.ind_begin);
+        if (s.nind < 1) break;
+        check(garlic_ctx_create(s.device, nullptr, &s.ctx), "garlic_ctx_create");
+        check(garlic_panel_create(s.ctx, nchr, impl->chr_nloci.data(), s.nind, &s.panel), "garlic_panel_create");
+        check(garlic_panel_set_map(s.panel, pos.data(), gpos.data(), cs.data(), ce.data()), "garlic_panel_set_map");
+        check(garlic_panel_set_freq(s.panel, freq.data()), "garlic_panel_set_freq");
+        impl->shards.push_back(s);
+    }
+    // genotype rows are separate allocations in HapData: stage a slab of SNP rows at a time
+    const int64_t slab = std::max<int64_t>(1, ((int64_t)64 << 20) / (2 * (int64_t)impl->nind));
+    std::vector<int16_t> stage;
+    std::vector<double> stage_gl;
+    o = 0;
+    for (int c = 0; c < nchr; c++) {
+        const HapData *h = haps->at(c);
+        for (int l0 = 0; l0 < h->nloci; l0 += (int)slab) {
+            const int rows = (int)std::min<int64_t>(slab, h->nloci - l0);
+            stage.resize((size_t)rows * impl->nind);
+            for (int r = 0; r < rows; r++)
+                memcpy(&stage[(size_t)r * impl->nind], h->data[l0 + r], sizeof(short) * impl->nind);
+            if (USE_GL) {
+                stage_gl.resize((size_t)rows * impl->nind);
+                for (int r = 0; r < rows; r++)
+                    memcpy(&stage_gl[(size_t)r * impl->nind], gls->at(c)->data[l0 + r], sizeof(double) * impl->nind);
+            }
+            for (auto &s : impl->shards) {
+                check(garlic_panel_set_genotypes(s.panel, stage.data() + s.ind_begin, impl->nind, o + l0, rows,
+                                                 GARLIC_HOST), "garlic_panel_set_genotypes");
+                if (USE_GL)
+                    check(garlic_panel_set_gl(s.panel, stage_gl.data() + s.ind_begin, impl->nind, o + l0, rows,
+                                              GARLIC_HOST), "garlic_panel_set_gl");
+            }
+        }
+        o += h->nloci;
+    }
+}
+
+LodEngine::~LodEngine()
+{
+    for (auto &s : impl->shards) {
+        garlic_panel_destroy(s.panel);
+        garlic_ctx_destroy(s.ctx);
+    }
+    delete impl;
+}
+
+std::vector<WinData *> *LodEngine::lodWindows(int winsize, double error, int MAX_GAP)
+{
+    std::cerr << "Calculating LOD scores with winsize " << winsize << ".\n";
+    std::vector<WinData *> *win = initWinData(impl->maps, impl->nind);
+    const int nchr = (int)impl->chr_nloci.size();
+    std::vector<std::string> errors(impl->shards.size());
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < impl->shards.size(); k++) {
+        th.emplace_back([&, k] { // one host thread per GPU; no collective, just a gather of rows
+            auto &s = impl->shards[k];
+            std::vector<int64_t> base(nchr), pitch(nchr);
+            int64_t total = 0;
+            // individuals come back in chunks so the host never stages more than ~1 GiB
+            int64_t per_ind = 0;
+            for (int c = 0; c < nchr; c++) per_ind += impl->chr_nloci[c];
+            const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(s.nind, ((int64_t)1 << 27) / std::max<int64_t>(1, per_ind)));
+            std::vector<double> buf;
+            for (int i0 = 0; i0 < s.nind; i0 += chunk) {
+                const int n = std::min(chunk, s.nind - i0);
+                if (garlic_lod_out_layout(s.panel, 1, n, base.data(), pitch.data(), &total) != GARLIC_OK ||
+                    (buf.resize((size_t)total), false) ||
+                    garlic_lod_windows(s.panel, winsize, error, MAX_GAP, impl->use_gl, i0, n, 1, buf.data(),
+                                       GARLIC_HOST) != GARLIC_OK) {
+                    errors[k] = garlic_hip_last_error();
+                    return;
+                }
+                for (int c = 0; c < nchr; c++)
+                    for (int i = 0; i < n; i++)
+                        memcpy(win->at(c)->data[s.ind_begin + i0 + i], &buf[base[c] + (int64_t)i * pitch[c]],
+                               sizeof(double) * impl->chr_nloci[c]);
+            }
+        });
+    }
+    for (auto &t : th) t.join();
+    for (auto &e : errors)
+        if (!e.empty()) { releaseWinData(win); fail("garlic_lod_windows: " + e); }
+    return win;
+}
+
+std::vector<WinData *> *calcLODWindows(std::vector<HapData *> *haps, std::vector<FreqData *> *freqs,
+                                       std::vector<MapData *> *maps, std::vector<GenoLikeData *> *gls,
+                                       centromere *centro, int winsize, double error, int MAX_GAP, bool USE_GL)
+{
+    // GLDataByChr may be an uninitialised pointer when !USE_GL (garlic-roh.cpp:713,720): never touched then
+    LodEngine engine(haps, freqs, maps, USE_GL ? gls : nullptr, centro, USE_GL, g_options.devices);
+    return engine.lodWindows(winsize, error, MAX_GAP);
+}
+
+std::vector<WinData *> *calcwLODWindows(std::vector<HapData *> *, std::vector<FreqData *> *, std::vector<MapData *> *,
+                                        std::vector<GenoLikeData *> *, std::vector<LDData *> *, centromere *, int,
+                                        double, int, bool, int, double, int)
+{
+    fail("calcwLODWindows: the wLOD kernel is not part of this build yet");
+}
+
+// ------------------------------------------------------------------------- consumers
+DoubleData *convertWinData2DoubleData(std::vector<WinData *> *wins, int step)
+{
+    // garlic-data.cpp:2026-2069: chr -> ind -> every step-th locus; MISSING and NaN are dropped
+    int size = 0;
+    for (auto w : *wins)
+        for (int i = 0; i < w->nind; i++)
+            for (int l = 0; l < w->nloci; l += step) {
+                const double x = w->data[i][l];
+                if (x != MISSING && !std::isnan(x)) size++;
+            }
+    DoubleData *d = new DoubleData;
+    d->size = size;
+    d->data = new double[size > 0 ? size : 1];
+    int k = 0;
+    for (auto w : *wins)
+        for (int i = 0; i < w->nind; i++)
+            for (int l = 0; l < w->nloci; l += step) {
+                const double x = w->data[i][l];
+                if (x != MISSING && !std::isnan(x)) d->data[k++] = x;
+            }
+    return d;
+}
+
+void writeWinData(std::vector<WinData *> *wins, IndData *indData, std::vector<MapData *> *maps,
+                  const std::string &outfile)
+{
+    for (size_t c = 0; c < maps->size(); c++) {
+        const std::string path = outfile + "." + indData->pop + "." + maps->at(c)->chr + ".raw.lod.windows.gz";
+        gzFile f = gzopen(path.c_str(), "wb");
+        if (!f) { std::cerr << "ERROR: Failed to open " << path << " for writing.\n"; throw -1; }
+        const WinData *w = wins->at(c);
+        std::ostringstream row;
+        for (int i = 0; i < w->nind; i++) {
+            row.str("");
+            for (int l = 0; l < w->nloci; l++) {
+                if (w->data[i][l] == MISSING) row << "NA"; // garlic-data.cpp:1736
+                else row << w->data[i][l];                  // default precision: 6 significant digits
+                if (l < w->nloci - 1) row << " ";
+            }
+            row << "\n";
+            const std::string s = row.str();
+            gzwrite(f, s.data(), (unsigned)s.size());
+        }
+        gzclose(f);
+        std::cerr << "Wrote " << path << "\n";
+    }
+}
+
+} // namespace garlic_host

@@ -1,0 +1,164 @@
+// Host-side mirror of the reference's Phase-I interface, on top of the C ABI (include/garlic_hip.h).
+//
+// The reference is a C++ program with no plugin layer: its boundary for this path is
+//     calcLODWindows   src/garlic-roh.h:96-102
+//     calcwLODWindows  src/garlic-roh.h:104-112
+// and the structs those borrow (src/garlic-data.h:32-108).  This header re-declares structs of
+// the same shape and the two entry points with the same argument meaning and error behaviour
+// (`throw 0`, src/garlic-data.cpp:1619), so GARLIC's callers -- main, exploreWinsizes,
+// selectWinsize, selectWinsizeFromList -- can be pointed here unchanged.
+// Also: the ingest GARLIC does before the path (tped/tfam/tgls/freq/map/centromere) and the
+// two consumers right after it (raw LOD writer, KDE feed flattening).
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+namespace garlic_host {
+
+const int MISSING = -9999; // src/garlic-data.h:24
+
+struct HapData {           // src/garlic-data.h:32-38
+    short **data;          // [locus][ind]: copies of the counted allele, -9 = missing
+    int nind;
+    int nloci;
+};
+struct MapData {           // src/garlic-data.h:51-60
+    int *physicalPos;
+    double *geneticPos;
+    std::string *locusName;
+    char *allele;          // the allele that is counted
+    int nloci;
+    std::string chr;
+};
+struct IndData {           // src/garlic-data.h:62-67
+    std::string pop;
+    std::string *indID;
+    int nind;
+};
+struct FreqData {          // src/garlic-data.h:69-73
+    double *freq;
+    int nloci;
+};
+struct GenoLikeData {      // src/garlic-data.h:89-95
+    double **data;         // [locus][ind]: per-genotype error probability
+    int nind;
+    int nloci;
+};
+struct LDData {            // src/garlic-data.h:103-108
+    double **LD;           // [locus][winsize]
+    int nloci;
+    int winsize;
+};
+struct WinData {           // src/garlic-data.h:81-87
+    double **data;         // [ind][locus], MISSING where no score
+    int nind;
+    int nloci;
+};
+struct DoubleData {        // src/garlic-data.h:97-101
+    double *data;
+    int size;
+};
+
+// src/garlic-centromeres.h: only centromereStart/End are used on the path (garlic-roh.cpp:36-37)
+class centromere {
+public:
+    centromere() {}
+    // arg: hg18 | hg19 | hg38 | none ; file: custom "chr start end" table (garlic-centromeres.cpp:64)
+    centromere(const std::string &arg, const std::string &file, const std::string &defaultFileName);
+    int centromereStart(const std::string &chr);
+    int centromereEnd(const std::string &chr);
+    void readCustomCentromeres(const std::string &filename);
+    void set(const std::string &chr, int start, int end);
+
+private:
+    std::map<std::string, int> gapStart, gapEnd;
+    std::map<std::string, int> warned;
+};
+
+std::string checkChrName(std::string chr); // "1" -> "chr1" (garlic-data.cpp:1886-1891)
+
+// ---- allocation helpers with the reference's semantics
+HapData *initHapData(unsigned int nind, unsigned int nloci);
+void releaseHapData(HapData *d);
+void releaseHapData(std::vector<HapData *> *v);
+MapData *initMapData(int nloci);
+void releaseMapData(MapData *d);
+void releaseMapData(std::vector<MapData *> *v);
+FreqData *initFreqData(int nloci);
+void releaseFreqData(FreqData *d);
+void releaseFreqData(std::vector<FreqData *> *v);
+GenoLikeData *initGLData(unsigned int nind, unsigned int nloci);
+void releaseGLData(GenoLikeData *d);
+void releaseGLData(std::vector<GenoLikeData *> *v);
+LDData *initLDData(int nloci, int winsize);
+void releaseLDData(LDData *d);
+WinData *initWinData(unsigned int nind, unsigned int nloci);          // throws 0 on empty shapes
+std::vector<WinData *> *initWinData(std::vector<MapData *> *mapDataByChr, int nind);
+void releaseWinData(WinData *d);
+void releaseWinData(std::vector<WinData *> *v);
+void releaseDoubleData(DoubleData *d);
+void releaseIndData(IndData *d);
+
+// ---- ingest (what main does before the path, src/garlic-main.cpp:216-279)
+void loadTPEDData(const std::string &tpedfile, int &numLoci, int &numInd,
+                  std::vector<HapData *> **hapDataByChr, std::vector<MapData *> **mapDataByChr,
+                  std::vector<FreqData *> **freqDataByChr, char TPED_MISSING);   // garlic-data.cpp:10
+void scanIndData3(const std::string &filename, int &numInd, std::string &popName);  // :1893
+IndData *readIndData3(const std::string &filename, int numInd);                     // :1963
+std::vector<GenoLikeData *> *readTGLSData(const std::string &filename, int expectedLoci, int expectedInd,
+                                          std::vector<MapData *> *mapDataByChr,
+                                          const std::string &GL_TYPE);             // :1516
+std::vector<FreqData *> *readFreqData(const std::string &freqfile,
+                                      std::vector<MapData *> *mapDataByChr);        // :1345
+void writeFreqData(const std::string &freqOutfile, std::vector<FreqData *> *freqDataByChr,
+                   std::vector<MapData *> *mapDataByChr);                           // :1442
+int filterMonomorphicSites(std::vector<MapData *> **mapDataByChr, std::vector<HapData *> **hapDataByChr,
+                           std::vector<FreqData *> **freqDataByChr,
+                           std::vector<GenoLikeData *> **GLDataByChr, bool USE_GL); // :871
+// genetic map for --weighted: 4 columns chr snpid gpos ppos, linear interpolation (:702-844)
+int loadAndInterpolateMap(const std::string &mapfile, std::vector<MapData *> *mapDataByChr);
+
+// ---- the path (drop-in signatures)
+struct LodOptions {
+    std::vector<int> devices;   // HIP device ordinals; empty = {0}.  Individuals shard contiguously.
+};
+void setLodOptions(const LodOptions &o);
+
+std::vector<WinData *> *calcLODWindows(std::vector<HapData *> *hapDataByChr,
+                                       std::vector<FreqData *> *freqDataByChr,
+                                       std::vector<MapData *> *mapDataByChr,
+                                       std::vector<GenoLikeData *> *GLDataByChr, centromere *centro,
+                                       int winsize, double error, int MAX_GAP, bool USE_GL);
+
+std::vector<WinData *> *calcwLODWindows(std::vector<HapData *> *hapDataByChr,
+                                        std::vector<FreqData *> *freqDataByChr,
+                                        std::vector<MapData *> *mapDataByChr,
+                                        std::vector<GenoLikeData *> *GLDataByChr,
+                                        std::vector<LDData *> *ldDataByChr, centromere *centro,
+                                        int winsize, double error, int MAX_GAP, bool USE_GL, int M,
+                                        double mu, int numThreads);
+
+// A panel kept on the device(s) across window sizes (exploreWinsizes / selectWinsize call the
+// path once per candidate winsize on the same data, garlic-roh.cpp:726-751,798-837,881-920).
+class LodEngine {
+public:
+    LodEngine(std::vector<HapData *> *hapDataByChr, std::vector<FreqData *> *freqDataByChr,
+              std::vector<MapData *> *mapDataByChr, std::vector<GenoLikeData *> *GLDataByChr,
+              centromere *centro, bool USE_GL, const std::vector<int> &devices);
+    ~LodEngine();
+    std::vector<WinData *> *lodWindows(int winsize, double error, int MAX_GAP);
+    LodEngine(const LodEngine &) = delete;
+    LodEngine &operator=(const LodEngine &) = delete;
+
+private:
+    struct Impl;
+    Impl *impl;
+};
+
+// ---- consumers right after the path
+DoubleData *convertWinData2DoubleData(std::vector<WinData *> *winDataByChr, int step); // :2026
+void writeWinData(std::vector<WinData *> *winDataByChr, IndData *indData,
+                  std::vector<MapData *> *mapDataByChr, const std::string &outfile);      // :1704
+
+} // namespace garlic_host

@@ -1,0 +1,151 @@
+// garlic-lod: GARLIC's Phase I (window LOD scores) as a stand-alone tool on MI355X.
+// Keeps the reference's ingest (tped/tfam/tgls/freq/map/centromere) and the Phase-I part of its
+// command line (src/garlic-cli.cpp), and writes what GARLIC's next stage consumes:
+//   <out>.<pop>.<chr>.raw.lod.windows.gz   with --raw-lod   (src/garlic-data.cpp:1704)
+//   <out>.<W>SNPs.lod.f64                  the KDE feed: convertWinData2DoubleData's doubles
+//                                          (src/garlic-data.cpp:2026), thinned to every W-th window
+//                                          unless --no-kde-thinning
+// KDE / ROH assembly / GMM themselves stay in GARLIC (out of scope here).
+#include "garlic_host.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+using namespace garlic_host;
+
+namespace {
+struct Args {
+    std::string tped, tfam, out = "outfile", build = "none", centromere = "none", tgls = "none",
+                gl_type = "none", freq_file = "none", map = "none";
+    char tped_missing = '0';       // src/garlic-cli.cpp:114
+    double error = -1;             // :34 (must be in (0,1) unless TGLS)
+    int winsize = 0;               // :38
+    std::vector<int> winsize_multi;
+    bool auto_winsize = false, weighted = false, raw_lod = false, kde_thinning = true;
+    int auto_winsize_step = 10, max_gap = 200000, M = 7, threads = 1, kde_subsample = 20, gpus = 1;
+    double mu = 1e-9, overlap_frac = 0.25;
+};
+
+[[noreturn]] void usage(const char *msg)
+{
+    std::cerr << "ERROR: " << msg << "\n"
+              << "usage: garlic-lod --tped F --tfam F --out P (--build hg18|hg19|hg38 | --centromere F)\n"
+                 "         (--error E | --tgls F --gl-type GQ|GL|PL) (--winsize W | --winsize-multi W1 W2 ...)\n"
+                 "         [--auto-winsize] [--auto-winsize-step N] [--max-gap N] [--overlap-frac X]\n"
+                 "         [--freq-file F] [--tped-missing C] [--raw-lod] [--kde-subsample N] [--no-kde-thinning]\n"
+                 "         [--weighted --map F --M N --mu X --threads N] [--gpus N]\n";
+    exit(1);
+}
+
+Args parse(int argc, char **argv)
+{
+    Args a;
+    for (int i = 1; i < argc; i++) {
+        const std::string f = argv[i];
+        auto val = [&]() -> std::string { if (i + 1 >= argc) usage(("missing value for " + f).c_str()); return argv[++i]; };
+        if (f == "--tped") a.tped = val();
+        else if (f == "--tfam") a.tfam = val();
+        else if (f == "--out") a.out = val();
+        else if (f == "--build") a.build = val();
+        else if (f == "--centromere") a.centromere = val();
+        else if (f == "--tgls") a.tgls = val();
+        else if (f == "--gl-type") a.gl_type = val();
+        else if (f == "--freq-file") a.freq_file = val();
+        else if (f == "--map") a.map = val();
+        else if (f == "--tped-missing") a.tped_missing = val()[0];
+        else if (f == "--error") a.error = atof(val().c_str());
+        else if (f == "--winsize") a.winsize = atoi(val().c_str());
+        else if (f == "--winsize-multi") {
+            while (i + 1 < argc && argv[i + 1][0] != '-') a.winsize_multi.push_back(atoi(argv[++i]));
+        }
+        else if (f == "--auto-winsize") a.auto_winsize = !a.auto_winsize; // bool flags toggle (param_t.cpp:278)
+        else if (f == "--auto-winsize-step") a.auto_winsize_step = atoi(val().c_str());
+        else if (f == "--max-gap") a.max_gap = atoi(val().c_str());
+        else if (f == "--overlap-frac") a.overlap_frac = atof(val().c_str());
+        else if (f == "--weighted") a.weighted = !a.weighted;
+        else if (f == "--M") a.M = atoi(val().c_str());
+        else if (f == "--mu") a.mu = atof(val().c_str());
+        else if (f == "--threads") a.threads = atoi(val().c_str());
+        else if (f == "--raw-lod") a.raw_lod = !a.raw_lod;
+        else if (f == "--kde-subsample") a.kde_subsample = atoi(val().c_str());
+        else if (f == "--no-kde-thinning") a.kde_thinning = !a.kde_thinning;
+        else if (f == "--gpus") a.gpus = atoi(val().c_str());
+        else usage(("unknown flag " + f).c_str());
+    }
+    // validators of src/garlic-cli.cpp:240-462 that concern Phase I
+    if (a.tped.empty() || a.tfam.empty()) usage("--tped and --tfam are required");
+    if (a.build == "none" && a.centromere == "none") usage("must provide --build or --centromere (garlic-cli.cpp:285-291)");
+    if ((a.error <= 0 || a.error >= 1) && a.tgls == "none")
+        usage("Genotype error rate must be > 0 and < 1, or a TGLS file must be provided.");
+    if (a.tgls != "none" && a.gl_type != "GQ" && a.gl_type != "GL" && a.gl_type != "PL")
+        usage("Must choose GQ/GL/PL for genotype likelihood format.");
+    if (a.winsize <= 1 && a.winsize_multi.empty()) usage("SNP window size must be > 1.");
+    for (int w : a.winsize_multi) if (w <= 1) usage("SNP window sizes must be > 1.");
+    if (a.max_gap < 0) usage("Max gap must be > 0.");
+    if (a.overlap_frac < 0 || a.overlap_frac > 1) usage("Overlap fraction must be >= 0 and <= 1.");
+    if (a.weighted && a.map == "none") usage("--weighted needs --map");
+    return a;
+}
+
+void writeFeed(const std::string &path, const DoubleData *d)
+{
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) { std::cerr << "ERROR: cannot write " << path << "\n"; throw 0; }
+    fwrite(d->data, sizeof(double), (size_t)d->size, f);
+    fclose(f);
+    std::cerr << "Wrote " << path << " (" << d->size << " window scores)\n";
+}
+} // namespace
+
+int main(int argc, char **argv)
+{
+    const Args a = parse(argc, argv);
+    try {
+        centromere centro(a.build, a.centromere, "none");
+        int numLoci = 0, numInd = 0;
+        std::vector<HapData *> *haps; std::vector<MapData *> *maps; std::vector<FreqData *> *freqs;
+        loadTPEDData(a.tped, numLoci, numInd, &haps, &maps, &freqs, a.tped_missing);
+        std::string pop;
+        int nindFam = 0;
+        scanIndData3(a.tfam, nindFam, pop);
+        if (nindFam != numInd) { std::cerr << "ERROR: tfam lists " << nindFam << " individuals, tped has " << numInd << "\n"; return 1; }
+        IndData *ind = readIndData3(a.tfam, numInd);
+        std::cerr << "Loaded " << numLoci << " loci x " << numInd << " individuals (" << maps->size() << " chromosomes)\n";
+
+        const bool USE_GL = a.tgls != "none";
+        std::vector<GenoLikeData *> *gls = nullptr;
+        if (USE_GL) gls = readTGLSData(a.tgls, numLoci, numInd, maps, a.gl_type); // rows in pre-filter TPED order
+        if (a.freq_file != "none") { releaseFreqData(freqs); freqs = readFreqData(a.freq_file, maps); }
+        else writeFreqData(a.out + ".freq", freqs, maps);                        // garlic-main.cpp:245-253
+        if (a.weighted) loadAndInterpolateMap(a.map, maps);
+        const int kept = filterMonomorphicSites(&maps, &haps, &freqs, &gls, USE_GL);
+        std::cerr << "Filtered monomorphic sites: " << kept << " loci kept\n";
+
+        std::vector<int> devices;
+        for (int d = 0; d < a.gpus; d++) devices.push_back(d);
+        if (a.weighted) { std::cerr << "ERROR: --weighted (wLOD) is not available in this build\n"; return 1; }
+
+        std::vector<int> sizes = a.winsize_multi.empty() ? std::vector<int>{a.winsize} : a.winsize_multi;
+        LodEngine engine(haps, freqs, maps, gls, &centro, USE_GL, devices); // one upload, many window sizes
+        for (int W : sizes) {
+            std::vector<WinData *> *win = engine.lodWindows(W, a.error, a.max_gap);
+            if (a.raw_lod) writeWinData(win, ind, maps, sizes.size() == 1 ? a.out : a.out + "." + std::to_string(W) + "SNPs");
+            DoubleData *feed = convertWinData2DoubleData(win, a.kde_thinning ? W : 1);
+            writeFeed(a.out + "." + std::to_string(W) + "SNPs.lod.f64", feed);
+            releaseDoubleData(feed);
+            releaseWinData(win);
+        }
+        if (a.auto_winsize)
+            std::cerr << "NOTE: --auto-winsize picks among the feeds above in GARLIC's KDE stage (Phase II, not part of this tool)\n";
+        releaseIndData(ind);
+        releaseHapData(haps); releaseMapData(maps); releaseFreqData(freqs);
+        if (gls) releaseGLData(gls);
+    } catch (...) {
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,42 @@
+"""Individual sharding across the GPUs of a node.
+
+Individuals are independent on this path (reference src/garlic-roh.cpp:46 iterates them one by
+one), so rank r owns a contiguous block of the TFAM order, gets ALL SNPs for it plus replicated
+per-SNP tables, and there is no collective on the data path.  The only communication is the
+host-side gather of per-individual score rows, in rank order, because the KDE feed iterates
+chromosome -> individual -> locus (src/garlic-data.cpp:2033-2037)."""
+import numpy as np
+
+
+def shard_range(nind, world, rank):
+    """Contiguous block [begin, end) of individuals for `rank`; blocks of ceil(nind/world)."""
+    per = (nind + world - 1) // world
+    begin = min(nind, rank * per)
+    return begin, min(nind, begin + per)
+
+
+def gather_rows(local_rows, nind, group=None):
+    """local_rows: list (one per chromosome) of float64 [n_local][nloci_c] arrays of this rank's
+    individuals.  Returns on rank 0 the list of [nind][nloci_c] arrays in TFAM order (None on the
+    other ranks).  Works with any torch.distributed backend (gloo on CPU, nccl = RCCL on GPUs)."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    out = [] if rank == 0 else None
+    for rows in local_rows:
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        nloci = rows.shape[1]
+        per = (nind + world - 1) // world
+        # equal-sized buffers for gather: pad the last block
+        buf = torch.zeros((per, nloci), dtype=torch.float64)
+        buf[: rows.shape[0]] = torch.from_numpy(rows)
+        parts = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, parts, dst=0, group=group)
+        if rank == 0:
+            full = np.empty((nind, nloci), dtype=np.float64)
+            for r in range(world):
+                b, e = shard_range(nind, world, r)
+                full[b:e] = parts[r][: e - b].numpy()
+            out.append(full)
+    return out

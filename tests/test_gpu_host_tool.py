@@ -1,0 +1,91 @@
+"""GPU: the garlic-lod tool (C++ host adapter + ingest + C ABI) end to end on the tiny data set the
+reference's prebuilt binary was run on (tests/golden/e2e, tools/make_golden_e2e.py)."""
+import glob
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+E2E = os.path.join(ROOT, "tests", "golden", "e2e")
+TOOL = os.path.join(ROOT, "garlic_amd", "host", "garlic-lod")
+
+
+def read_rows(path):
+    with gzip.open(path, "rt") as f:
+        return [line.split() for line in f]
+
+
+def run_tool(tmp_path, *extra):
+    out = str(tmp_path / "mine")
+    cmd = [TOOL, "--tped", os.path.join(E2E, "tiny.tped.gz"), "--tfam", os.path.join(E2E, "tiny.tfam"),
+           "--centromere", os.path.join(E2E, "tiny.centromeres.txt"), "--error", "0.001", "--out", out, *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out
+
+
+def test_freq_and_raw_lod_match_reference_binary(tmp_path):
+    out = run_tool(tmp_path, "--winsize", "30", "--raw-lod")
+    # allele frequencies: same text
+    assert gzip.open(out + ".freq.gz", "rt").read() == gzip.open(os.path.join(E2E, "ref.freq.gz"), "rt").read()
+    n_tok = n_same = 0
+    for ref in sorted(glob.glob(os.path.join(E2E, "ref.POP.*.raw.lod.windows.gz"))):
+        mine = out + os.path.basename(ref)[3:]
+        a, b = read_rows(ref), read_rows(mine)
+        assert len(a) == len(b) == 24
+        for ra, rb in zip(a, b):
+            assert len(ra) == len(rb)
+            assert [x == "NA" for x in ra] == [x == "NA" for x in rb]       # identical MISSING mask
+            va = np.array([float(x) for x in ra if x != "NA"])
+            vb = np.array([float(x) for x in rb if x != "NA"])
+            # the prebuilt binary carries its own (older) libm; everything is printed with 6 digits
+            assert np.allclose(va, vb, rtol=2e-5, atol=2e-6)
+            n_tok += len(ra)
+            n_same += sum(x == y for x, y in zip(ra, rb))
+    assert n_same / n_tok > 0.999, (n_same, n_tok)
+
+
+def test_kde_feed_matches_oracle(tmp_path):
+    """<out>.<W>SNPs.lod.f64 = convertWinData2DoubleData of the scores (garlic-data.cpp:2026), bit exact."""
+    out = run_tool(tmp_path, "--winsize-multi", "20", "45")
+    # independent re-parse of the tped (first non-missing allele is the counted one)
+    chroms = {}
+    with gzip.open(os.path.join(E2E, "tiny.tped.gz"), "rt") as f:
+        for line in f:
+            t = line.split()
+            chroms.setdefault(t[0], []).append(t)
+    cen = {l.split()[0]: (int(l.split()[1]), int(l.split()[2])) for l in open(os.path.join(E2E, "tiny.centromeres.txt"))}
+    per_chr = []
+    for c, rows in chroms.items():
+        pos = np.array([int(float(t[3])) for t in rows], dtype=np.int32)
+        geno = np.zeros((len(rows), 24), dtype=np.int16)
+        freq = np.zeros(len(rows))
+        for l, t in enumerate(rows):
+            al = t[4:]
+            one = next((x for x in al if x != "0"), "0")
+            cnt = tot = 0
+            for i in range(24):
+                a1, a2 = al[2 * i], al[2 * i + 1]
+                if a1 == "0" or a2 == "0":
+                    geno[l, i] = -9
+                else:
+                    geno[l, i] = (a1 == one) + (a2 == one)
+                for x in (a1, a2):
+                    if x != "0":
+                        tot += 1
+                        cnt += x == one
+            freq[l] = cnt / tot if tot else 0.0
+        keep = (freq > 0) & (freq < 1)
+        per_chr.append((geno[keep], freq[keep], pos[keep], cen[c]))
+    for W in (20, 45):
+        want = np.concatenate([
+            ol.oracle_flatten(ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, 200000), W)
+            for g, f, p, (cs, ce) in per_chr])
+        got = np.fromfile(f"{out}.{W}SNPs.lod.f64", dtype=np.float64)
+        assert ol.bits_equal(got, want), W

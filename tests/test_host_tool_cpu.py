@@ -1,0 +1,39 @@
+"""CPU: garlic-lod's flag validation mirrors the reference's Phase-I validators (src/garlic-cli.cpp:240-462)
+and the tool fails loudly when there is no GPU (no CPU fallback)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+E2E = os.path.join(ROOT, "tests", "golden", "e2e")
+TOOL = os.path.join(ROOT, "garlic_amd", "host", "garlic-lod")
+BASE = ["--tped", os.path.join(E2E, "tiny.tped.gz"), "--tfam", os.path.join(E2E, "tiny.tfam")]
+
+
+def run(*args):
+    return subprocess.run([TOOL, *args], capture_output=True, text=True)
+
+
+@pytest.mark.parametrize("args,msg", [
+    (BASE + ["--error", "0.001", "--winsize", "30"], "--build or --centromere"),
+    (BASE + ["--build", "hg19", "--winsize", "30"], "error rate must be > 0 and < 1"),
+    (BASE + ["--build", "hg19", "--error", "0.001", "--winsize", "1"], "window size must be > 1"),
+    (BASE + ["--build", "hg19", "--error", "0.001", "--winsize", "30", "--overlap-frac", "1.5"], "Overlap fraction"),
+    (BASE + ["--build", "hg19", "--tgls", "x.tgls", "--winsize", "30"], "GQ/GL/PL"),
+    (BASE + ["--build", "hg19", "--error", "0.001", "--winsize", "30", "--weighted"], "--map"),
+])
+def test_validators(args, msg):
+    r = run(*args)
+    assert r.returncode != 0 and msg in r.stderr
+
+
+def test_no_gpu_is_a_loud_failure(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = run(*BASE, "--centromere", os.path.join(E2E, "tiny.centromeres.txt"), "--error", "0.001",
+            "--winsize", "30", "--out", str(tmp_path / "x"))
+    assert r.returncode != 0
+    assert "Loaded 6000 loci x 24 individuals (3 chromosomes)" in r.stderr   # ingest ran
+    assert "no HIP device" in r.stderr or "garlic_ctx_create" in r.stderr

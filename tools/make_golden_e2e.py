@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""End-to-end text fixture: a tiny TPED/TFAM/centromere data set and what
+the reference's PREBUILT binary (/root/reference/bin/linux/garlic, v1.1.6a, static) writes for it:
+the allele-frequency file and the raw LOD windows (--raw-lod).  Build container only.
+The binary embeds its own libm and prints 6 significant digits, so this pins ingest, plumbing and
+formats -- the bit-level pin is tools/make_golden.py."""
+import glob
+import gzip
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden", "e2e")
+BIN = "/root/reference/bin/linux/garlic"
+
+
+def main():
+    rng = np.random.default_rng(20260105)
+    nind, W = 24, 30
+    os.makedirs(OUT, exist_ok=True)
+    lines = []
+    cen = []
+    alleles = "ACGT"
+    for c, n in ((1, 2500), (2, 2000), (7, 1500)):
+        pos = np.cumsum(rng.integers(200, 4000, size=n))
+        pos[n // 3:] += 250000                       # one > max_gap hole
+        k0 = n // 2
+        cen.append((c, int(pos[k0]) + 1, int(pos[k0]) + 40000))
+        pos[k0 + 1:] += 50000                        # centromere gap with no SNP inside
+        freq = rng.uniform(0.05, 0.95, size=n)
+        for l in range(n):
+            a, b = rng.choice(4, size=2, replace=False)
+            A, B = alleles[a], alleles[b]
+            g = []
+            for i in range(nind):
+                if rng.random() < 0.02:
+                    g += ["0", "0"]
+                else:
+                    g += [A if rng.random() < freq[l] else B, A if rng.random() < freq[l] else B]
+            lines.append(f"{c} rs{c}_{l} 0 {int(pos[l])} " + " ".join(g))
+    with gzip.open(os.path.join(OUT, "tiny.tped.gz"), "wt") as f:
+        f.write("\n".join(lines) + "\n")
+    with open(os.path.join(OUT, "tiny.tfam"), "w") as f:
+        for i in range(nind):
+            f.write(f"POP ind{i} 0 0 0 -9\n")
+    with open(os.path.join(OUT, "tiny.centromeres.txt"), "w") as f:
+        for c, s, e in cen:
+            f.write(f"{c} {s} {e}\n")
+    tmp = tempfile.mkdtemp()
+    cmd = [BIN, "--tped", os.path.join(OUT, "tiny.tped.gz"), "--tfam", os.path.join(OUT, "tiny.tfam"),
+           "--centromere", os.path.join(OUT, "tiny.centromeres.txt"), "--error", "0.001", "--winsize", str(W),
+           "--raw-lod", "--kde-subsample", "0", "--out", os.path.join(tmp, "ref")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    print(r.stdout[-400:], r.stderr[-800:])
+    for p in glob.glob(os.path.join(tmp, "ref*")):
+        print(" ", os.path.basename(p), os.path.getsize(p))
+    shutil.copy(os.path.join(tmp, "ref.freq.gz"), os.path.join(OUT, "ref.freq.gz"))
+    for p in glob.glob(os.path.join(tmp, "ref.*.raw.lod.windows.gz")):
+        shutil.copy(p, os.path.join(OUT, os.path.basename(p)))
+    with open(os.path.join(OUT, "COMMAND.txt"), "w") as f:
+        f.write("garlic v1.1.6a prebuilt binary:\n" + " ".join(os.path.basename(x) if x.startswith("/") else x for x in cmd) + "\n")
+    shutil.rmtree(tmp)
+
+
+if __name__ == "__main__":
+    main()
