@@ -166,6 +166,19 @@ class Panel:
         check(lib().garlic_panel_set_genotypes(self.handle, _vp(ptr), ld, locus_begin, locus_count,
                                                DEVICE))
 
+    def set_gl(self, gl, locus_begin=0):
+        """gl: float64 numpy array [nloci_chunk][>= nind]: per-genotype error probabilities (TGLS)."""
+        gl = np.asarray(gl)
+        assert gl.dtype == np.float64 and gl.ndim == 2 and gl.strides[1] == 8
+        check(lib().garlic_panel_set_gl(self.handle, _vp(gl.ctypes.data), gl.strides[0] // 8, locus_begin,
+                                        gl.shape[0], HOST))
+
+    def set_ld(self, winsize, ld):
+        """ld: float64 [nloci][winsize] LD weights of wLOD (all chromosomes concatenated)."""
+        ld = np.ascontiguousarray(ld, dtype=np.float64)
+        assert ld.shape == (self.nloci, winsize)
+        check(lib().garlic_panel_set_ld(self.handle, winsize, _vp(ld.ctypes.data), HOST))
+
     def out_layout(self, pitch_align=1, nind_out=None):
         nind_out = self.nind if nind_out is None else nind_out
         base = np.empty(self.nchr, dtype=np.int64)
@@ -183,6 +196,20 @@ class Panel:
         out = np.empty(total, dtype=np.float64)
         check(lib().garlic_lod_windows(self.handle, winsize, error, max_gap, int(use_gl), ind_begin,
                                        ind_count, pitch_align, _vp(out.ctypes.data), HOST))
+        res = []
+        for c in range(self.nchr):
+            n = int(self.chr_nloci[c])
+            blk = out[base[c]: base[c] + ind_count * pitch[c]].reshape(ind_count, pitch[c])
+            res.append(blk[:, :n])
+        return res
+
+    def wlod_windows(self, winsize, error, max_gap, M, mu, ind_begin=0, ind_count=None, pitch_align=1,
+                     use_gl=False):
+        ind_count = self.nind - ind_begin if ind_count is None else ind_count
+        base, pitch, total = self.out_layout(pitch_align, ind_count)
+        out = np.empty(total, dtype=np.float64)
+        check(lib().garlic_wlod_windows(self.handle, winsize, error, max_gap, int(use_gl), M, mu, ind_begin,
+                                        ind_count, pitch_align, _vp(out.ctypes.data), HOST))
         res = []
         for c in range(self.nchr):
             n = int(self.chr_nloci[c])

@@ -7,6 +7,7 @@
 // and the launches.  There is no CPU fallback: without a HIP device every compute call fails.
 #include "../../include/garlic_hip.h"
 #include "lod_kernels.hpp"
+#include "variant_kernels.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -16,6 +17,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 using namespace garlic;
@@ -135,6 +137,21 @@ struct garlic_panel {
     DevBuf<int32_t> d_counter;
     DevBuf<ChrDev> d_chrs;
     DevBuf<int16_t> d_stage16;
+    // TGLS: dictionary-coded per-genotype error probabilities
+    bool have_gl = false;
+    std::vector<double> gl_values;                 // code -> error probability
+    std::unordered_map<uint64_t, int> gl_code;     // bit pattern -> code
+    DevBuf<uint8_t> d_codes;                       // [GOFF+nloci+pad][nind_pad]
+    DevBuf<double> d_tabgl;
+    bool tabgl_valid = false;
+    int tabgl_ncodes = 0;
+    // wLOD
+    bool have_ld = false, wlod_use_gl = false;
+    int32_t ld_winsize = 0;
+    DevBuf<double> d_rld, d_decay, d_stage64;
+    bool decay_valid = false;
+    int32_t decay_M = 0;
+    double decay_mu = 0;
     DevBuf<double> d_out;
     garlic_call_stats stats{};
 };
@@ -267,8 +284,68 @@ void plan_runs(const garlic_panel *p, int32_t W, std::vector<Run> &runs, std::ve
     }
 }
 
-int launch_lod(garlic_panel *p, int32_t W, double error, int32_t max_gap, int32_t ind_begin,
-               int32_t ind_count, int32_t pitch_align, double *out, int32_t where)
+enum Mode { MODE_LOD, MODE_LOD_GL, MODE_WLOD };
+
+// ---- TGLS: term table per (SNP, error code, genotype), host libm
+int ensure_gl_table(garlic_panel *p)
+{
+    const int ncodes = (int)p->gl_values.size();
+    if (ncodes < 1) return fail(GARLIC_ERR_STATE, "use_gl set but no genotype likelihoods were given");
+    if (p->tabgl_valid && p->tabgl_ncodes == ncodes) return GARLIC_OK;
+    const int64_t rows = GOFF + p->nloci + GPAD_BACK;
+    std::vector<double> tab((size_t)rows * ncodes * 4, 0.0);
+    const double *freq = p->freq.data();
+    const double *val = p->gl_values.data();
+    double *t = tab.data() + (size_t)GOFF * ncodes * 4;
+    parallel_for(p->nloci, 1 << 12, [=](int64_t lo, int64_t hi) {
+        for (int64_t l = lo; l < hi; l++)
+            for (int c = 0; c < ncodes; c++) {
+                double *e = t + ((size_t)l * ncodes + c) * 4;
+                e[0] = host_lod(0, freq[l], val[c]);
+                e[1] = host_lod(1, freq[l], val[c]);
+                e[2] = host_lod(2, freq[l], val[c]);
+                e[3] = host_lod(-9, freq[l], val[c]);
+            }
+    });
+    int rc;
+    if ((rc = p->d_tabgl.reserve(tab.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(p->d_tabgl.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice,
+                           p->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    p->tabgl_valid = true;
+    p->tabgl_ncodes = ncodes;
+    return GARLIC_OK;
+}
+
+// ---- wLOD: per-SNP {nomut, norec} (garlic-roh.cpp:134-140, 246-249), host libm exp
+int ensure_decay_table(garlic_panel *p, int32_t M, double mu)
+{
+    if (!p->have_gpos) return fail(GARLIC_ERR_STATE, "wLOD needs genetic positions (set_map with gpos)");
+    if (p->decay_valid && p->decay_M == M && memcmp(&p->decay_mu, &mu, sizeof mu) == 0) return GARLIC_OK;
+    const int64_t rows = GOFF + p->nloci + GPAD_BACK;
+    std::vector<double> dec((size_t)rows * 2, 0.0);
+    for (int c = 0; c < p->nchr; c++)
+        for (int64_t l = p->chr_off[c]; l < p->chr_off[c + 1]; l++) {
+            const bool first = (l == p->chr_off[c]); // locus 0 of a chromosome: absolute position
+            const double dP = first ? (double)p->pos[l] : (double)(p->pos[l] - p->pos[l - 1]);
+            const double dG = first ? p->gpos[l] : (p->gpos[l] - p->gpos[l - 1]);
+            const double Md = M; // the reference passes the int M as a double parameter
+            dec[(GOFF + l) * 2 + 0] = exp(-2.0 * Md * mu * dP);
+            dec[(GOFF + l) * 2 + 1] = exp(-2.0 * Md * 1 * dG);
+        }
+    int rc;
+    if ((rc = p->d_decay.reserve(dec.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(p->d_decay.p, dec.data(), sizeof(double) * dec.size(), hipMemcpyHostToDevice,
+                           p->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    p->decay_valid = true;
+    p->decay_M = M;
+    p->decay_mu = mu;
+    return GARLIC_OK;
+}
+
+int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_gap, int32_t M, double mu,
+               int32_t ind_begin, int32_t ind_count, int32_t pitch_align, double *out, int32_t where)
 {
     garlic_ctx *ctx = p->ctx;
     int rc;
@@ -281,9 +358,18 @@ int launch_lod(garlic_panel *p, int32_t W, double error, int32_t max_gap, int32_
                     ind_count, p->nind);
     if (!out) return fail(GARLIC_ERR_INVALID, "out is NULL");
     if (pitch_align < 1) return fail(GARLIC_ERR_INVALID, "pitch_align must be >= 1");
+    const bool use_gl = (mode == MODE_LOD_GL) || (mode == MODE_WLOD && p->wlod_use_gl);
 
     if ((rc = ensure_segments(p, max_gap))) return rc;
-    if ((rc = ensure_term_table(p, error))) return rc;
+    if (use_gl) {
+        if (!p->have_gl) return fail(GARLIC_ERR_STATE, "use_gl set but no genotype likelihoods were given");
+        if ((rc = ensure_gl_table(p))) return rc;
+    } else if ((rc = ensure_term_table(p, error))) return rc;
+    if (mode == MODE_WLOD) {
+        if (!p->have_ld || p->ld_winsize != W)
+            return fail(GARLIC_ERR_STATE, "wLOD needs LD weights for winsize %d (garlic_panel_set_ld)", W);
+        if ((rc = ensure_decay_table(p, M, mu))) return rc;
+    }
 
     Layout L = make_layout(p, pitch_align, ind_count);
     for (int c = 0; c < p->nchr; c++)
@@ -295,8 +381,8 @@ int launch_lod(garlic_panel *p, int32_t W, double error, int32_t max_gap, int32_
     int64_t n_valid = 0;
     plan_runs(p, W, runs, fill, n_valid);
 
-    // Work list: (run, 64-individual block) items, longest runs first (LPT); the persistent waves
-    // of lod_chain_kernel pull them from a device counter.
+    // Work list: (run, 64-individual block) items, longest runs first (LPT); the persistent
+    // workgroups of lod_chain_kernel pull them from a device counter.
     std::vector<int> order(runs.size());
     for (size_t i = 0; i < runs.size(); i++) order[i] = (int)i;
     std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
@@ -311,7 +397,7 @@ int launch_lod(garlic_panel *p, int32_t W, double error, int32_t max_gap, int32_
     }
     // Persistent workgroups (2 waves each: CHAIN + POST), one per CU by default; items are pulled
     // longest first, so the short runs pack behind the long ones instead of competing with them
-    // for HBM bandwidth.  (LDS would allow 3 workgroups per CU.)
+    // for HBM bandwidth.  (LDS would allow 2 workgroups per CU.)
     int workers = 256;
     if (const char *e = getenv("GARLIC_WORKERS")) workers = std::max(1, atoi(e));
     workers = std::min<int>(workers, (int)items.size());
@@ -349,7 +435,7 @@ int launch_lod(garlic_panel *p, int32_t W, double error, int32_t max_gap, int32_
     }
     if (!items.empty()) HIP_TRY(hipMemsetAsync(p->d_counter.p, 0, sizeof(int32_t), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev_k0, ctx->stream));
-    if (!items.empty()) {
+    if (!items.empty() && mode == MODE_LOD) {
         ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p,     p->d_chrs.p,     d_out, p->nind_pad,
                     ind_begin,     ind_count,  W,               (int32_t)items.size(), p->d_counter.p};
         if (aligned16)
@@ -358,6 +444,23 @@ int launch_lod(garlic_panel *p, int32_t W, double error, int32_t max_gap, int32_
         else
             hipLaunchKernelGGL(lod_chain_kernel<false>, dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
                                ctx->stream, a);
+    } else if (!items.empty()) {
+        VariantArgs a{p->d_packed.p, p->d_tab.p,  p->d_tabgl.p, p->d_codes.p, p->d_decay.p, p->d_rld.p,
+                      p->d_items.p,  p->d_chrs.p, d_out,        p->nind_pad,  ind_begin,    ind_count,
+                      W,             (int32_t)p->gl_values.size(), use_gl ? 1 : 0};
+        if (mode == MODE_LOD_GL) {
+            hipLaunchKernelGGL(lod_chain_gl_kernel, dim3((unsigned)items.size()), dim3(WAVE), 0,
+                               ctx->stream, a);
+        } else {
+            const int ring = W + TILE;
+            const size_t lds = sizeof(double) * ((size_t)ring * WAVE + ((W + 1) & ~1) + (size_t)WAVE * TPITCH);
+            if (lds > 160 * 1024)
+                return fail(GARLIC_ERR_INVALID, "wLOD kernel of this build supports winsize <= %d", 240);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wlod_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(wlod_kernel, dim3((unsigned)items.size()), dim3(WAVE), lds, ctx->stream, a,
+                               ring);
+        }
     }
     HIP_TRY(hipEventRecord(ctx->ev_k1, ctx->stream));
     HIP_TRY(hipGetLastError());
@@ -514,7 +617,8 @@ int garlic_panel_destroy(garlic_panel *p)
     p->d_packed.release(); p->d_pos.release(); p->d_cs.release(); p->d_ce.release();
     p->d_chr_off.release(); p->d_tab.release(); p->d_blk_counts.release();
     p->d_blk_offsets.release(); p->d_total.release(); p->d_boundaries.release();
-    p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release();
+    p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release(); p->d_codes.release(); p->d_tabgl.release();
+    p->d_rld.release(); p->d_decay.release(); p->d_stage64.release();
     p->d_out.release();
     delete p;
     return GARLIC_OK;
@@ -542,6 +646,7 @@ int garlic_panel_set_map(garlic_panel *p, const int32_t *pos, const double *gpos
     HIP_TRY(hipStreamSynchronize(s));
     p->have_map = true;
     p->seg_valid = false;
+    p->decay_valid = false;
     return GARLIC_OK;
 }
 
@@ -551,6 +656,7 @@ int garlic_panel_set_freq(garlic_panel *p, const double *freq)
     p->freq.assign(freq, freq + p->nloci);
     p->have_freq = true;
     p->tab_valid = false;
+    p->tabgl_valid = false;
     return GARLIC_OK;
 }
 
@@ -596,14 +702,79 @@ int garlic_panel_set_genotypes(garlic_panel *p, const int16_t *geno, int64_t ld,
     return GARLIC_OK;
 }
 
-int garlic_panel_set_gl(garlic_panel *, const double *, int64_t, int64_t, int64_t, int32_t)
+int garlic_panel_set_gl(garlic_panel *p, const double *gl, int64_t ld, int64_t locus_begin,
+                        int64_t locus_count, int32_t where)
 {
-    return fail(GARLIC_ERR_STATE, "TGLS per-genotype likelihoods are not implemented in this build");
+    if (!p || !gl) return fail(GARLIC_ERR_INVALID, "panel and gl are required");
+    if (ld < p->nind) return fail(GARLIC_ERR_INVALID, "ld %lld < nind %d", (long long)ld, p->nind);
+    if (locus_begin < 0 || locus_count < 1 || locus_begin + locus_count > p->nloci)
+        return fail(GARLIC_ERR_INVALID, "locus range [%lld,+%lld) outside panel of %lld loci",
+                    (long long)locus_begin, (long long)locus_count, (long long)p->nloci);
+    int rc;
+    if ((rc = set_device(p->ctx))) return rc;
+    hipStream_t s = p->ctx->stream;
+    const int64_t rows_total = GOFF + p->nloci + GPAD_BACK;
+    if (!p->d_codes.p) {
+        if ((rc = p->d_codes.reserve((size_t)(rows_total * p->nind_pad)))) return rc;
+        HIP_TRY(hipMemsetAsync(p->d_codes.p, 0, (size_t)(rows_total * p->nind_pad), s));
+    }
+    // distinct error probabilities -> one-byte codes (the term table needs the host libm)
+    std::vector<double> host;
+    const double *src = gl;
+    if (where == GARLIC_DEVICE) {
+        host.resize((size_t)(locus_count * ld));
+        HIP_TRY(hipMemcpyAsync(host.data(), gl, sizeof(double) * host.size(), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        src = host.data();
+    }
+    std::vector<uint8_t> codes((size_t)(locus_count * p->nind_pad), 0);
+    for (int64_t l = 0; l < locus_count; l++)
+        for (int i = 0; i < p->nind; i++) {
+            uint64_t bits;
+            memcpy(&bits, &src[l * ld + i], sizeof bits);
+            auto it = p->gl_code.find(bits);
+            int code;
+            if (it == p->gl_code.end()) {
+                code = (int)p->gl_values.size();
+                if (code > 255)
+                    return fail(GARLIC_ERR_INVALID,
+                                "more than 256 distinct genotype-likelihood values: the dictionary "
+                                "TGLS path of this build needs quantised inputs (GQ / PL integers)");
+                p->gl_code.emplace(bits, code);
+                p->gl_values.push_back(src[l * ld + i]);
+                p->tabgl_valid = false;
+            } else code = it->second;
+            codes[(size_t)(l * p->nind_pad + i)] = (uint8_t)code;
+        }
+    HIP_TRY(hipMemcpyAsync(p->d_codes.p + (GOFF + locus_begin) * p->nind_pad, codes.data(), codes.size(),
+                           hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    p->have_gl = true;
+    return GARLIC_OK;
 }
 
-int garlic_panel_set_ld(garlic_panel *, int32_t, const double *, int32_t)
+int garlic_panel_set_ld(garlic_panel *p, int32_t winsize, const double *ld, int32_t where)
 {
-    return fail(GARLIC_ERR_STATE, "LD weights (wLOD) are not implemented in this build");
+    if (!p || !ld) return fail(GARLIC_ERR_INVALID, "panel and ld are required");
+    if (winsize <= 1) return fail(GARLIC_ERR_INVALID, "winsize must be > 1");
+    int rc;
+    if ((rc = set_device(p->ctx))) return rc;
+    hipStream_t s = p->ctx->stream;
+    const size_t n = (size_t)p->nloci * winsize;
+    if ((rc = p->d_rld.reserve(n))) return rc;
+    const double *src = ld;
+    if (where == GARLIC_HOST) {
+        if ((rc = p->d_stage64.reserve(n))) return rc;
+        HIP_TRY(hipMemcpyAsync(p->d_stage64.p, ld, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        src = p->d_stage64.p;
+    }
+    hipLaunchKernelGGL(reciprocal_kernel, dim3(2048), dim3(256), 0, s, src, p->d_rld.p, (int64_t)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    p->d_stage64.release();
+    p->have_ld = true;
+    p->ld_winsize = winsize;
+    return GARLIC_OK;
 }
 
 int garlic_lod_out_layout(garlic_panel *p, int32_t pitch_align, int32_t nind_out, int64_t *chr_base,
@@ -626,14 +797,18 @@ int garlic_lod_windows(garlic_panel *p, int32_t winsize, double error, int32_t m
                        double *out, int32_t where)
 {
     if (!p) return fail(GARLIC_ERR_INVALID, "panel is NULL");
-    if (use_gl) return fail(GARLIC_ERR_STATE, "TGLS per-genotype likelihoods are not implemented in this build");
-    return launch_lod(p, winsize, error, max_gap, ind_begin, ind_count, pitch_align, out, where);
+    return launch_lod(p, use_gl ? MODE_LOD_GL : MODE_LOD, winsize, error, max_gap, 0, 0.0, ind_begin,
+                      ind_count, pitch_align, out, where);
 }
 
-int garlic_wlod_windows(garlic_panel *, int32_t, double, int32_t, int32_t, int32_t, double, int32_t,
-                        int32_t, int32_t, double *, int32_t)
+int garlic_wlod_windows(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
+                        int32_t M, double mu, int32_t ind_begin, int32_t ind_count, int32_t pitch_align,
+                        double *out, int32_t where)
 {
-    return fail(GARLIC_ERR_STATE, "wLOD is not implemented in this build");
+    if (!p) return fail(GARLIC_ERR_INVALID, "panel is NULL");
+    p->wlod_use_gl = use_gl != 0;
+    return launch_lod(p, MODE_WLOD, winsize, error, max_gap, M, mu, ind_begin, ind_count, pitch_align,
+                      out, where);
 }
 
 int garlic_last_call_stats(garlic_panel *p, garlic_call_stats *stats)

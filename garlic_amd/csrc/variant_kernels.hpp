@@ -1,0 +1,148 @@
+// TGLS (per-genotype likelihood) and wLOD (gap-weighted) variants of the window LOD path.
+// Round-1 versions: compiler-scheduled, one wavefront per (run, 64 individuals) item, written
+// for exactness first (every FP64 operation in the reference's order); the unweighted --error path
+// in lod_kernels.hpp is the tuned one.
+//
+//   TGLS  src/garlic-roh.cpp:68,91-95,117 : error := GL[locus][ind] inside lod().  lod() needs the
+//         host libm's log10, so the distinct error values of a panel are dictionary-encoded
+//         (one byte per genotype) and the host tabulates lod(g, freq[l], error[code]) per SNP:
+//         term = tabgl[(l * ncodes + code) * 4 + g].
+//   wLOD  src/garlic-roh.cpp:204-277 : score[l] = (lod * nomut(dP[l])) * norec(dG[l]);
+//         win[s] = sum_{j<W} score[s+j] * (1.0 / LD[s][j]), left to right from +0.0, every valid
+//         window independently.  nomut/norec (host libm exp) come as one per-SNP pair; 1.0/LD is an
+//         IEEE division done once on the device.
+#pragma once
+#include "lod_kernels.hpp"
+
+namespace garlic {
+
+struct VariantArgs {
+    const uint32_t *packed;
+    const double *tab;        // [GOFF+nloci+pad][4]            (!use_gl)
+    const double *tabgl;      // [GOFF+nloci+pad][ncodes][4]    (use_gl)
+    const uint8_t *codes;     // [GOFF+nloci+pad][nind_pad]     (use_gl)
+    const double *decay;      // [GOFF+nloci+pad][2] = {nomut, norec} (wLOD)
+    const double *rld;        // [nloci][winsize] = 1.0 / LD    (wLOD)
+    const ChainItem *items;
+    const ChrDev *chrs;
+    double *out;
+    int64_t nind_pad;
+    int32_t ind_begin, ind_count, winsize, ncodes, use_gl;
+};
+
+// per-SNP term of this lane's individual; G = padded global locus index
+__device__ __forceinline__ double variant_term(const VariantArgs &p, int64_t G, int64_t col)
+{
+    const uint32_t word = p.packed[(G >> 4) * p.nind_pad + col];
+    const uint32_t g = (word >> (2 * (int)(G & 15))) & 3u;
+    if (p.use_gl) {
+        const uint32_t code = p.codes[G * p.nind_pad + col];
+        return p.tabgl[((G * p.ncodes) + code) * 4 + g];
+    }
+    return p.tab[G * 4 + g];
+}
+
+// masked transposed store of one 32-step tile held in LDS (64 rows x TPITCH doubles)
+__device__ __forceinline__ void variant_store(const double *tile, int s0, int a, int b, int lane,
+                                              int rows_valid, double *out_tile, int64_t pitch)
+{
+    const int rsub = lane >> 4, csub = lane & 15;
+    for (int q = 0; q < WAVE / 4; q++) {
+        const int r = 4 * q + rsub;
+        if (r >= rows_valid) continue;
+        const double v0 = tile[r * TPITCH + 2 * csub], v1 = tile[r * TPITCH + 2 * csub + 1];
+        double *dst = out_tile + (int64_t)r * pitch + 2 * csub;
+        const int s = s0 + 2 * csub;
+        if (s >= a && s <= b) dst[0] = v0;
+        if (s + 1 >= a && s + 1 <= b) dst[1] = v1;
+    }
+}
+
+// ---- TGLS: rolling sum with per-genotype error (garlic-roh.cpp:91-95)
+__global__ void __launch_bounds__(WAVE)
+lod_chain_gl_kernel(VariantArgs p)
+{
+    __shared__ double tile[WAVE * TPITCH];
+    const ChainItem it = p.items[blockIdx.x];
+    if (it.chr < 0) return;
+    const ChrDev c = p.chrs[it.chr];
+    const int lane = threadIdx.x, W = p.winsize, a = it.a, b = it.b;
+    const int rows_valid = min(WAVE, p.ind_count - it.ind0);
+    const int64_t col = (int64_t)p.ind_begin + it.ind0 + lane;
+    const int64_t Gbase = c.loc_base + GOFF;
+    double acc = 0.0;
+    for (int l = a; l < a + W - 1; l++) acc += variant_term(p, Gbase + l, col); // first window, W-1 terms
+    double *out_row0 = p.out + c.out_base + (int64_t)it.ind0 * c.out_pitch;
+    for (int s0 = a & ~(TILE - 1); s0 <= b; s0 += TILE) {
+        double t_in[TILE], t_out[TILE];
+#pragma unroll
+        for (int j = 0; j < TILE; j++) {
+            const int s = s0 + j;
+            const bool in = (s >= a && s <= b);
+            t_in[j] = in ? variant_term(p, Gbase + s + W - 1, col) : 0.0;
+            t_out[j] = (in && s > a) ? variant_term(p, Gbase + s - 1, col) : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < TILE; j++) {
+            acc = (acc - t_out[j]) + t_in[j];
+            tile[lane * TPITCH + j] = acc;
+        }
+        __syncthreads(); // one wave per block: orders the LDS writes above before the reads below
+        variant_store(tile, s0, a, b, lane, rows_valid, out_row0 + s0, c.out_pitch);
+    }
+}
+
+// ---- 1.0 / LD, IEEE division (garlic-roh.cpp:270 does it per use; the quotient is the same double)
+__global__ void reciprocal_kernel(const double *__restrict__ ld, double *__restrict__ rld, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) rld[i] = 1.0 / ld[i];
+}
+
+// ---- wLOD: every valid window summed afresh (garlic-roh.cpp:253-273)
+// dynamic LDS: score ring [ring][64] doubles | rld row [winsize] | transpose tile [64][TPITCH]
+__global__ void __launch_bounds__(WAVE)
+wlod_kernel(VariantArgs p, int ring)
+{
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    double *score = dyn;                              // [ring][64], slot = locus % ring
+    double *rrow = dyn + (size_t)ring * WAVE;         // [winsize]
+    double *tile = rrow + ((p.winsize + 1) & ~1);     // [64][TPITCH]
+    const ChainItem it = p.items[blockIdx.x];
+    if (it.chr < 0) return;
+    const ChrDev c = p.chrs[it.chr];
+    const int lane = threadIdx.x, W = p.winsize, a = it.a, b = it.b;
+    const int rows_valid = min(WAVE, p.ind_count - it.ind0);
+    const int64_t col = (int64_t)p.ind_begin + it.ind0 + lane;
+    const int64_t Gbase = c.loc_base + GOFF;
+    double *out_row0 = p.out + c.out_base + (int64_t)it.ind0 * c.out_pitch;
+    int have = a; // scores of loci [a, have) are in the ring
+    for (int s0 = a & ~(TILE - 1); s0 <= b; s0 += TILE) {
+        const int need = min(b, s0 + TILE - 1) + W; // loci < need are used by this tile
+        for (int l = have; l < need; l++) {
+            const int64_t G = Gbase + l;
+            // (lod * nomut) * norec, in that order (garlic-roh.cpp:249)
+            score[(l % ring) * WAVE + lane] = (variant_term(p, G, col) * p.decay[2 * G]) * p.decay[2 * G + 1];
+        }
+        have = max(have, need);
+        for (int j = 0; j < TILE; j++) {
+            const int s = s0 + j;
+            double sum = 0.0;
+            if (s >= a && s <= b) {
+                const double *src = p.rld + (c.loc_base + s) * (int64_t)W;
+                __syncthreads();
+                for (int k = lane; k < W; k += WAVE) rrow[k] = src[k];
+                __syncthreads();
+                for (int k = 0; k < W; k++)
+                    sum += score[((s + k) % ring) * WAVE + lane] * rrow[k]; // product rounded, then added
+            }
+            tile[lane * TPITCH + j] = sum;
+        }
+        __syncthreads();
+        variant_store(tile, s0, a, b, lane, rows_valid, out_row0 + s0, c.out_pitch);
+        __syncthreads();
+    }
+}
+
+} // namespace garlic

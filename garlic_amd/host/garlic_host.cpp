@@ -640,6 +640,28 @@ LodEngine::~LodEngine()
 
 std::vector<WinData *> *LodEngine::lodWindows(int winsize, double error, int MAX_GAP)
 {
+    return run(nullptr, winsize, error, MAX_GAP, 0, 0.0);
+}
+
+std::vector<WinData *> *LodEngine::wlodWindows(std::vector<LDData *> *lds, int winsize, double error, int MAX_GAP,
+                                               int M, double mu)
+{
+    // LDData rows are separate allocations: flatten to [locus][winsize] and hand to every device
+    int64_t nloci = 0;
+    for (int n : impl->chr_nloci) nloci += n;
+    std::vector<double> flat((size_t)nloci * winsize);
+    int64_t o = 0;
+    for (size_t c = 0; c < lds->size(); c++)
+        for (int l = 0; l < lds->at(c)->nloci; l++, o++)
+            memcpy(&flat[(size_t)o * winsize], lds->at(c)->LD[l], sizeof(double) * winsize);
+    for (auto &s : impl->shards) check(garlic_panel_set_ld(s.panel, winsize, flat.data(), GARLIC_HOST), "garlic_panel_set_ld");
+    return run(lds, winsize, error, MAX_GAP, M, mu);
+}
+
+std::vector<WinData *> *LodEngine::run(std::vector<LDData *> *lds, int winsize, double error, int MAX_GAP, int M,
+                                       double mu)
+{
+    const bool weighted = lds != nullptr;
     std::cerr << "Calculating LOD scores with winsize " << winsize << ".\n";
     std::vector<WinData *> *win = initWinData(impl->maps, impl->nind);
     const int nchr = (int)impl->chr_nloci.size();
@@ -659,8 +681,10 @@ std::vector<WinData *> *LodEngine::lodWindows(int winsize, double error, int MAX
                 const int n = std::min(chunk, s.nind - i0);
                 if (garlic_lod_out_layout(s.panel, 1, n, base.data(), pitch.data(), &total) != GARLIC_OK ||
                     (buf.resize((size_t)total), false) ||
-                    garlic_lod_windows(s.panel, winsize, error, MAX_GAP, impl->use_gl, i0, n, 1, buf.data(),
-                                       GARLIC_HOST) != GARLIC_OK) {
+                    (weighted ? garlic_wlod_windows(s.panel, winsize, error, MAX_GAP, impl->use_gl, M, mu, i0, n, 1,
+                                                    buf.data(), GARLIC_HOST)
+                              : garlic_lod_windows(s.panel, winsize, error, MAX_GAP, impl->use_gl, i0, n, 1,
+                                                   buf.data(), GARLIC_HOST)) != GARLIC_OK) {
                     errors[k] = garlic_hip_last_error();
                     return;
                 }
@@ -686,11 +710,14 @@ std::vector<WinData *> *calcLODWindows(std::vector<HapData *> *haps, std::vector
     return engine.lodWindows(winsize, error, MAX_GAP);
 }
 
-std::vector<WinData *> *calcwLODWindows(std::vector<HapData *> *, std::vector<FreqData *> *, std::vector<MapData *> *,
-                                        std::vector<GenoLikeData *> *, std::vector<LDData *> *, centromere *, int,
-                                        double, int, bool, int, double, int)
+std::vector<WinData *> *calcwLODWindows(std::vector<HapData *> *haps, std::vector<FreqData *> *freqs,
+                                        std::vector<MapData *> *maps, std::vector<GenoLikeData *> *gls,
+                                        std::vector<LDData *> *lds, centromere *centro, int winsize, double error,
+                                        int MAX_GAP, bool USE_GL, int M, double mu, int /*numThreads*/)
 {
-    fail("calcwLODWindows: the wLOD kernel is not part of this build yet");
+    // numThreads only partitions loci in the reference (garlic-data.cpp:538); the result does not depend on it
+    LodEngine engine(haps, freqs, maps, USE_GL ? gls : nullptr, centro, USE_GL, g_options.devices);
+    return engine.wlodWindows(lds, winsize, error, MAX_GAP, M, mu);
 }
 
 // ------------------------------------------------------------------------- consumers

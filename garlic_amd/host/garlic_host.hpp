@@ -148,10 +148,14 @@ public:
               centromere *centro, bool USE_GL, const std::vector<int> &devices);
     ~LodEngine();
     std::vector<WinData *> *lodWindows(int winsize, double error, int MAX_GAP);
+    std::vector<WinData *> *wlodWindows(std::vector<LDData *> *ldDataByChr, int winsize, double error,
+                                        int MAX_GAP, int M, double mu);
     LodEngine(const LodEngine &) = delete;
     LodEngine &operator=(const LodEngine &) = delete;
 
 private:
+    std::vector<WinData *> *run(std::vector<LDData *> *lds, int winsize, double error, int MAX_GAP, int M,
+                                double mu);
     struct Impl;
     Impl *impl;
 };

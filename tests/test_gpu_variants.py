@@ -1,0 +1,101 @@
+"""GPU parity of the TGLS (per-genotype likelihood) and wLOD (gap-weighted) variants, bit for bit
+against the reference's golden outputs and the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from garlic_amd import abi
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_tgls_golden(gpu_ctx):
+    d = np.load(os.path.join(G, "tgls_lod.npz"))
+    cs, ce = (int(x) for x in d["centro"])
+    n, nind = d["geno"].shape
+    with abi.Panel(gpu_ctx, [n], nind) as panel:
+        panel.set_map(d["pos"], [cs], [ce])
+        panel.set_freq(d["freq"])
+        panel.set_genotypes(d["geno"])
+        panel.set_gl(d["gl_error"])
+        for W in (10, 60):
+            for pa in (1, 32):
+                out = panel.lod_windows(W, 0.001, int(d["max_gap"]), use_gl=True, pitch_align=pa)
+                assert ol.bits_equal(np.ascontiguousarray(out[0]), d[f"win_W{W}"]), (W, pa)
+        # the --error path of the same panel is unaffected by the GL data
+        want = ol.oracle_calc_lod(d["geno"], d["freq"], d["pos"], cs, ce, 10, 0.001, int(d["max_gap"]))
+        assert ol.bits_equal(np.ascontiguousarray(panel.lod_windows(10, 0.001, int(d["max_gap"]))[0]), want)
+
+
+def test_tgls_random_multichr_and_chunked_upload(gpu_ctx):
+    rng = np.random.default_rng(77)
+    mg = 200000
+    chroms = [ol.random_panel(rng, n, 70, max_gap=mg) for n in (600, 333)]
+    gq = [rng.integers(3, 61, size=c[0].shape).astype(np.float64) for c in chroms]
+    err = [np.vectorize(lambda x: ol.oracle().oracle_tgls_to_error(float(x), 0))(q) for q in gq]
+    with abi.Panel(gpu_ctx, [600, 333], 70) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms])
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        allerr = np.concatenate(err, axis=0)
+        for l0 in range(0, 933, 200):
+            panel.set_gl(allerr[l0:l0 + 200], locus_begin=l0)
+        out = panel.lod_windows(25, 0.5, mg, use_gl=True, pitch_align=32)
+        for c, (g, f, p, cs, ce) in enumerate(chroms):
+            want = ol.oracle_calc_lod(g, f, p, cs, ce, 25, 0.5, mg, gl=err[c])
+            assert ol.bits_equal(np.ascontiguousarray(out[c]), want), c
+
+
+def test_too_many_distinct_likelihoods_is_refused(gpu_ctx):
+    rng = np.random.default_rng(3)
+    g, f, p, cs, ce = ol.random_panel(rng, 100, 8)
+    with abi.Panel(gpu_ctx, [100], 8) as panel:
+        with pytest.raises(abi.GarlicError) as e:
+            panel.set_gl(rng.uniform(0.001, 0.5, size=(100, 8)))
+        assert e.value.code == abi.ERR_INVALID
+
+
+def test_wlod_golden(gpu_ctx):
+    d = np.load(os.path.join(G, "wlod.npz"))
+    cs, ce = (int(x) for x in d["centro"])
+    n, nind = d["geno"].shape
+    with abi.Panel(gpu_ctx, [n], nind) as panel:
+        panel.set_map(d["pos"], [cs], [ce], gpos=d["gpos"])
+        panel.set_freq(d["freq"])
+        panel.set_genotypes(d["geno"])
+        for W in (10, 30):
+            panel.set_ld(W, d[f"ldsafe_W{W}"])
+            for pa in (1, 32):
+                out = panel.wlod_windows(W, float(d["error"]), int(d["max_gap"]), int(d["M"]), float(d["mu"]),
+                                         pitch_align=pa)
+                assert ol.bits_equal(np.ascontiguousarray(out[0]), d[f"win_W{W}"]), (W, pa)
+        with pytest.raises(abi.GarlicError):     # LD weights are for W=30 now
+            panel.wlod_windows(10, 0.001, 200000, 7, 1e-9)
+
+
+def test_wlod_random_multichr_with_gl(gpu_ctx):
+    rng = np.random.default_rng(8)
+    mg, W = 200000, 40
+    chroms = [ol.random_panel(rng, n, 66, max_gap=mg, mono=0.0) for n in (500, 260)]
+    gpos = [np.cumsum(np.diff(c[2], prepend=0) * 1e-6 * rng.uniform(0.8, 1.2, size=c[2].shape[0])) for c in chroms]
+    lds = []
+    for c in chroms:
+        ld = ol.oracle_hr2_ld(c[0], W)
+        lds.append(np.where(np.isfinite(ld) & (ld > 0), ld, 1.0))
+    err = [rng.choice([1e-16, 1e-3, 0.01, 0.5, 1.0], size=c[0].shape) for c in chroms]
+    with abi.Panel(gpu_ctx, [500, 260], 66) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms],
+                      gpos=np.concatenate(gpos))
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        panel.set_gl(np.concatenate(err, axis=0))
+        panel.set_ld(W, np.concatenate(lds, axis=0))
+        for use_gl in (False, True):
+            out = panel.wlod_windows(W, 0.001, mg, 7, 1e-9, use_gl=use_gl, pitch_align=32)
+            for c, (g, f, p, cs, ce) in enumerate(chroms):
+                want = ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, 0.001, mg, 1e-9, 7,
+                                           gl=err[c] if use_gl else None)
+                assert ol.bits_equal(np.ascontiguousarray(out[c]), want), (use_gl, c)
