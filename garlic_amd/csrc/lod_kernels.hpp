@@ -251,7 +251,7 @@ constexpr uint32_t SLOT_BYTES = 3072;
 constexpr uint32_t SL_LW1 = 0, SL_LW2 = 256, SL_TW1 = 512, SL_TW2 = 768;
 constexpr uint32_t SL_LTAB = 1024, SL_TTAB = 2048;
 constexpr uint32_t LDS_ITEM = 3072;                              // broadcast word for the item index
-constexpr uint32_t LDS_TILE = 22528;                             // TILE buffer 0 of the asm loop
+constexpr uint32_t LDS_TILE = GARLIC_CHAIN_LDS_TILE0;                             // TILE buffer 0 of the asm loop
 constexpr uint32_t LDS_BYTES = GARLIC_CHAIN_LDS_TOTAL;
 constexpr int CHAIN_THREADS = 128;
 

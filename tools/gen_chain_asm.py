@@ -16,58 +16,70 @@ the extra LDS traffic saturates the CU's LDS pipeline.
                  src/garlic-roh.cpp:98-100), acc -> transpose tile (ds_write_b128 per 2 steps)
                  -- no vector-memory instruction at all: a request of its own would queue behind
                  POST's stores in the CU's memory pipeline and stall the chain (measured: +30 %)
-  wave 1  POST   LDS-DMA prefetch of CHAIN's genotype words / term rows (6-slot ring, requested
-                 5 tiles ahead, confirmed landed 2 tiles ahead); transposed write-out of the
-                 previous tile: 16 x (ds_read_b128 -> global_store_dwordx4), 4 rows x 256 B each
+  wave 1  POST   LDS-DMA prefetch of CHAIN's genotype words / term rows (8-slot ring) and the
+                 transposed write-out of finished tiles: 16 x (ds_read_b128 ->
+                 global_store_dwordx4), 4 rows x 256 B per store
+
+The two waves are decoupled: 4 transpose-tile buffers and three LDS counters instead of a barrier
+per tile (a barrier makes every POST stall -- HBM back-pressure comes in bursts -- a CHAIN stall):
+    tiles_done     CHAIN -> POST   tile k is complete in LDS, input slot k is released
+    tiles_stored   POST -> CHAIN   tile buffer k has been read back (may be overwritten)
+    inputs_landed  POST -> CHAIN   highest tile whose inputs are confirmed in the ring
+POST's vector-memory operations retire in issue order: vmcnt(60) before requesting tile k+8 proves
+everything older than the last 3 tiles' 48 stores + 12 requests has completed, i.e. the inputs of
+tile k+5.
 
 CHAIN per tile (32 window starts x 64 individuals), software pipeline over 8-step batches g:
     A(g)  byte offsets (genotype*8) of the batch's entering / leaving terms in their table rows
     R(g)  16 ds_read_b64 into one of two 32-VGPR buffers
     C(g)  the chain + tile writes, with A(g+2) woven in
-  iteration g:  wait R(g) | issue R(g+1) | C(g) (+) A(g+2);   one s_barrier per tile; the
-  transpose tile is double buffered (CHAIN writes tile k while POST stores tile k-1).
-POST's vector-memory operations retire in issue order; per stage it waits vmcnt(60) (= the 3 x 16
-stores and 2 x 6 requests younger than the tile-after-next's inputs stay in flight), requests the
-inputs 5 tiles ahead, then stores.
+  iteration g:  wait R(g) | issue R(g+1) | C(g) (+) A(g+2)
 
 LDS map (bytes; must match lod_kernels.hpp):
-      0  generic-path slot (3072) + item word           (not touched here)
-   4096  ring: 6 slots x 3072 {lead w+1, lead w+2, trail w+1, trail w+2 (256 each),
+      0  generic-path slot (3072), item word (3072), flags (3584)   (flags used here)
+   4096  ring: 8 slots x 3072 {lead w+1, lead w+2, trail w+1, trail w+2 (256 each),
                                lead term rows 1024, trail term rows 1024}
-  22528  TILE[2][64 rows x 272 B]
+  28672  TILE[4][64 rows x 272 B]
 """
 import os
+
+
 ABL = os.environ.get("GARLIC_ABLATE", "")
 
-NSLOT = 6
+NSLOT = int(os.environ.get("GARLIC_NSLOT", "8"))
+NTILE = int(os.environ.get("GARLIC_NTILE", "4"))
 RING = 4096
 SLOT = 3072
 SL_LW1, SL_LW2, SL_TW1, SL_TW2, SL_LTAB, SL_TTAB = 0, 256, 512, 768, 1024, 2048
+FLAGS = 3584          # +0 tiles_done, +4 tiles_stored, +8 inputs_landed
 TILE_BASE = RING + NSLOT * SLOT
 TILE_BUF = 64 * 34 * 8
 TPITCH_B = 34 * 8
-LDS_TOTAL = TILE_BASE + 2 * TILE_BUF
+LDS_TOTAL = TILE_BASE + NTILE * TILE_BUF
 
-# ---- fixed VGPRs (clobbered by the block)
-V_BUF = [100, 132]          # two term buffers, 16 x 64-bit each
-V_ADDR = 164                # 16 LDS byte offsets
-V_ACC = 180                 # 4 VGPRs: P0 = [180:181], P1 = [182:183]
+# ---- fixed VGPRs (clobbered by the block; each wave has its own register file)
+V_BUF = [100, 132]          # CHAIN: two term buffers, 16 x 64-bit each
+V_ADDR = 164                # CHAIN: 16 LDS byte offsets
+V_ACC = 180                 # CHAIN: P0 = [180:181], P1 = [182:183]
 V_LL, V_LH, V_TL, V_TH = 184, 185, 186, 187
 V_WL1, V_WL2, V_WT1, V_WT2 = 188, 189, 190, 191
 V_LANE4, V_LANE16, V_VOFFA, V_VOFFB, V_TWR, V_TRD = 192, 193, 194, 195, 196, 197
-V_STOFF = 198               # 16 store offsets
-V_ST = 24                   # 64 VGPRs of store data: v24..v87
+V_STOFF = 198               # POST: 16 store offsets
+V_ST = 24                   # POST: 64 VGPRs of store data
 V_LC, V_TC = 214, 215
+V_FLAG, V_TRD2, V_TMP0, V_TMP1 = 216, 217, 218, 219   # TMP pair 64-bit aligned (ds_read2 dst)
 # ---- fixed SGPRs
 S_PLEAD, S_PTRAIL, S_PLTAB, S_PTTAB = 40, 42, 44, 46
-S_ROWINC = 48               # 2*npad*4 bytes
+S_ROWINC = 48
 S_OUT = 50
 S_CNT = 52
 S_SHL, S_SHT = 53, 54
 S_TMP = 55
+S_K = 56
+S_F0, S_F1 = 57, 58
 
-CLOBBER_V = sorted(set(list(range(V_ST, V_ST + 64)) + list(range(100, 216))))
-CLOBBER_S = list(range(40, 56))
+CLOBBER_V = sorted(set(list(range(V_ST, V_ST + 64)) + list(range(100, 220))))
+CLOBBER_S = list(range(40, 59))
 
 
 class Gen:
@@ -91,8 +103,8 @@ class Gen:
         self.emit(f"s_waitcnt lgkmcnt({n})")
         self.complete = self.issued - n
 
-    def reset_lds(self):
-        assert self.complete == self.issued, "LDS queue must be drained at a tile boundary"
+    def drained(self):
+        """the caller just emitted s_waitcnt lgkmcnt(0)"""
         self.issued = self.complete = 0
 
 
@@ -104,6 +116,7 @@ def quad(r):
     return f"v[{r}:{r + 3}]"
 
 
+# ------------------------------------------------------------------ CHAIN
 def addr_ops(j):
     """the 4 VALU ops producing the LDS byte offsets of step j's leaving/entering terms"""
     k = j % 16
@@ -122,14 +135,15 @@ def addr_ops(j):
     return ops
 
 
-def gen_A(g, n):
+def all_addr_ops(n):
+    ops = []
     for i in range(8):
-        for op in addr_ops(8 * n + i):
-            g.emit(op)
+        ops += addr_ops(8 * n + i)
+    return ops
 
 
 def gen_R(g, slot, n):
-    """issue the 16 term reads of batch n of a tile living in `slot`; returns id of the last"""
+    """issue the 16 term reads of batch n of the tile living in ring slot `slot`"""
     buf = V_BUF[n % 2]
     last = 0
     for i in range(8):
@@ -147,25 +161,19 @@ def gen_C(g, n, a_ops, tbuf):
     for i in range(8):
         j = 8 * n + i
         dst, prev = (P0, P1) if j % 2 == 0 else (P1, P0)
-        g.emit(f"v_add_f64 {pair(dst)}, {pair(prev)}, -{pair(buf + 4 * i)}")
+        if "nodp" not in ABL:
+            g.emit(f"v_add_f64 {pair(dst)}, {pair(prev)}, -{pair(buf + 4 * i)}")
         for _ in range(2):
             if a_ops:
                 g.emit(a_ops.pop(0))
-        g.emit(f"v_add_f64 {pair(dst)}, {pair(dst)}, {pair(buf + 4 * i + 2)}")
+        if "nodp" not in ABL:
+            g.emit(f"v_add_f64 {pair(dst)}, {pair(dst)}, {pair(buf + 4 * i + 2)}")
         for _ in range(2):
             if a_ops:
                 g.emit(a_ops.pop(0))
-        if j % 2 == 1:
-            if "chainwrite" not in ABL:
-                g.lds(f"ds_write_b128 v{V_TWR}, {quad(V_ACC)} offset:{tbuf * TILE_BUF + 8 * (j - 1)}")
+        if j % 2 == 1 and "chainwrite" not in ABL:
+            g.lds(f"ds_write_b128 v{V_TWR}, {quad(V_ACC)} offset:{tbuf * TILE_BUF + 8 * (j - 1)}")
     assert not a_ops
-
-
-def all_addr_ops(n):
-    ops = []
-    for i in range(8):
-        ops += addr_ops(8 * n + i)
-    return ops
 
 
 def gen_words(g, slot):
@@ -183,19 +191,126 @@ def gen_funnel(g):
     g.emit(f"v_mov_b32_e32 v{V_TC}, v{V_WT2}")
 
 
+def chain_tile(g, slot, uid):
+    """CHAIN, one tile k: ring slot = k % NSLOT, tile buffer = k % NTILE"""
+    nxt = (slot + 1) % NSLOT
+    tbuf = slot % NTILE
+    e = g.emit
+    if "nosync" not in ABL:
+        # wait until POST has (a) read back the tile that last used this tile buffer and (b) confirmed
+        # the inputs of the NEXT tile (its words are read in batch 1, its terms from batch 3 on)
+        e(f"CHAIN_POLL_{uid}_%=:")
+        e(f"ds_read2_b32 v[{V_TMP0}:{V_TMP1}], v{V_FLAG} offset0:1 offset1:2")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"v_readfirstlane_b32 s{S_F0}, v{V_TMP0}")
+        e(f"v_readfirstlane_b32 s{S_F1}, v{V_TMP1}")
+        e(f"s_add_u32 s{S_F0}, s{S_F0}, {NTILE - 1}")
+        e(f"s_cmp_ge_u32 s{S_F0}, s{S_K}")           # tiles_stored >= k - (NTILE-1)
+        e(f"s_cbranch_scc0 CHAIN_SLEEP_{uid}_%=")
+        e(f"s_cmp_gt_u32 s{S_F1}, s{S_K}")           # inputs_landed >= k + 1
+        e(f"s_cbranch_scc1 CHAIN_GO_{uid}_%=")
+        e(f"CHAIN_SLEEP_{uid}_%=:")
+        e("s_sleep 1")
+        e(f"s_branch CHAIN_POLL_{uid}_%=")
+        e(f"CHAIN_GO_{uid}_%=:")
+    else:
+        e("s_waitcnt lgkmcnt(0)")
+    g.drained()
+    # batch 0: R(k,0) is complete (the poll drained the LDS queue)
+    r1 = gen_R(g, slot, 1)
+    gen_C(g, 0, all_addr_ops(2), tbuf)
+    # batch 1
+    words = gen_words(g, nxt)
+    g.wait_lds(r1)
+    r2 = gen_R(g, slot, 2)
+    gen_C(g, 1, all_addr_ops(3), tbuf)
+    # batch 2: bits of tile k+1 replace those of tile k (A(k,3) is done)
+    g.wait_lds(r2)
+    assert words <= g.complete
+    gen_funnel(g)
+    r3 = gen_R(g, slot, 3)
+    gen_C(g, 2, all_addr_ops(0), tbuf)
+    # batch 3
+    g.wait_lds(r3)
+    gen_R(g, nxt, 0)
+    gen_C(g, 3, all_addr_ops(1), tbuf)
+    # publish: tile k complete in LDS (its writes are waited for), input slot k released
+    e(f"s_add_u32 s{S_K}, s{S_K}, 1")
+    e(f"v_mov_b32_e32 v{V_TMP0}, s{S_K}")
+    e("s_waitcnt lgkmcnt(0)")
+    g.drained()
+    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP0}")
+
+
+def gen_chain(g):
+    e = g.emit
+    e("ROLE_CHAIN_%=:")
+    e(f"s_mov_b32 s{S_CNT}, %[ntiles]")
+    e(f"s_mov_b32 s{S_SHL}, %[shl]")
+    e(f"s_mov_b32 s{S_SHT}, %[sht]")
+    e(f"s_mov_b32 s{S_K}, 0")
+    e(f"v_mov_b64 {pair(V_ACC + 2)}, %[acc]")
+    e(f"v_mov_b32_e32 v{V_LC}, %[lc]")
+    e(f"v_mov_b32_e32 v{V_TC}, %[tc]")
+    e(f"v_lshlrev_b32_e32 v{V_LANE4}, 2, %[lane]")
+    e(f"v_mul_u32_u24_e32 v{V_TWR}, {TPITCH_B}, %[lane]")
+    e(f"v_add_u32_e32 v{V_TWR}, {TILE_BASE}, v{V_TWR}")
+    e(f"v_mov_b32_e32 v{V_FLAG}, {FLAGS}")
+    e(f"v_mov_b32_e32 v{V_TMP0}, 0")
+    e(f"v_mov_b32_e32 v{V_TMP1}, 0")
+    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP0}")                                  # tiles_done = 0
+    e(f"ds_write2_b32 v{V_FLAG}, v{V_TMP0}, v{V_TMP1} offset0:1 offset1:2")  # stored = landed = 0
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_barrier")  # the previous item's counters are gone; POST may start
+    e("CHAIN_FIRST_%=:")  # wait for the ring's initial fill
+    e(f"ds_read_b32 v{V_TMP1}, v{V_FLAG} offset:8")
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"v_readfirstlane_b32 s{S_F1}, v{V_TMP1}")
+    e(f"s_cmp_gt_u32 s{S_F1}, 0")
+    e("s_cbranch_scc1 CHAIN_START_%=")
+    e("s_sleep 2")
+    e("s_branch CHAIN_FIRST_%=")
+    e("CHAIN_START_%=:")
+    g.drained()
+    # pipeline prologue for the first tile (slot 0)
+    w = gen_words(g, 0)
+    g.wait_lds(w)
+    gen_funnel(g)
+    for op in all_addr_ops(0):
+        e(op)
+    gen_R(g, 0, 0)
+    for op in all_addr_ops(1):
+        e(op)
+    e("CHAIN_LOOP_%=:")
+    for slot in range(NSLOT):
+        chain_tile(g, slot, slot)
+        e(f"s_cmp_eq_u32 s{S_K}, s{S_CNT}")
+        if slot < NSLOT - 1:
+            e("s_cbranch_scc1 CHAIN_DONE_%=")
+        else:
+            e("s_cbranch_scc0 CHAIN_LOOP_%=")
+    e("CHAIN_DONE_%=:")
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"v_mov_b64 %[acc], {pair(V_ACC + 2)}")
+    e("s_branch DONE_%=")
+
+
+# ------------------------------------------------------------------ POST
 def gen_prefetch(g, slot):
-    """6 LDS-DMA requests for the tile 4 ahead into `slot`, then advance the prefetch pointers.
-    An SALU write of M0 needs a wait state before the LDS-DMA reads it: the pointer adds sit there."""
+    """6 LDS-DMA requests for one tile into ring slot `slot`, then advance the prefetch pointers.
+    An SALU write of M0 needs a wait state before the LDS-DMA reads it (gfx9 family)."""
+    if "nodma" in ABL:
+        return
     base = RING + slot * SLOT
     seq = [
-        (base + SL_LW1, f"global_load_lds_dword v{V_VOFFA}, s[{S_PLEAD}:{S_PLEAD + 1}]", None),
-        (base + SL_LW2, f"global_load_lds_dword v{V_VOFFB}, s[{S_PLEAD}:{S_PLEAD + 1}]", None),
-        (base + SL_TW1, f"global_load_lds_dword v{V_VOFFA}, s[{S_PTRAIL}:{S_PTRAIL + 1}]", None),
-        (base + SL_TW2, f"global_load_lds_dword v{V_VOFFB}, s[{S_PTRAIL}:{S_PTRAIL + 1}]", None),
-        (base + SL_LTAB, f"global_load_lds_dwordx4 v{V_LANE16}, s[{S_PLTAB}:{S_PLTAB + 1}]", None),
-        (base + SL_TTAB, f"global_load_lds_dwordx4 v{V_LANE16}, s[{S_PTTAB}:{S_PTTAB + 1}]", None),
+        (base + SL_LW1, f"global_load_lds_dword v{V_VOFFA}, s[{S_PLEAD}:{S_PLEAD + 1}]"),
+        (base + SL_LW2, f"global_load_lds_dword v{V_VOFFB}, s[{S_PLEAD}:{S_PLEAD + 1}]"),
+        (base + SL_TW1, f"global_load_lds_dword v{V_VOFFA}, s[{S_PTRAIL}:{S_PTRAIL + 1}]"),
+        (base + SL_TW2, f"global_load_lds_dword v{V_VOFFB}, s[{S_PTRAIL}:{S_PTRAIL + 1}]"),
+        (base + SL_LTAB, f"global_load_lds_dwordx4 v{V_LANE16}, s[{S_PLTAB}:{S_PLTAB + 1}]"),
+        (base + SL_TTAB, f"global_load_lds_dwordx4 v{V_LANE16}, s[{S_PTTAB}:{S_PTTAB + 1}]"),
     ]
-    for m0, ld, _ in seq:
+    for m0, ld in seq:
         g.emit(f"s_mov_b32 m0, {m0}")
         g.emit("s_nop 0")
         g.emit(ld)
@@ -208,93 +323,41 @@ def gen_prefetch(g, slot):
             g.emit(f"s_addc_u32 s{p + 1}, s{p + 1}, 0")
 
 
-def gen_tile(g, slot):
-    nxt = (slot + 1) % NSLOT
-    tbuf = slot % 2
-    if "nochain" in ABL:
-        g.emit("s_barrier")
-        return
-    g.emit(f"; ---- tile in slot {slot}")
-    g.reset_lds()
-    # batch 0: R(k,0) finished at the previous boundary
-    r1 = gen_R(g, slot, 1)
-    gen_C(g, 0, all_addr_ops(2), tbuf)
-    # batch 1 (POST confirmed the next tile's inputs before the previous barrier)
-    words = gen_words(g, nxt)
-    g.wait_lds(r1)
-    r2 = gen_R(g, slot, 2)
-    gen_C(g, 1, all_addr_ops(3), tbuf)
-    # batch 2: bits of tile k+1 replace those of tile k (A(k,3) is done)
-    g.wait_lds(r2)
-    assert words <= g.complete
-    gen_funnel(g)
-    r3 = gen_R(g, slot, 3)
-    gen_C(g, 2, all_addr_ops(0), tbuf)
-    # batch 3: slot k is free once R(k,3) has landed
-    g.wait_lds(r3)
-    gen_R(g, nxt, 0)
-    gen_C(g, 3, all_addr_ops(1), tbuf)
-    g.emit("s_waitcnt lgkmcnt(0)")
-    g.complete = g.issued
-    g.emit("s_barrier")
-
-
-def gen_chain(g):
+def post_tile(g, slot, uid):
+    """POST, one tile k: ring slot = k % NSLOT, tile buffer = k % NTILE"""
+    tbuf = slot % NTILE
     e = g.emit
-    e("ROLE_CHAIN_%=:")
-    e(f"s_mov_b32 s{S_CNT}, %[ntiles]")
-    e(f"s_mov_b32 s{S_SHL}, %[shl]")
-    e(f"s_mov_b32 s{S_SHT}, %[sht]")
-    e(f"v_mov_b64 {pair(V_ACC + 2)}, %[acc]")
-    e(f"v_mov_b32_e32 v{V_LC}, %[lc]")
-    e(f"v_mov_b32_e32 v{V_TC}, %[tc]")
-    e(f"v_lshlrev_b32_e32 v{V_LANE4}, 2, %[lane]")
-    e(f"v_mul_u32_u24_e32 v{V_TWR}, {TPITCH_B}, %[lane]")
-    e(f"v_add_u32_e32 v{V_TWR}, {TILE_BASE}, v{V_TWR}")
-    e("s_barrier")  # POST has filled the ring with the first 5 tiles
-    # pipeline prologue for the first tile (slot 0)
-    w = gen_words(g, 0)
-    g.wait_lds(w)
-    gen_funnel(g)
-    gen_A(g, 0)
-    r0 = gen_R(g, 0, 0)
-    gen_A(g, 1)
-    g.wait_lds(r0)
-    e("CHAIN_LOOP_%=:")
-    for slot in range(NSLOT):
-        gen_tile(g, slot)
-        e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
-        e(f"s_cmp_eq_u32 s{S_CNT}, 0")
-        if slot < NSLOT - 1:
-            e("s_cbranch_scc1 CHAIN_DONE_%=")
-        else:
-            e("s_cbranch_scc0 CHAIN_LOOP_%=")
-    e("CHAIN_DONE_%=:")
-    e("s_barrier")  # POST stores the last tile
-    e(f"v_mov_b64 %[acc], {pair(V_ACC + 2)}")
-    e("s_branch DONE_%=")
-
-
-def post_stage(g, slot_next, tbuf, store=True, drain=False):
-    """one POST stage: confirm the inputs CHAIN touches next stage, request the tile 5 ahead into the
-    slot CHAIN released last stage, store the tile CHAIN finished last stage"""
-    g.reset_lds()
-    g.emit("s_waitcnt vmcnt(60)")
-    gen_prefetch(g, slot_next)
-    if drain:
-        g.emit("s_waitcnt vmcnt(0)")
-    if store and "nopost" not in ABL:
+    e(f"POST_POLL_{uid}_%=:")  # wait for CHAIN to finish tile k
+    e(f"ds_read_b32 v{V_TMP0}, v{V_FLAG}")
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"v_readfirstlane_b32 s{S_F0}, v{V_TMP0}")
+    e(f"s_cmp_gt_u32 s{S_F0}, s{S_K}")               # tiles_done >= k + 1
+    e(f"s_cbranch_scc1 POST_GO_{uid}_%=")
+    e("s_sleep 1")
+    e(f"s_branch POST_POLL_{uid}_%=")
+    e(f"POST_GO_{uid}_%=:")
+    g.drained()
+    e("s_waitcnt vmcnt(60)")   # confirms the inputs requested 3 iterations ago (tile k+NSLOT-3)
+    gen_prefetch(g, slot)      # slot k is free: request tile k+NSLOT into it
+    if "nopost" not in ABL:
         ids = []
         for q in range(16):
-            ids.append(g.lds(f"ds_read_b128 {quad(V_ST + 4 * q)}, v{V_TRD} offset:{tbuf * TILE_BUF + q * 4 * TPITCH_B}"))
+            # DS offsets are 16 bit: tile buffers 2,3 are addressed from a second base register
+            base, rel = (V_TRD, tbuf) if tbuf < 2 else (V_TRD2, tbuf - 2)
+            ids.append(g.lds(f"ds_read_b128 {quad(V_ST + 4 * q)}, v{base} offset:{rel * TILE_BUF + q * 4 * TPITCH_B}"))
         for q in range(16):
             g.wait_lds(ids[q])
             if "poststore" not in ABL:
-                g.emit(f"global_store_dwordx4 v{V_STOFF + q}, {quad(V_ST + 4 * q)}, s[{S_OUT}:{S_OUT + 1}]")
-        g.emit(f"s_add_u32 s{S_OUT}, s{S_OUT}, 256")
-        g.emit(f"s_addc_u32 s{S_OUT + 1}, s{S_OUT + 1}, 0")
+                e(f"global_store_dwordx4 v{V_STOFF + q}, {quad(V_ST + 4 * q)}, s[{S_OUT}:{S_OUT + 1}]")
+        e(f"s_add_u32 s{S_OUT}, s{S_OUT}, 256")
+        e(f"s_addc_u32 s{S_OUT + 1}, s{S_OUT + 1}, 0")
     assert g.complete == g.issued
-    g.emit("s_barrier")
+    # publish: tile buffer k read back; inputs up to tile k+NSLOT-3 have landed
+    e(f"s_add_u32 s{S_K}, s{S_K}, 1")
+    e(f"s_add_u32 s{S_F1}, s{S_K}, {NSLOT - 4}")
+    e(f"v_mov_b32_e32 v{V_TMP0}, s{S_K}")
+    e(f"v_mov_b32_e32 v{V_TMP1}, s{S_F1}")
+    e(f"ds_write2_b32 v{V_FLAG}, v{V_TMP0}, v{V_TMP1} offset0:1 offset1:2")
 
 
 def gen_post(g):
@@ -307,6 +370,8 @@ def gen_post(g):
     e(f"s_mov_b64 s[{S_ROWINC}:{S_ROWINC + 1}], %[rowinc]")
     e(f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], %[out]")
     e(f"s_mov_b32 s{S_CNT}, %[ntiles]")
+    e(f"s_mov_b32 s{S_K}, 0")
+    e(f"v_mov_b32_e32 v{V_FLAG}, {FLAGS}")
     e(f"v_lshlrev_b32_e32 v{V_LANE4}, 2, %[lane]")
     e(f"v_lshlrev_b32_e32 v{V_LANE16}, 4, %[lane]")
     e(f"v_add_u32_e32 v{V_VOFFA}, %[npad4], v{V_LANE4}")
@@ -320,29 +385,26 @@ def gen_post(g):
     e(f"v_mul_lo_u32 v{V_TRD}, v{V_TRD}, %[pitch8]")
     e(f"v_add_u32_e32 v{V_STOFF}, v{V_TRD}, v{V_STOFF}")
     e(f"v_add_u32_e32 v{V_TRD}, {TILE_BASE}, v{V_STOFF + 1}")
+    e(f"v_add_u32_e32 v{V_TRD2}, {2 * TILE_BUF}, v{V_TRD}")
     e(f"s_lshl_b32 s{S_TMP}, %[pitch8], 2")
     for q in range(1, 16):
         e(f"v_add_u32_e32 v{V_STOFF + q}, s{S_TMP}, v{V_STOFF + q - 1}")
-    # ring: tiles 0..4 -> slots 0..4, all landed before CHAIN starts
-    for slot in range(NSLOT - 1):
+    e("s_barrier")  # CHAIN has reset the counters
+    for slot in range(NSLOT):  # ring: tiles 0..NSLOT-1, all landed before CHAIN is told
         gen_prefetch(g, slot)
     e("s_waitcnt vmcnt(0)")
-    e("s_barrier")
-    # stage 0 (CHAIN runs tile 0): request tile 5 into slot 5 and let it land (the counted wait of
-    # the steady state only confirms a request once 60 younger operations exist); nothing to store
-    post_stage(g, NSLOT - 1, 0, store=False, drain=True)
+    e(f"v_mov_b32_e32 v{V_TMP0}, {NSLOT - 1}")
+    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP0} offset:8")
     e("POST_LOOP_%=:")
-    # stage s = 1..: CHAIN runs tile s; request tile s+5 into slot (s-1)%6, store tile s-1
     for idx in range(NSLOT):
-        post_stage(g, idx % NSLOT, idx % 2)
-        e(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
-        e(f"s_cmp_eq_u32 s{S_CNT}, 0")
+        post_tile(g, idx, idx)
+        e(f"s_cmp_eq_u32 s{S_K}, s{S_CNT}")
         if idx < NSLOT - 1:
             e("s_cbranch_scc1 POST_DONE_%=")
         else:
             e("s_cbranch_scc0 POST_LOOP_%=")
     e("POST_DONE_%=:")
-    e("s_waitcnt vmcnt(0)")  # run-ahead requests land before the ring is reused
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")  # run-ahead requests land before the ring is reused
     e("s_branch DONE_%=")
 
 
@@ -364,9 +426,10 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     path = os.path.join(here, "..", "garlic_amd", "csrc", "chain_loop_gfx950.inc")
     with open(path, "w") as f:
-        f.write("// GENERATED by tools/gen_chain_asm.py -- do not edit; see that file for the schedule.\n")
+        f.write("// GENERATED by tools/gen_chain_asm.py -- do not edit; see that file for roles and schedule.\n")
         f.write("// One inline-asm block: steady-state loop of lod_chain_kernel, 2 waves in 2 roles (gfx950).\n")
         f.write(f"#define GARLIC_CHAIN_LDS_TOTAL {LDS_TOTAL}\n")
+        f.write(f"#define GARLIC_CHAIN_LDS_TILE0 {TILE_BASE}\n")
         f.write("#define GARLIC_CHAIN_LOOP_ASM \\\n")
         for ln in lines:
             if ln.startswith(";"):
@@ -379,7 +442,7 @@ def main():
         chunks = [", ".join(regs[i:i + 12]) for i in range(0, len(regs), 12)]
         f.write(", \\\n    ".join(chunks) + "\n")
     n_instr = sum(1 for ln in lines if not ln.startswith(";") and not ln.endswith(":"))
-    print(f"wrote {path}: {n_instr} instructions")
+    print(f"wrote {os.path.normpath(path)}: {n_instr} instructions, LDS {LDS_TOTAL} B, tile0 at {TILE_BASE}")
 
 
 if __name__ == "__main__":
