@@ -239,7 +239,7 @@ struct ChainArgs {
     int32_t *next_item;       // device counter (zeroed per launch): the persistent waves' queue head
 };
 
-// LDS map (bytes).  One workgroup = 2 waves (CHAIN + POST roles) working on one item; the hand-scheduled loop
+// LDS map (bytes).  One workgroup = 3 waves (CHAIN, POST, PRE roles) working on one item; the hand-scheduled loop
 // (chain_loop_gfx950.inc, see tools/gen_chain_asm.py for the full map) owns everything from 4096
 // on; the compiler-generated "generic" tile path used for a run's first and last tiles keeps its
 // inputs in the slot at 0 and transposes through TILE buffer 0.
@@ -253,7 +253,7 @@ constexpr uint32_t SL_LTAB = 1024, SL_TTAB = 2048;
 constexpr uint32_t LDS_ITEM = 3072;                              // broadcast word for the item index
 constexpr uint32_t LDS_TILE = GARLIC_CHAIN_LDS_TILE0;                             // TILE buffer 0 of the asm loop
 constexpr uint32_t LDS_BYTES = GARLIC_CHAIN_LDS_TOTAL;
-constexpr int CHAIN_THREADS = 128;
+constexpr int CHAIN_THREADS = 192;
 
 // Wave-uniform stream state (lives in SGPRs).
 struct Streams {
@@ -384,7 +384,7 @@ lod_chain_kernel(ChainArgs p)
     // Persistent workgroup: pulls (run, 64-individual block) items, longest runs
     // first, from one device-wide counter.  Wave 2 owns the accumulator: it sums the run's first
     // window and runs the first / last (partial) tiles through the compiler-generated path; all
-    // full tiles go through the 2-role hand-scheduled loop.
+    // full tiles go through the 3-role hand-scheduled loop.
     for (;;) {
     if (threadIdx.x == 0)
         *reinterpret_cast<volatile int *>(smem + LDS_ITEM) = atomicAdd(p.next_item, 1);
@@ -471,12 +471,10 @@ lod_chain_kernel(ChainArgs p)
         int ntiles = (b + 1 - s0) / TILE;
         if (ntiles >= 2) {
             const uint64_t rowinc = (uint64_t)(2 * npad) * 4;
-            uint32_t lc = 0, tc = 0; // genotype word +0 of the first full tile (CHAIN role only)
-            if (wave == 0) {
-                lc = st.lead_row[lane];
-                tc = st.trail_row[lane];
-            }
-            // both waves enter together; the block starts by draining each wave's own memory
+            // genotype word +0 of the first full tile, both streams (POST funnel-shifts the words)
+            uint32_t lc = st.lead_row[lane];
+            uint32_t tc = st.trail_row[lane];
+            // all waves enter together; the block starts by draining each wave's own memory
             // operations, its stage barriers order the LDS hand-offs (TILE buffer 0 above
             // included: the loop first writes it two barriers in)
             asm volatile(GARLIC_CHAIN_LOOP_ASM

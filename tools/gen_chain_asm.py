@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates garlic_amd/csrc/chain_loop_gfx950.inc: the hand-scheduled steady-state loop of the LOD
-chain kernel -- ONE inline-asm block executed by the 2 wavefronts of a workgroup, each in its own
+chain kernel -- ONE inline-asm block executed by the 3 wavefronts of a workgroup, each in its own
 role (gfx950, wave64; one workgroup = one (SNP run, 64 individuals) item at a time).
 
 Why hand-scheduled, why two roles: a single wavefront issues about one instruction every 4 cycles,
@@ -11,14 +11,18 @@ v_add_f64 per step; here every LDS read is issued an 8-step batch ahead and all 
 Splitting further (separate look-up waves handing terms over through LDS) was measured SLOWER:
 the extra LDS traffic saturates the CU's LDS pipeline.
 
-  wave 0  CHAIN  2-bit extract (2 VALU per term), term look-up (ds_read_b64), the dependent FP64
+  wave 0  CHAIN  one VALU per term (byte extract of a pre-expanded LDS offset), term look-up
+                 (ds_read_b64), the dependent FP64
                  chain acc = (acc - t_out) + t_in (two roundings, reference
                  src/garlic-roh.cpp:98-100), acc -> transpose tile (ds_write_b128 per 2 steps)
                  -- no vector-memory instruction at all: a request of its own would queue behind
                  POST's stores in the CU's memory pipeline and stall the chain (measured: +30 %)
-  wave 1  POST   LDS-DMA prefetch of CHAIN's genotype words / term rows (8-slot ring) and the
+  wave 1  POST   LDS-DMA prefetch of genotype words / term rows (8-slot ring); funnel shift of the
+                 words and expansion of the 2-bit genotypes into one byte each (= genotype*8, the
+                 LDS offset inside a term row: 3 VALU per 4 genotypes via a 24-bit multiply);
                  transposed write-out of finished tiles: 16 x (ds_read_b128 ->
-                 global_store_dwordx4), 4 rows x 256 B per store
+                 global_store_dwordx4), 4 rows x 256 B per store.  POST is HBM-bound and has issue
+                 slots to spare; CHAIN is the long pole, so work moves this way.
 
 The two waves are decoupled: 4 transpose-tile buffers and three LDS counters instead of a barrier
 per tile (a barrier makes every POST stall -- HBM back-pressure comes in bursts -- a CHAIN stall):
@@ -30,27 +34,31 @@ everything older than the last 3 tiles' 48 stores + 12 requests has completed, i
 tile k+5.
 
 CHAIN per tile (32 window starts x 64 individuals), software pipeline over 8-step batches g:
-    A(g)  byte offsets (genotype*8) of the batch's entering / leaving terms in their table rows
+    A(g)  byte offsets of the batch's entering / leaving terms: 1 VALU each (v_and / v_bfe / v_lshr)
     R(g)  16 ds_read_b64 into one of two 32-VGPR buffers
     C(g)  the chain + tile writes, with A(g+2) woven in
   iteration g:  wait R(g) | issue R(g+1) | C(g) (+) A(g+2)
 
 LDS map (bytes; must match lod_kernels.hpp):
       0  generic-path slot (3072), item word (3072), flags (3584)   (flags used here)
-   4096  ring: 8 slots x 3072 {lead w+1, lead w+2, trail w+1, trail w+2 (256 each),
-                               lead term rows 1024, trail term rows 1024}
-  28672  TILE[4][64 rows x 272 B]
+   4096  ring: 8 slots x 7168 {lead term rows 1024, trail term rows 1024, genotype words
+                               lead w+1, lead w+2, trail w+1, trail w+2 (256 each),
+                               expanded lead offsets 2048 (32 B per lane), expanded trail 2048}
+  61440  TILE[4][64 rows x 272 B]
 """
 import os
 
 
 ABL = os.environ.get("GARLIC_ABLATE", "")
+STORE_FLAGS = os.environ.get("GARLIC_STORE_FLAGS", "nt")  # non-temporal: the scores are written once and never re-read here (measured -2.7 %)
 
 NSLOT = int(os.environ.get("GARLIC_NSLOT", "8"))
 NTILE = int(os.environ.get("GARLIC_NTILE", "4"))
 RING = 4096
-SLOT = 3072
-SL_LW1, SL_LW2, SL_TW1, SL_TW2, SL_LTAB, SL_TTAB = 0, 256, 512, 768, 1024, 2048
+SLOT = 7168
+SL_LTAB, SL_TTAB = 0, 1024
+SL_LW1, SL_LW2, SL_TW1, SL_TW2 = 2048, 2304, 2560, 2816
+SL_EXPL, SL_EXPT = 3072, 5120
 FLAGS = 3584          # +0 tiles_done, +4 tiles_stored, +8 inputs_landed
 TILE_BASE = RING + NSLOT * SLOT
 TILE_BUF = 64 * 34 * 8
@@ -61,13 +69,18 @@ LDS_TOTAL = TILE_BASE + NTILE * TILE_BUF
 V_BUF = [100, 132]          # CHAIN: two term buffers, 16 x 64-bit each
 V_ADDR = 164                # CHAIN: 16 LDS byte offsets
 V_ACC = 180                 # CHAIN: P0 = [180:181], P1 = [182:183]
-V_LL, V_LH, V_TL, V_TH = 184, 185, 186, 187
+V_LL, V_LH, V_TL, V_TH = 184, 185, 186, 187   # POST: funnel-shifted genotype bits
 V_WL1, V_WL2, V_WT1, V_WT2 = 188, 189, 190, 191
 V_LANE4, V_LANE16, V_VOFFA, V_VOFFB, V_TWR, V_TRD = 192, 193, 194, 195, 196, 197
+V_LANE32 = 192              # CHAIN only (CHAIN has no V_LANE4): lane * 32
+V_LANE32P = 217             # POST: lane * 32
 V_STOFF = 198               # POST: 16 store offsets
 V_ST = 24                   # POST: 64 VGPRs of store data
+V_E = [220, 236]            # CHAIN: two sets of 16 expanded-offset dwords (lead 8, trail 8)
+V_X = 100                   # POST: 16 expanded dwords being built + 4 scratch (POST has no V_BUF)
 V_LC, V_TC = 214, 215
-V_FLAG, V_TRD2, V_TMP0, V_TMP1 = 216, 217, 218, 219   # TMP pair 64-bit aligned (ds_read2 dst)
+V_FLAG, V_TMP0, V_TMP1 = 216, 218, 219   # TMP pair 64-bit aligned (ds_read2 dst)
+V_TRD2 = 122                # POST: second tile-read base
 # ---- fixed SGPRs
 S_PLEAD, S_PTRAIL, S_PLTAB, S_PTTAB = 40, 42, 44, 46
 S_ROWINC = 48
@@ -78,7 +91,7 @@ S_TMP = 55
 S_K = 56
 S_F0, S_F1 = 57, 58
 
-CLOBBER_V = sorted(set(list(range(V_ST, V_ST + 64)) + list(range(100, 220))))
+CLOBBER_V = sorted(set(list(range(V_ST, V_ST + 64)) + list(range(100, 252))))
 CLOBBER_S = list(range(40, 59))
 
 
@@ -117,28 +130,27 @@ def quad(r):
 
 
 # ------------------------------------------------------------------ CHAIN
-def addr_ops(j):
-    """the 4 VALU ops producing the LDS byte offsets of step j's leaving/entering terms"""
-    k = j % 16
-    lw, tw = (V_LL, V_TL) if j < 16 else (V_LH, V_TH)
+def addr_ops(j, eset):
+    """the 2 VALU ops producing the LDS byte offsets of step j's leaving/entering terms: byte j%4 of
+    dword j//4 of the tile's expanded offsets (set `eset`: lead dwords 0-7, trail dwords 8-15)"""
     i = j % 8
     at, al = V_ADDR + 2 * i, V_ADDR + 2 * i + 1
     ops = []
-    for dst, src in ((at, tw), (al, lw)):
-        if k == 0:
-            ops.append(f"v_lshlrev_b32_e32 v{dst}, 3, v{src}")
-        elif k == 1:
-            ops.append(f"v_lshlrev_b32_e32 v{dst}, 1, v{src}")
+    for dst, src in ((at, V_E[eset] + 8 + j // 4), (al, V_E[eset] + j // 4)):
+        b = j % 4
+        if b == 0:
+            ops.append(f"v_and_b32_e32 v{dst}, 0xff, v{src}")
+        elif b == 3:
+            ops.append(f"v_lshrrev_b32_e32 v{dst}, 24, v{src}")
         else:
-            ops.append(f"v_lshrrev_b32_e32 v{dst}, {2 * k - 3}, v{src}")
-        ops.append(f"v_and_b32_e32 v{dst}, 24, v{dst}")
+            ops.append(f"v_bfe_u32 v{dst}, v{src}, {8 * b}, 8")
     return ops
 
 
-def all_addr_ops(n):
+def all_addr_ops(n, eset):
     ops = []
     for i in range(8):
-        ops += addr_ops(8 * n + i)
+        ops += addr_ops(8 * n + i, eset)
     return ops
 
 
@@ -163,32 +175,25 @@ def gen_C(g, n, a_ops, tbuf):
         dst, prev = (P0, P1) if j % 2 == 0 else (P1, P0)
         if "nodp" not in ABL:
             g.emit(f"v_add_f64 {pair(dst)}, {pair(prev)}, -{pair(buf + 4 * i)}")
-        for _ in range(2):
-            if a_ops:
-                g.emit(a_ops.pop(0))
+        if a_ops:
+            g.emit(a_ops.pop(0))
         if "nodp" not in ABL:
             g.emit(f"v_add_f64 {pair(dst)}, {pair(dst)}, {pair(buf + 4 * i + 2)}")
-        for _ in range(2):
-            if a_ops:
-                g.emit(a_ops.pop(0))
+        if a_ops:
+            g.emit(a_ops.pop(0))
         if j % 2 == 1 and "chainwrite" not in ABL:
             g.lds(f"ds_write_b128 v{V_TWR}, {quad(V_ACC)} offset:{tbuf * TILE_BUF + 8 * (j - 1)}")
     assert not a_ops
 
 
-def gen_words(g, slot):
-    b = (RING + slot * SLOT) // 256
-    g.lds(f"ds_read2st64_b32 v[{V_WL1}:{V_WL2}], v{V_LANE4} offset0:{b + SL_LW1 // 256} offset1:{b + SL_LW2 // 256}")
-    return g.lds(f"ds_read2st64_b32 v[{V_WT1}:{V_WT2}], v{V_LANE4} offset0:{b + SL_TW1 // 256} offset1:{b + SL_TW2 // 256}")
-
-
-def gen_funnel(g):
-    g.emit(f"v_alignbit_b32 v{V_LL}, v{V_WL1}, v{V_LC}, s{S_SHL}")
-    g.emit(f"v_alignbit_b32 v{V_LH}, v{V_WL2}, v{V_WL1}, s{S_SHL}")
-    g.emit(f"v_alignbit_b32 v{V_TL}, v{V_WT1}, v{V_TC}, s{S_SHT}")
-    g.emit(f"v_alignbit_b32 v{V_TH}, v{V_WT2}, v{V_WT1}, s{S_SHT}")
-    g.emit(f"v_mov_b32_e32 v{V_LC}, v{V_WL2}")
-    g.emit(f"v_mov_b32_e32 v{V_TC}, v{V_WT2}")
+def gen_exp_reads(g, slot, eset):
+    """CHAIN: the tile's 16 expanded-offset dwords (this lane's 32 B per stream)"""
+    base = RING + slot * SLOT
+    last = 0
+    for h in range(2):
+        g.lds(f"ds_read_b128 {quad(V_E[eset] + 4 * h)}, v{V_LANE32} offset:{base + SL_EXPL + 16 * h}")
+        last = g.lds(f"ds_read_b128 {quad(V_E[eset] + 8 + 4 * h)}, v{V_LANE32} offset:{base + SL_EXPT + 16 * h}")
+    return last
 
 
 def chain_tile(g, slot, uid):
@@ -216,24 +221,24 @@ def chain_tile(g, slot, uid):
     else:
         e("s_waitcnt lgkmcnt(0)")
     g.drained()
+    es, en = slot % 2, (slot + 1) % 2   # expanded-offset register set of this / the next tile
     # batch 0: R(k,0) is complete (the poll drained the LDS queue)
     r1 = gen_R(g, slot, 1)
-    gen_C(g, 0, all_addr_ops(2), tbuf)
-    # batch 1
-    words = gen_words(g, nxt)
+    gen_C(g, 0, all_addr_ops(2, es), tbuf)
+    # batch 1: fetch the next tile's expanded offsets into the other register set
+    exp = gen_exp_reads(g, nxt, en)
     g.wait_lds(r1)
     r2 = gen_R(g, slot, 2)
-    gen_C(g, 1, all_addr_ops(3), tbuf)
-    # batch 2: bits of tile k+1 replace those of tile k (A(k,3) is done)
+    gen_C(g, 1, all_addr_ops(3, es), tbuf)
+    # batch 2
     g.wait_lds(r2)
-    assert words <= g.complete
-    gen_funnel(g)
+    assert exp <= g.complete
     r3 = gen_R(g, slot, 3)
-    gen_C(g, 2, all_addr_ops(0), tbuf)
+    gen_C(g, 2, all_addr_ops(0, en), tbuf)
     # batch 3
     g.wait_lds(r3)
     gen_R(g, nxt, 0)
-    gen_C(g, 3, all_addr_ops(1), tbuf)
+    gen_C(g, 3, all_addr_ops(1, en), tbuf)
     # publish: tile k complete in LDS (its writes are waited for), input slot k released
     e(f"s_add_u32 s{S_K}, s{S_K}, 1")
     e(f"v_mov_b32_e32 v{V_TMP0}, s{S_K}")
@@ -246,13 +251,9 @@ def gen_chain(g):
     e = g.emit
     e("ROLE_CHAIN_%=:")
     e(f"s_mov_b32 s{S_CNT}, %[ntiles]")
-    e(f"s_mov_b32 s{S_SHL}, %[shl]")
-    e(f"s_mov_b32 s{S_SHT}, %[sht]")
     e(f"s_mov_b32 s{S_K}, 0")
     e(f"v_mov_b64 {pair(V_ACC + 2)}, %[acc]")
-    e(f"v_mov_b32_e32 v{V_LC}, %[lc]")
-    e(f"v_mov_b32_e32 v{V_TC}, %[tc]")
-    e(f"v_lshlrev_b32_e32 v{V_LANE4}, 2, %[lane]")
+    e(f"v_lshlrev_b32_e32 v{V_LANE32}, 5, %[lane]")
     e(f"v_mul_u32_u24_e32 v{V_TWR}, {TPITCH_B}, %[lane]")
     e(f"v_add_u32_e32 v{V_TWR}, {TILE_BASE}, v{V_TWR}")
     e(f"v_mov_b32_e32 v{V_FLAG}, {FLAGS}")
@@ -272,14 +273,13 @@ def gen_chain(g):
     e("s_branch CHAIN_FIRST_%=")
     e("CHAIN_START_%=:")
     g.drained()
-    # pipeline prologue for the first tile (slot 0)
-    w = gen_words(g, 0)
-    g.wait_lds(w)
-    gen_funnel(g)
-    for op in all_addr_ops(0):
+    # pipeline prologue for the first tile (slot 0, register set 0)
+    x = gen_exp_reads(g, 0, 0)
+    g.wait_lds(x)
+    for op in all_addr_ops(0, 0):
         e(op)
     gen_R(g, 0, 0)
-    for op in all_addr_ops(1):
+    for op in all_addr_ops(1, 0):
         e(op)
     e("CHAIN_LOOP_%=:")
     for slot in range(NSLOT):
@@ -323,8 +323,45 @@ def gen_prefetch(g, slot):
             g.emit(f"s_addc_u32 s{p + 1}, s{p + 1}, 0")
 
 
+def post_expand(g, slot):
+    """POST: funnel-shift the tile's genotype words (both streams) and expand each 2-bit genotype
+    into one byte = genotype*8; this lane's 32 bytes per stream go to the slot's EXP areas
+    (8 VALU per 4 genotypes; POST is HBM-bound and has the issue slots)."""
+    if "noexpand" in ABL:
+        return
+    e = g.emit
+    b = (RING + slot * SLOT) // 256
+    g.lds(f"ds_read2st64_b32 v[{V_WL1}:{V_WL2}], v{V_LANE4} offset0:{b + SL_LW1 // 256} offset1:{b + SL_LW2 // 256}")
+    w = g.lds(f"ds_read2st64_b32 v[{V_WT1}:{V_WT2}], v{V_LANE4} offset0:{b + SL_TW1 // 256} offset1:{b + SL_TW2 // 256}")
+    g.wait_lds(w)
+    e(f"v_alignbit_b32 v{V_LL}, v{V_WL1}, v{V_LC}, s{S_SHL}")
+    e(f"v_alignbit_b32 v{V_LH}, v{V_WL2}, v{V_WL1}, s{S_SHL}")
+    e(f"v_alignbit_b32 v{V_TL}, v{V_WT1}, v{V_TC}, s{S_SHT}")
+    e(f"v_alignbit_b32 v{V_TH}, v{V_WT2}, v{V_WT1}, s{S_SHT}")
+    e(f"v_mov_b32_e32 v{V_LC}, v{V_WL2}")
+    e(f"v_mov_b32_e32 v{V_TC}, v{V_WT2}")
+    t = [V_X + 16, V_X + 17, V_X + 18, V_X + 19]
+    for stream, (lo, hi) in enumerate(((V_LL, V_LH), (V_TL, V_TH))):
+        for d in range(8):            # dword d holds steps 4d..4d+3, one byte (= genotype*8) each
+            src = lo if d < 4 else hi
+            o = 8 * (d % 4)
+            dst = V_X + 8 * stream + d
+            for i in range(4):
+                e(f"v_bfe_u32 v{t[i]}, v{src}, {o + 2 * i}, 2")
+            e(f"v_lshl_or_b32 v{t[0]}, v{t[1]}, 8, v{t[0]}")
+            e(f"v_lshl_or_b32 v{t[2]}, v{t[3]}, 8, v{t[2]}")
+            e(f"v_lshl_or_b32 v{dst}, v{t[2]}, 16, v{t[0]}")
+            e(f"v_lshlrev_b32_e32 v{dst}, 3, v{dst}")
+    base = RING + slot * SLOT
+    for stream, area in enumerate((SL_EXPL, SL_EXPT)):
+        for h in range(2):
+            g.lds(f"ds_write_b128 v{V_LANE32P}, {quad(V_X + 8 * stream + 4 * h)} offset:{base + area + 16 * h}")
+
+
 def post_tile(g, slot, uid):
-    """POST, one tile k: ring slot = k % NSLOT, tile buffer = k % NTILE"""
+    """POST, one tile k (tile buffer = k % NTILE): transposed write-out.  Its stores are never waited
+    for; when HBM pushes back the wave simply blocks at the store issue (which is why nothing else
+    lives in this wave)."""
     tbuf = slot % NTILE
     e = g.emit
     e(f"POST_POLL_{uid}_%=:")  # wait for CHAIN to finish tile k
@@ -337,8 +374,6 @@ def post_tile(g, slot, uid):
     e(f"s_branch POST_POLL_{uid}_%=")
     e(f"POST_GO_{uid}_%=:")
     g.drained()
-    e("s_waitcnt vmcnt(60)")   # confirms the inputs requested 3 iterations ago (tile k+NSLOT-3)
-    gen_prefetch(g, slot)      # slot k is free: request tile k+NSLOT into it
     if "nopost" not in ABL:
         ids = []
         for q in range(16):
@@ -348,34 +383,23 @@ def post_tile(g, slot, uid):
         for q in range(16):
             g.wait_lds(ids[q])
             if "poststore" not in ABL:
-                e(f"global_store_dwordx4 v{V_STOFF + q}, {quad(V_ST + 4 * q)}, s[{S_OUT}:{S_OUT + 1}]")
+                e(f"global_store_dwordx4 v{V_STOFF + q}, {quad(V_ST + 4 * q)}, s[{S_OUT}:{S_OUT + 1}] {STORE_FLAGS}".rstrip())
         e(f"s_add_u32 s{S_OUT}, s{S_OUT}, 256")
         e(f"s_addc_u32 s{S_OUT + 1}, s{S_OUT + 1}, 0")
     assert g.complete == g.issued
-    # publish: tile buffer k read back; inputs up to tile k+NSLOT-3 have landed
+    # publish: tile buffer k has been read back
     e(f"s_add_u32 s{S_K}, s{S_K}, 1")
-    e(f"s_add_u32 s{S_F1}, s{S_K}, {NSLOT - 4}")
     e(f"v_mov_b32_e32 v{V_TMP0}, s{S_K}")
-    e(f"v_mov_b32_e32 v{V_TMP1}, s{S_F1}")
-    e(f"ds_write2_b32 v{V_FLAG}, v{V_TMP0}, v{V_TMP1} offset0:1 offset1:2")
+    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP0} offset:4")
 
 
 def gen_post(g):
     e = g.emit
     e("ROLE_POST_%=:")
-    e(f"s_mov_b64 s[{S_PLEAD}:{S_PLEAD + 1}], %[plead]")
-    e(f"s_mov_b64 s[{S_PTRAIL}:{S_PTRAIL + 1}], %[ptrail]")
-    e(f"s_mov_b64 s[{S_PLTAB}:{S_PLTAB + 1}], %[pltab]")
-    e(f"s_mov_b64 s[{S_PTTAB}:{S_PTTAB + 1}], %[pttab]")
-    e(f"s_mov_b64 s[{S_ROWINC}:{S_ROWINC + 1}], %[rowinc]")
     e(f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], %[out]")
     e(f"s_mov_b32 s{S_CNT}, %[ntiles]")
     e(f"s_mov_b32 s{S_K}, 0")
     e(f"v_mov_b32_e32 v{V_FLAG}, {FLAGS}")
-    e(f"v_lshlrev_b32_e32 v{V_LANE4}, 2, %[lane]")
-    e(f"v_lshlrev_b32_e32 v{V_LANE16}, 4, %[lane]")
-    e(f"v_add_u32_e32 v{V_VOFFA}, %[npad4], v{V_LANE4}")
-    e(f"v_add_u32_e32 v{V_VOFFB}, %[npad4], v{V_VOFFA}")
     # tile read address (lane>>4)*272 + (lane&15)*16 ; store offset (lane>>4)*pitch8 + (lane&15)*16
     e(f"v_lshrrev_b32_e32 v{V_TRD}, 4, %[lane]")
     e(f"v_and_b32_e32 v{V_STOFF}, 15, %[lane]")
@@ -390,11 +414,6 @@ def gen_post(g):
     for q in range(1, 16):
         e(f"v_add_u32_e32 v{V_STOFF + q}, s{S_TMP}, v{V_STOFF + q - 1}")
     e("s_barrier")  # CHAIN has reset the counters
-    for slot in range(NSLOT):  # ring: tiles 0..NSLOT-1, all landed before CHAIN is told
-        gen_prefetch(g, slot)
-    e("s_waitcnt vmcnt(0)")
-    e(f"v_mov_b32_e32 v{V_TMP0}, {NSLOT - 1}")
-    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP0} offset:8")
     e("POST_LOOP_%=:")
     for idx in range(NSLOT):
         post_tile(g, idx, idx)
@@ -404,6 +423,78 @@ def gen_post(g):
         else:
             e("s_cbranch_scc0 POST_LOOP_%=")
     e("POST_DONE_%=:")
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_branch DONE_%=")
+
+
+# ------------------------------------------------------------------ PRE
+def pre_tile(g, slot, uid):
+    """PRE, iteration k: once CHAIN has finished tile k its ring slot is free -> request tile
+    k+NSLOT into it; the inputs requested 3 iterations ago (tile k+NSLOT-3) have landed -> expand."""
+    e = g.emit
+    e(f"PRE_POLL_{uid}_%=:")
+    e(f"ds_read_b32 v{V_TMP0}, v{V_FLAG}")
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"v_readfirstlane_b32 s{S_F0}, v{V_TMP0}")
+    e(f"s_cmp_gt_u32 s{S_F0}, s{S_K}")               # tiles_done >= k + 1
+    e(f"s_cbranch_scc1 PRE_GO_{uid}_%=")
+    e("s_sleep 1")
+    e(f"s_branch PRE_POLL_{uid}_%=")
+    e(f"PRE_GO_{uid}_%=:")
+    g.drained()
+    gen_prefetch(g, slot)
+    # this wave's only vector-memory operations are its LDS-DMA requests (6 per tile), retired in
+    # order: 3 younger tiles may stay in flight
+    e("s_waitcnt vmcnt(18)")
+    post_expand(g, (slot + NSLOT - 3) % NSLOT)
+    e(f"s_add_u32 s{S_K}, s{S_K}, 1")
+    e(f"s_add_u32 s{S_F1}, s{S_K}, {NSLOT - 4}")
+    e(f"v_mov_b32_e32 v{V_TMP1}, s{S_F1}")
+    e("s_waitcnt lgkmcnt(0)")
+    g.drained()
+    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP1} offset:8")   # inputs_ready = k + NSLOT - 3
+
+
+def gen_pre(g):
+    e = g.emit
+    e("ROLE_PRE_%=:")
+    e(f"s_mov_b64 s[{S_PLEAD}:{S_PLEAD + 1}], %[plead]")
+    e(f"s_mov_b64 s[{S_PTRAIL}:{S_PTRAIL + 1}], %[ptrail]")
+    e(f"s_mov_b64 s[{S_PLTAB}:{S_PLTAB + 1}], %[pltab]")
+    e(f"s_mov_b64 s[{S_PTTAB}:{S_PTTAB + 1}], %[pttab]")
+    e(f"s_mov_b64 s[{S_ROWINC}:{S_ROWINC + 1}], %[rowinc]")
+    e(f"s_mov_b32 s{S_CNT}, %[ntiles]")
+    e(f"s_mov_b32 s{S_K}, 0")
+    e(f"s_mov_b32 s{S_SHL}, %[shl]")
+    e(f"s_mov_b32 s{S_SHT}, %[sht]")
+    e(f"v_mov_b32_e32 v{V_LC}, %[lc]")
+    e(f"v_mov_b32_e32 v{V_TC}, %[tc]")
+    e(f"v_mov_b32_e32 v{V_FLAG}, {FLAGS}")
+    e(f"v_lshlrev_b32_e32 v{V_LANE4}, 2, %[lane]")
+    e(f"v_lshlrev_b32_e32 v{V_LANE16}, 4, %[lane]")
+    e(f"v_lshlrev_b32_e32 v{V_LANE32P}, 5, %[lane]")
+    e(f"v_add_u32_e32 v{V_VOFFA}, %[npad4], v{V_LANE4}")
+    e(f"v_add_u32_e32 v{V_VOFFB}, %[npad4], v{V_VOFFA}")
+    e("s_barrier")  # CHAIN has reset the counters
+    for slot in range(NSLOT):  # ring: tiles 0..NSLOT-1
+        gen_prefetch(g, slot)
+    e("s_waitcnt vmcnt(0)")
+    g.drained()
+    for slot in range(NSLOT - 3):  # tiles 0..NSLOT-4 expanded up front; the loop stays ahead
+        post_expand(g, slot)
+    e("s_waitcnt lgkmcnt(0)")
+    g.drained()
+    e(f"v_mov_b32_e32 v{V_TMP0}, {NSLOT - 4}")
+    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP0} offset:8")
+    e("PRE_LOOP_%=:")
+    for idx in range(NSLOT):
+        pre_tile(g, idx, idx)
+        e(f"s_cmp_eq_u32 s{S_K}, s{S_CNT}")
+        if idx < NSLOT - 1:
+            e("s_cbranch_scc1 PRE_DONE_%=")
+        else:
+            e("s_cbranch_scc0 PRE_LOOP_%=")
+    e("PRE_DONE_%=:")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")  # run-ahead requests land before the ring is reused
     e("s_branch DONE_%=")
 
@@ -412,10 +503,13 @@ def gen_all():
     g = Gen()
     e = g.emit
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    e("s_cmp_eq_u32 %[wave], 0")
-    e("s_cbranch_scc0 ROLE_POST_%=")
+    e("s_cmp_eq_u32 %[wave], 1")
+    e("s_cbranch_scc1 ROLE_POST_%=")
+    e("s_cmp_eq_u32 %[wave], 2")
+    e("s_cbranch_scc1 ROLE_PRE_%=")
     gen_chain(g)
     gen_post(g)
+    gen_pre(g)
     e("DONE_%=:")
     e("s_waitcnt lgkmcnt(0)")
     return g.out
@@ -427,7 +521,7 @@ def main():
     path = os.path.join(here, "..", "garlic_amd", "csrc", "chain_loop_gfx950.inc")
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_chain_asm.py -- do not edit; see that file for roles and schedule.\n")
-        f.write("// One inline-asm block: steady-state loop of lod_chain_kernel, 2 waves in 2 roles (gfx950).\n")
+        f.write("// One inline-asm block: steady-state loop of lod_chain_kernel, 3 waves in 3 roles (gfx950).\n")
         f.write(f"#define GARLIC_CHAIN_LDS_TOTAL {LDS_TOTAL}\n")
         f.write(f"#define GARLIC_CHAIN_LDS_TILE0 {TILE_BASE}\n")
         f.write("#define GARLIC_CHAIN_LOOP_ASM \\\n")
