@@ -15,6 +15,11 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def gpu_ctx():
+    # torch ships its own HIP runtime: let it find the device first, then libgarlic_hip joins
+    # (the other order leaves torch without a device in this image)
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    torch.zeros(1, device="cuda")
     from garlic_amd import abi
     ctx = abi.Context(0)
     yield ctx
