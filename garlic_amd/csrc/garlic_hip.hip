@@ -154,6 +154,15 @@ struct garlic_panel {
     double decay_mu = 0;
     DevBuf<double> d_out;
     garlic_call_stats stats{};
+    // work list of the last call, still on the device: repeated calls with the same arguments
+    // (bench steps, window-size sweeps coming back to a size) skip planning and uploads
+    struct {
+        bool valid = false;
+        int mode = -1;
+        int32_t W = 0, max_gap = 0, ind_begin = 0, ind_count = 0, pitch_align = 0;
+        size_t n_items = 0, n_fill = 0;
+        int64_t n_runs = 0, n_valid = 0;
+    } plan;
 };
 
 namespace {
@@ -376,41 +385,50 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         if (3 * L.pitch[c] * 8 + 512 >= (int64_t)1 << 32)
             return fail(GARLIC_ERR_INVALID, "chromosome %d too long for 32-bit row offsets", c);
 
+    const bool reuse = p->plan.valid && p->plan.mode == (int)mode && p->plan.W == W &&
+                       p->plan.max_gap == max_gap && p->plan.ind_begin == ind_begin &&
+                       p->plan.ind_count == ind_count && p->plan.pitch_align == pitch_align;
+    const int nblk = (ind_count + WAVE - 1) / WAVE;
     std::vector<Run> runs;
     std::vector<FillItem> fill;
-    int64_t n_valid = 0;
-    plan_runs(p, W, runs, fill, n_valid);
-
-    // Work list: (run, 64-individual block) items, longest runs first (LPT); the persistent
-    // workgroups of lod_chain_kernel pull them from a device counter.
-    std::vector<int> order(runs.size());
-    for (size_t i = 0; i < runs.size(); i++) order[i] = (int)i;
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-        return (runs[x].b - runs[x].a) > (runs[y].b - runs[y].a);
-    });
-    const int nblk = (ind_count + WAVE - 1) / WAVE;
     std::vector<ChainItem> items;
-    items.reserve(runs.size() * nblk);
-    for (size_t i = 0; i < order.size(); i++) {
-        const Run &r = runs[order[i]];
-        for (int k = 0; k < nblk; k++) items.push_back(ChainItem{r.chr, r.a, r.b, k * WAVE});
+    std::vector<ChrDev> chrs;
+    int64_t n_valid = p->plan.n_valid;
+    size_t n_items = p->plan.n_items, n_fill = p->plan.n_fill;
+    int64_t n_runs = p->plan.n_runs;
+    if (!reuse) {
+        plan_runs(p, W, runs, fill, n_valid);
+        // Work list: (run, 64-individual block) items, longest runs first (LPT); the persistent
+        // workgroups of lod_chain_kernel pull them from a device counter.
+        std::vector<int> order(runs.size());
+        for (size_t i = 0; i < runs.size(); i++) order[i] = (int)i;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+            return (runs[x].b - runs[x].a) > (runs[y].b - runs[y].a);
+        });
+        items.reserve(runs.size() * nblk);
+        for (size_t i = 0; i < order.size(); i++) {
+            const Run &r = runs[order[i]];
+            for (int k = 0; k < nblk; k++) items.push_back(ChainItem{r.chr, r.a, r.b, k * WAVE});
+        }
+        chrs.resize(p->nchr);
+        for (int c = 0; c < p->nchr; c++)
+            chrs[c] = ChrDev{p->chr_off[c], L.base[c], L.pitch[c], p->chr_nloci[c],
+                             (pitch_align >= 2 && 64 * L.pitch[c] * 8 + 512 < ((int64_t)1 << 32)) ? 1 : 0};
+        n_items = items.size();
+        n_fill = fill.size();
+        n_runs = (int64_t)runs.size();
+        if ((rc = p->d_chrs.reserve(chrs.size()))) return rc;
+        if ((rc = p->d_items.reserve(std::max<size_t>(n_items, 1)))) return rc;
+        if ((rc = p->d_fill.reserve(std::max<size_t>(n_fill, 1)))) return rc;
+        if ((rc = p->d_counter.reserve(1))) return rc;
+        p->plan.valid = false;
     }
-    // Persistent workgroups (2 waves each: CHAIN + POST), one per CU by default; items are pulled
-    // longest first, so the short runs pack behind the long ones instead of competing with them
-    // for HBM bandwidth.  (LDS would allow 2 workgroups per CU.)
+    // Persistent workgroups (3 waves each: CHAIN, POST, PRE), one per CU; items are pulled longest
+    // first, so the short runs pack behind the long ones instead of competing with them for HBM
+    // bandwidth.
     int workers = 256;
     if (const char *e = getenv("GARLIC_WORKERS")) workers = std::max(1, atoi(e));
-    workers = std::min<int>(workers, (int)items.size());
-
-    std::vector<ChrDev> chrs(p->nchr);
-    for (int c = 0; c < p->nchr; c++)
-        chrs[c] = ChrDev{p->chr_off[c], L.base[c], L.pitch[c], p->chr_nloci[c],
-                         (pitch_align >= 2 && 64 * L.pitch[c] * 8 + 512 < ((int64_t)1 << 32)) ? 1 : 0};
-
-    if ((rc = p->d_chrs.reserve(chrs.size()))) return rc;
-    if ((rc = p->d_items.reserve(std::max<size_t>(items.size(), 1)))) return rc;
-    if ((rc = p->d_fill.reserve(std::max<size_t>(fill.size(), 1)))) return rc;
-    if ((rc = p->d_counter.reserve(1))) return rc;
+    workers = std::min<int>(workers, (int)n_items);
 
     double *d_out = out;
     if (where == GARLIC_HOST) {
@@ -420,36 +438,38 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     const bool aligned16 = (pitch_align % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
 
     HIP_TRY(hipEventRecord(ctx->ev_begin, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(p->d_chrs.p, chrs.data(), sizeof(ChrDev) * chrs.size(),
-                           hipMemcpyHostToDevice, ctx->stream));
-    if (!items.empty())
-        HIP_TRY(hipMemcpyAsync(p->d_items.p, items.data(), sizeof(ChainItem) * items.size(),
+    if (!reuse) {
+        HIP_TRY(hipMemcpyAsync(p->d_chrs.p, chrs.data(), sizeof(ChrDev) * chrs.size(),
                                hipMemcpyHostToDevice, ctx->stream));
-    if (!fill.empty())
-        HIP_TRY(hipMemcpyAsync(p->d_fill.p, fill.data(), sizeof(FillItem) * fill.size(),
-                               hipMemcpyHostToDevice, ctx->stream));
-    if (!fill.empty()) {
-        dim3 grid((unsigned)fill.size(), (unsigned)((ind_count + FILL_ROWS - 1) / FILL_ROWS));
+        if (n_items)
+            HIP_TRY(hipMemcpyAsync(p->d_items.p, items.data(), sizeof(ChainItem) * n_items,
+                                   hipMemcpyHostToDevice, ctx->stream));
+        if (n_fill)
+            HIP_TRY(hipMemcpyAsync(p->d_fill.p, fill.data(), sizeof(FillItem) * n_fill,
+                                   hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (n_fill) {
+        dim3 grid((unsigned)n_fill, (unsigned)((ind_count + FILL_ROWS - 1) / FILL_ROWS));
         hipLaunchKernelGGL(fill_missing_kernel, grid, dim3(256), 0, ctx->stream, p->d_fill.p,
                            p->d_chrs.p, ind_count, d_out);
     }
-    if (!items.empty()) HIP_TRY(hipMemsetAsync(p->d_counter.p, 0, sizeof(int32_t), ctx->stream));
+    if (n_items) HIP_TRY(hipMemsetAsync(p->d_counter.p, 0, sizeof(int32_t), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev_k0, ctx->stream));
-    if (!items.empty() && mode == MODE_LOD) {
+    if (n_items && mode == MODE_LOD) {
         ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p,     p->d_chrs.p,     d_out, p->nind_pad,
-                    ind_begin,     ind_count,  W,               (int32_t)items.size(), p->d_counter.p};
+                    ind_begin,     ind_count,  W,               (int32_t)n_items, p->d_counter.p};
         if (aligned16)
             hipLaunchKernelGGL(lod_chain_kernel<true>, dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
                                ctx->stream, a);
         else
             hipLaunchKernelGGL(lod_chain_kernel<false>, dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
                                ctx->stream, a);
-    } else if (!items.empty()) {
+    } else if (n_items) {
         VariantArgs a{p->d_packed.p, p->d_tab.p,  p->d_tabgl.p, p->d_codes.p, p->d_decay.p, p->d_rld.p,
                       p->d_items.p,  p->d_chrs.p, d_out,        p->nind_pad,  ind_begin,    ind_count,
                       W,             (int32_t)p->gl_values.size(), use_gl ? 1 : 0};
         if (mode == MODE_LOD_GL) {
-            hipLaunchKernelGGL(lod_chain_gl_kernel, dim3((unsigned)items.size()), dim3(WAVE), 0,
+            hipLaunchKernelGGL(lod_chain_gl_kernel, dim3((unsigned)n_items), dim3(WAVE), 0,
                                ctx->stream, a);
         } else {
             const int ring = W + TILE;
@@ -458,7 +478,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                 return fail(GARLIC_ERR_INVALID, "wLOD kernel of this build supports winsize <= %d", 240);
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wlod_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(wlod_kernel, dim3((unsigned)items.size()), dim3(WAVE), lds, ctx->stream, a,
+            hipLaunchKernelGGL(wlod_kernel, dim3((unsigned)n_items), dim3(WAVE), lds, ctx->stream, a,
                                ring);
         }
     }
@@ -473,8 +493,12 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
 
     garlic_call_stats &st = p->stats;
     st.n_segments = (int64_t)p->boundaries.size();
-    st.n_runs = (int64_t)runs.size();
-    st.n_chain_items = (int64_t)runs.size() * nblk;
+    st.n_runs = n_runs;
+    st.n_chain_items = (int64_t)n_items;
+    p->plan.valid = true;
+    p->plan.mode = (int)mode; p->plan.W = W; p->plan.max_gap = max_gap; p->plan.ind_begin = ind_begin;
+    p->plan.ind_count = ind_count; p->plan.pitch_align = pitch_align;
+    p->plan.n_items = n_items; p->plan.n_fill = n_fill; p->plan.n_runs = n_runs; p->plan.n_valid = n_valid;
     st.n_valid_windows = n_valid;
     st.n_missing = p->nloci - n_valid;
     (void)hipEventElapsedTime(&st.chain_kernel_ms, ctx->ev_k0, ctx->ev_k1);
@@ -647,6 +671,7 @@ int garlic_panel_set_map(garlic_panel *p, const int32_t *pos, const double *gpos
     p->have_map = true;
     p->seg_valid = false;
     p->decay_valid = false;
+    p->plan.valid = false;
     return GARLIC_OK;
 }
 

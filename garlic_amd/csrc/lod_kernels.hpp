@@ -484,7 +484,8 @@ lod_chain_kernel(ChainArgs p)
                            [ptrail] "s"(st.trail_row), [pltab] "s"(st.lead_tab),
                            [pttab] "s"(st.trail_tab), [rowinc] "s"(rowinc), [out] "s"(out_tile),
                            [ntiles] "s"(ntiles), [shl] "s"(st.sh_lead), [sht] "s"(st.sh_trail),
-                           [npad4] "s"((uint32_t)(npad * 4)), [pitch8] "s"((uint32_t)(pitch * 8))
+                           [npad4] "s"((uint32_t)(npad * 4)), [pitch8] "s"((uint32_t)(pitch * 8)),
+                           [rows] "s"(rows_valid)
                          : GARLIC_CHAIN_LOOP_CLOBBERS);
             st.lead_row += (int64_t)(2 * ntiles) * npad;
             st.trail_row += (int64_t)(2 * ntiles) * npad;

@@ -90,9 +90,10 @@ S_SHL, S_SHT = 53, 54
 S_TMP = 55
 S_K = 56
 S_F0, S_F1 = 57, 58
+S_ROWS = 59                # POST: valid individuals (rows) of this item
 
 CLOBBER_V = sorted(set(list(range(V_ST, V_ST + 64)) + list(range(100, 252))))
-CLOBBER_S = list(range(40, 59))
+CLOBBER_S = list(range(40, 60))
 
 
 class Gen:
@@ -383,7 +384,11 @@ def post_tile(g, slot, uid):
         for q in range(16):
             g.wait_lds(ids[q])
             if "poststore" not in ABL:
+                # row groups wholly past the shard's last individual are pad rows: not stored
+                e(f"s_cmp_gt_u32 s{S_ROWS}, {4 * q}")
+                e(f"s_cbranch_scc0 POST_SKIP_{uid}_{q}_%=")
                 e(f"global_store_dwordx4 v{V_STOFF + q}, {quad(V_ST + 4 * q)}, s[{S_OUT}:{S_OUT + 1}] {STORE_FLAGS}".rstrip())
+                e(f"POST_SKIP_{uid}_{q}_%=:")
         e(f"s_add_u32 s{S_OUT}, s{S_OUT}, 256")
         e(f"s_addc_u32 s{S_OUT + 1}, s{S_OUT + 1}, 0")
     assert g.complete == g.issued
@@ -396,6 +401,7 @@ def post_tile(g, slot, uid):
 def gen_post(g):
     e = g.emit
     e("ROLE_POST_%=:")
+    e(f"s_mov_b32 s{S_ROWS}, %[rows]")
     e(f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], %[out]")
     e(f"s_mov_b32 s{S_CNT}, %[ntiles]")
     e(f"s_mov_b32 s{S_K}, 0")
