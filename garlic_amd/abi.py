@@ -23,7 +23,7 @@ SYMBOLS = [
     "garlic_panel_create", "garlic_panel_destroy", "garlic_panel_set_map",
     "garlic_panel_set_freq", "garlic_panel_set_genotypes", "garlic_panel_set_gl",
     "garlic_panel_set_ld", "garlic_lod_out_layout", "garlic_lod_windows",
-    "garlic_wlod_windows", "garlic_last_call_stats",
+    "garlic_wlod_windows", "garlic_lod_flatten", "garlic_last_call_stats",
 ]
 
 
@@ -72,6 +72,7 @@ def lib():
                                      C.c_int32, C.c_int32, _vp, C.c_int32]
     L.garlic_wlod_windows.argtypes = [_vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_double, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32]
+    L.garlic_lod_flatten.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int64, _i64p]
     L.garlic_last_call_stats.argtypes = [_vp, C.POINTER(CallStats)]
     for name in SYMBOLS:
         f = getattr(L, name)
@@ -222,6 +223,14 @@ class Panel:
         ind_count = self.nind - ind_begin if ind_count is None else ind_count
         check(lib().garlic_lod_windows(self.handle, winsize, error, max_gap, int(use_gl), ind_begin,
                                        ind_count, pitch_align, _vp(out_ptr), DEVICE))
+
+    def flatten_device(self, scores_ptr, step, feed_ptr, feed_capacity, pitch_align=32, nind_out=None):
+        """KDE feed (convertWinData2DoubleData) of device-resident scores; returns the count."""
+        nind_out = self.nind if nind_out is None else nind_out
+        n = C.c_int64()
+        check(lib().garlic_lod_flatten(self.handle, _vp(scores_ptr), pitch_align, nind_out, step,
+                                       _vp(feed_ptr) if feed_ptr else None, feed_capacity, C.byref(n)))
+        return n.value
 
     def stats(self):
         st = CallStats()

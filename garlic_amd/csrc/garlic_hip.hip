@@ -137,6 +137,7 @@ struct garlic_panel {
     DevBuf<int32_t> d_counter;
     DevBuf<ChrDev> d_chrs;
     DevBuf<int16_t> d_stage16;
+    DevBuf<int64_t> d_row_counts;
     // TGLS: dictionary-coded per-genotype error probabilities
     bool have_gl = false;
     std::vector<double> gl_values;                 // code -> error probability
@@ -641,7 +642,7 @@ int garlic_panel_destroy(garlic_panel *p)
     p->d_packed.release(); p->d_pos.release(); p->d_cs.release(); p->d_ce.release();
     p->d_chr_off.release(); p->d_tab.release(); p->d_blk_counts.release();
     p->d_blk_offsets.release(); p->d_total.release(); p->d_boundaries.release();
-    p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release(); p->d_codes.release(); p->d_tabgl.release();
+    p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release(); p->d_row_counts.release(); p->d_codes.release(); p->d_tabgl.release();
     p->d_rld.release(); p->d_decay.release(); p->d_stage64.release();
     p->d_out.release();
     delete p;
@@ -834,6 +835,41 @@ int garlic_wlod_windows(garlic_panel *p, int32_t winsize, double error, int32_t 
     p->wlod_use_gl = use_gl != 0;
     return launch_lod(p, MODE_WLOD, winsize, error, max_gap, M, mu, ind_begin, ind_count, pitch_align,
                       out, where);
+}
+
+int garlic_lod_flatten(garlic_panel *p, const double *scores, int32_t pitch_align, int32_t nind_out,
+                       int32_t step, double *feed, int64_t feed_capacity, int64_t *count)
+{
+    if (!p || !scores || !count) return fail(GARLIC_ERR_INVALID, "panel, scores and count are required");
+    if (step < 1 || pitch_align < 1 || nind_out < 1)
+        return fail(GARLIC_ERR_INVALID, "step, pitch_align and nind_out must be >= 1");
+    int rc;
+    if ((rc = set_device(p->ctx))) return rc;
+    hipStream_t s = p->ctx->stream;
+    Layout L = make_layout(p, pitch_align, nind_out);
+    std::vector<ChrDev> chrs(p->nchr);
+    for (int c = 0; c < p->nchr; c++) chrs[c] = ChrDev{p->chr_off[c], L.base[c], L.pitch[c], p->chr_nloci[c], 0};
+    const int nrows = p->nchr * nind_out;
+    if ((rc = p->d_chrs.reserve(chrs.size()))) return rc;
+    if ((rc = p->d_row_counts.reserve((size_t)nrows))) return rc;
+    p->plan.valid = false; // d_chrs is shared with the work plan
+    HIP_TRY(hipMemcpyAsync(p->d_chrs.p, chrs.data(), sizeof(ChrDev) * chrs.size(), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(feed_count_kernel, dim3((unsigned)nrows), dim3(WAVE), 0, s, scores, p->d_chrs.p, p->nchr,
+                       nind_out, step, p->d_row_counts.p);
+    std::vector<int64_t> counts((size_t)nrows);
+    HIP_TRY(hipMemcpyAsync(counts.data(), p->d_row_counts.p, sizeof(int64_t) * nrows, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    int64_t total = 0; // exclusive scan over (chromosome, individual) rows: tiny, done on the host
+    for (auto &c : counts) { const int64_t n = c; c = total; total += n; }
+    *count = total;
+    if (total > feed_capacity || total == 0) return GARLIC_OK;
+    if (!feed) return fail(GARLIC_ERR_INVALID, "feed is NULL");
+    HIP_TRY(hipMemcpyAsync(p->d_row_counts.p, counts.data(), sizeof(int64_t) * nrows, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(feed_write_kernel, dim3((unsigned)nrows), dim3(WAVE), 0, s, scores, p->d_chrs.p, p->nchr,
+                       nind_out, step, p->d_row_counts.p, feed);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return GARLIC_OK;
 }
 
 int garlic_last_call_stats(garlic_panel *p, garlic_call_stats *stats)

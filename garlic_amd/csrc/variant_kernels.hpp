@@ -145,4 +145,42 @@ wlod_kernel(VariantArgs p, int ring)
     }
 }
 
+// ---- KDE feed: ordered compaction of every step-th scored window (garlic-data.cpp:2026-2069).
+// One wavefront per (chromosome, individual) row; lanes walk the sampled loci 64 at a time and
+// rank the keepers with a ballot (integer work: exact whatever the order).
+__device__ __forceinline__ bool feed_keep(double x) { return x != MISSING_D && !(x != x); }
+
+__global__ void __launch_bounds__(WAVE)
+feed_count_kernel(const double *scores, const ChrDev *chrs, int nchr, int nind, int step, int64_t *row_counts)
+{
+    const int row = blockIdx.x; // chr * nind + ind
+    const ChrDev c = chrs[row / nind];
+    const double *src = scores + c.out_base + (int64_t)(row % nind) * c.out_pitch;
+    const int nsamp = (c.nloci + step - 1) / step;
+    int cnt = 0;
+    for (int k = threadIdx.x; k < nsamp; k += WAVE) cnt += feed_keep(src[(int64_t)k * step]) ? 1 : 0;
+    cnt = wave_inclusive_scan(cnt);
+    if (threadIdx.x == WAVE - 1) row_counts[row] = cnt;
+}
+
+__global__ void __launch_bounds__(WAVE)
+feed_write_kernel(const double *scores, const ChrDev *chrs, int nchr, int nind, int step,
+                  const int64_t *row_offsets, double *feed)
+{
+    const int row = blockIdx.x;
+    const ChrDev c = chrs[row / nind];
+    const double *src = scores + c.out_base + (int64_t)(row % nind) * c.out_pitch;
+    const int nsamp = (c.nloci + step - 1) / step;
+    int64_t base = row_offsets[row];
+    for (int k0 = 0; k0 < nsamp; k0 += WAVE) {
+        const int k = k0 + threadIdx.x;
+        const double x = (k < nsamp) ? src[(int64_t)k * step] : MISSING_D;
+        const bool keep = (k < nsamp) && feed_keep(x);
+        const unsigned long long m = __ballot(keep);
+        const int rank = __popcll(m & ((1ull << threadIdx.x) - 1ull));
+        if (keep) feed[base + rank] = x;
+        base += __popcll(m);
+    }
+}
+
 } // namespace garlic

@@ -99,9 +99,12 @@ int garlic_panel_set_gl(garlic_panel *panel, const double *gl, int64_t ld, int64
 int garlic_panel_set_ld(garlic_panel *panel, int32_t winsize, const double *ld, int32_t where);
 
 /* Output addressing for this panel: pitch_align = 1 gives the reference's dense rows
- * (chr_pitch[c] = chr_nloci[c]); a larger value rounds every row pitch and chromosome base up to
- * that many doubles (32 = 256-byte aligned rows, what the kernels like best).  total = number of
- * doubles a full output needs for nind_out individuals. */
+ * (chr_pitch[c] = chr_nloci[c], chromosome blocks back to back).  A larger value rounds every row
+ * pitch and chromosome base up to that many doubles AND reserves rows up to the next multiple of
+ * 64 individuals per chromosome block (32 = 256-byte aligned rows: the layout the tuned kernel
+ * needs; with pitch_align = 1 a slower generic kernel path runs).  Pad rows / pad columns are
+ * never read back and hold unspecified values.  total = number of doubles the caller's buffer
+ * must have for nind_out individuals. */
 int garlic_lod_out_layout(garlic_panel *panel, int32_t pitch_align, int32_t nind_out,
                           int64_t *chr_base, int64_t *chr_pitch, int64_t *total);
 
@@ -117,6 +120,16 @@ int garlic_lod_windows(garlic_panel *panel, int32_t winsize, double error, int32
 int garlic_wlod_windows(garlic_panel *panel, int32_t winsize, double error, int32_t max_gap,
                         int32_t use_gl, int32_t M, double mu, int32_t ind_begin, int32_t ind_count,
                         int32_t pitch_align, double *out, int32_t where);
+
+/* convertWinData2DoubleData (src/garlic-data.cpp:2026-2069) on the device: the KDE feed.  Reads
+ * scores laid out as garlic_lod_out_layout(pitch_align, nind_out) describes (device memory) and
+ * writes, in the reference's order chromosome -> individual -> locus, every `step`-th window
+ * (locus 0, step, 2*step, ...) that is neither MISSING nor NaN.  feed (device) must hold
+ * feed_capacity doubles; *count (host) receives the number written (or needed, if larger than the
+ * capacity -- nothing is written then).  The explore / auto-winsize flows keep only these values
+ * (step = winsize), 8/winsize bytes per window instead of 8. */
+int garlic_lod_flatten(garlic_panel *panel, const double *scores, int32_t pitch_align, int32_t nind_out,
+                       int32_t step, double *feed, int64_t feed_capacity, int64_t *count);
 
 /* Introspection used by tests and the bench (device work of the last garlic_*_windows call). */
 typedef struct garlic_call_stats {

@@ -99,3 +99,35 @@ def test_wlod_random_multichr_with_gl(gpu_ctx):
                 want = ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, 0.001, mg, 1e-9, 7,
                                            gl=err[c] if use_gl else None)
                 assert ol.bits_equal(np.ascontiguousarray(out[c]), want), (use_gl, c)
+
+
+def test_kde_feed_flatten_on_device(gpu_ctx):
+    """garlic_lod_flatten = convertWinData2DoubleData (garlic-data.cpp:2026): order chr -> ind -> locus,
+    every step-th window, MISSING and NaN dropped -- against the golden and the oracle."""
+    import torch
+    rng = np.random.default_rng(21)
+    mg, W = 200000, 30
+    chroms = [ol.random_panel(rng, n, 70, max_gap=mg) for n in (900, 410, 64)]
+    # a NaN-producing frequency (only reachable through --freq-file): log10 of a negative ratio
+    chroms[1][1][100] = -0.25
+    with abi.Panel(gpu_ctx, [c[0].shape[0] for c in chroms], 70) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms])
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        base, pitch, total = panel.out_layout(32, 70)
+        out = torch.empty(total, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        panel.lod_windows_device(out.data_ptr(), W, 0.001, mg, pitch_align=32)
+        wins = [ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg) for g, f, p, cs, ce in chroms]
+        assert np.isnan(wins[1]).any()
+        for step in (1, W, 7):
+            want = np.concatenate([ol.oracle_flatten(w, step) for w in wins])
+            n = panel.flatten_device(out.data_ptr(), step, None, 0)          # count only
+            assert n == want.shape[0]
+            feed = torch.empty(n, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            assert panel.flatten_device(out.data_ptr(), step, feed.data_ptr(), n) == n
+            torch.cuda.synchronize()
+            assert ol.bits_equal(feed.cpu().numpy(), want), step
+    d = np.load(os.path.join(G, "flatten.npz"))
+    assert ol.bits_equal(ol.oracle_flatten(d["win"], 30), d["flat_step30"])
