@@ -457,7 +457,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     if (n_items) HIP_TRY(hipMemsetAsync(p->d_counter.p, 0, sizeof(int32_t), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev_k0, ctx->stream));
     if (n_items && mode == MODE_LOD) {
-        ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p,     p->d_chrs.p,     d_out, p->nind_pad,
+        ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p,     p->d_chrs.p,     d_out, p->nind_pad, p->nwordrows,
                     ind_begin,     ind_count,  W,               (int32_t)n_items, p->d_counter.p};
         if (aligned16)
             hipLaunchKernelGGL(lod_chain_kernel<true>, dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
@@ -467,7 +467,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                                ctx->stream, a);
     } else if (n_items) {
         VariantArgs a{p->d_packed.p, p->d_tab.p,  p->d_tabgl.p, p->d_codes.p, p->d_decay.p, p->d_rld.p,
-                      p->d_items.p,  p->d_chrs.p, d_out,        p->nind_pad,  ind_begin,    ind_count,
+                      p->d_items.p,  p->d_chrs.p, d_out,        p->nind_pad,  p->nwordrows, ind_begin,    ind_count,
                       W,             (int32_t)p->gl_values.size(), use_gl ? 1 : 0};
         if (mode == MODE_LOD_GL) {
             hipLaunchKernelGGL(lod_chain_gl_kernel, dim3((unsigned)n_items), dim3(WAVE), 0,
@@ -618,7 +618,7 @@ int garlic_panel_create(garlic_ctx *ctx, int32_t nchr, const int32_t *chr_nloci,
     }
     p->nloci = p->chr_off[nchr];
     p->nind_pad = ((int64_t)nind + 63 + 63) / 64 * 64;
-    p->nwordrows = ((GOFF + p->nloci + GPAD_BACK) >> 4) + 2;
+    p->nwordrows = ((((GOFF + p->nloci + GPAD_BACK) >> 4) + 2) + 15) & ~(int64_t)15; // whole 4 KB chunks
     auto cleanup = [&](int code) { garlic_panel_destroy(p); return code; };
     if ((rc = p->d_packed.reserve((size_t)(p->nwordrows * p->nind_pad)))) return cleanup(rc);
     if ((rc = p->d_chr_off.reserve(nchr + 1))) return cleanup(rc);
@@ -718,7 +718,7 @@ int garlic_panel_set_genotypes(garlic_panel *p, const int16_t *geno, int64_t ld,
             const int64_t wn = std::min<int64_t>(65535, w_hi - w);
             dim3 grid((unsigned)((p->nind_pad + 255) / 256), (unsigned)wn);
             hipLaunchKernelGGL(pack_genotypes_kernel, grid, block, 0, s, src, ld, l0, rows, p->nind,
-                               p->nind_pad, p->d_packed.p, w, w + wn);
+                               p->nind_pad, p->nwordrows, p->d_packed.p, w, w + wn);
         }
         if (where == GARLIC_HOST) HIP_TRY(hipStreamSynchronize(s)); // staging buffer is reused
     }

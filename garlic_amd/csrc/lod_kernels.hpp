@@ -35,7 +35,7 @@ constexpr int WAVE = 64;
 constexpr int TILE = 32;          // window starts per tile (= 256 B of one output row)
 constexpr int TPITCH = 34;        // doubles per LDS tile row: 272 B keeps ds_read_b128 16-B aligned
 constexpr int GOFF = 32;          // pad SNP rows in front of the packed genotypes / term table
-constexpr int GPAD_BACK = 256;    // pad SNP rows behind (prefetch over-reads stay in bounds)
+constexpr int GPAD_BACK = 32 * GARLIC_CHAIN_NSLOT + 48 * GARLIC_CHAIN_CHROWS + 64; // pad SNP rows behind: the input rings run NSLOT tiles (+ one genotype chunk) ahead
 constexpr double MISSING_D = -9999.0;
 
 struct ChrDev {
@@ -66,15 +66,27 @@ struct FillItem {    // a stretch of MISSING windows [lo, hi) of one chromosome
 // those (garlic-roh.cpp:379-383), which is entry 3 of the term table.
 // One thread = one (word row, individual); consecutive lanes = consecutive individuals, so both
 // the 16 strided reads and the write are coalesced.
+//
+// Device layout of the packed panel: [64-individual block][word row][64 individuals].  One chain
+// item (SNP run x 64 individuals) then reads ONE sequential stream, 256 B per 16 SNPs, which the
+// chain kernel fetches in 1 KB requests -- with the individual-minor layout of the whole panel
+// the same bytes are 256 B pieces 4*nind bytes apart, and those scattered HBM reads, interleaved
+// with the score write stream, cost 15 % of the kernel.
+__device__ __host__ __forceinline__ int64_t packed_index(int64_t w, int64_t col, int64_t nwordrows)
+{
+    return (((col >> 6) * nwordrows + w) << 6) + (col & 63);
+}
+
 __global__ void pack_genotypes_kernel(const int16_t *__restrict__ geno, int64_t ld,
                                       int64_t locus_begin, int64_t locus_count, int32_t nind,
-                                      int64_t nind_pad, uint32_t *__restrict__ packed,
-                                      int64_t word_lo, int64_t word_hi)
+                                      int64_t nind_pad, int64_t nwordrows,
+                                      uint32_t *__restrict__ packed, int64_t word_lo,
+                                      int64_t word_hi)
 {
     int64_t ind = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t w = word_lo + blockIdx.y;
     if (ind >= nind_pad || w >= word_hi) return;
-    uint32_t *dst = packed + w * nind_pad + ind;
+    uint32_t *dst = packed + packed_index(w, ind, nwordrows);
     // SNPs of this word that the caller did not supply keep their previous bits
     uint32_t word = *dst;
     if (ind >= nind) { *dst = 0xFFFFFFFFu; return; }
@@ -226,12 +238,13 @@ fill_missing_kernel(const FillItem *items, const ChrDev *chrs, int32_t nind, dou
 // ------------------------------------------------------------------------------------------
 // The chain kernel.
 struct ChainArgs {
-    const uint32_t *packed;   // [word row][nind_pad], word row w holds global loci 16w-GOFF ..
+    const uint32_t *packed;   // [nind_pad/64][nwordrows][64], word row w holds global loci 16w-GOFF ..
     const double *tab;        // [GOFF + nloci + pad][4] per-SNP terms
     const ChainItem *items;
     const ChrDev *chrs;
     double *out;
     int64_t nind_pad;
+    int64_t nwordrows;
     int32_t ind_begin;        // first individual of this call inside the panel shard
     int32_t ind_count;        // rows in the output
     int32_t winsize;
@@ -246,7 +259,6 @@ struct ChainArgs {
 //   slot: for each of the two SNP streams (entering / leaving the window) the genotype words +1
 //   and +2 of every lane (word +0 is carried in a register) and the 32 term rows
 //   {lod(0),lod(1),lod(2),0.0} of the tile's SNPs.
-constexpr int NSLOT = 1;
 constexpr uint32_t SLOT_BYTES = 3072;
 constexpr uint32_t SL_LW1 = 0, SL_LW2 = 256, SL_TW1 = 512, SL_TW2 = 768;
 constexpr uint32_t SL_LTAB = 1024, SL_TTAB = 2048;
@@ -257,23 +269,24 @@ constexpr int CHAIN_THREADS = 192;
 
 // Wave-uniform stream state (lives in SGPRs).
 struct Streams {
-    const uint32_t *lead_row, *trail_row;  // packed + word_row(current tile) * npad + first column
+    int64_t lead_w, trail_w;               // word row of the current tile's first SNP
     const double *lead_tab, *trail_tab;    // term row of the current tile's first SNP
-    int64_t npad;
     int sh_lead, sh_trail;                 // bit offset of the tile's first SNP in its word
 };
 
 __device__ __forceinline__ void advance(Streams &st)
 {   // next tile = two genotype words and 32 term rows further along both streams
-    st.lead_row += 2 * st.npad; st.trail_row += 2 * st.npad;
+    st.lead_w += 2; st.trail_w += 2;
     st.lead_tab += 4 * TILE; st.trail_tab += 4 * TILE;
 }
 
 // same content through registers (compiler-managed waits): head / leftover tiles
-__device__ __forceinline__ void fill_regs(unsigned char *smem, const Streams &st, int lane)
+// gcol = this lane's column of the packed panel (word row w at gcol[w * 64])
+__device__ __forceinline__ void fill_regs(unsigned char *smem, const Streams &st,
+                                          const uint32_t *gcol, int lane)
 {
-    const uint32_t l1 = st.lead_row[st.npad + lane], l2 = st.lead_row[2 * st.npad + lane];
-    const uint32_t t1 = st.trail_row[st.npad + lane], t2 = st.trail_row[2 * st.npad + lane];
+    const uint32_t l1 = gcol[(st.lead_w + 1) * WAVE], l2 = gcol[(st.lead_w + 2) * WAVE];
+    const uint32_t t1 = gcol[(st.trail_w + 1) * WAVE], t2 = gcol[(st.trail_w + 2) * WAVE];
     const double2 tl = reinterpret_cast<const double2 *>(st.lead_tab)[lane];
     const double2 tt = reinterpret_cast<const double2 *>(st.trail_tab)[lane];
     *reinterpret_cast<uint32_t *>(smem + SL_LW1 + lane * 4) = l1;
@@ -400,30 +413,37 @@ lod_chain_kernel(ChainArgs p)
     const int rows_valid = min(WAVE, p.ind_count - it.ind0);
     // lanes past the shard read the padded columns (code 3 -> term 0.0)
     const int64_t col0 = (int64_t)p.ind_begin + it.ind0;
-    const uint32_t *gcol = p.packed + col0 + lane;
-    const int64_t npad = p.nind_pad;
+    const uint32_t *gcol = p.packed + packed_index(0, col0 + lane, p.nwordrows);
     const int64_t Gbase = c.loc_base + GOFF; // global (padded) index of chromosome-local locus 0
 
     // ---- first window of the run: sum of W terms left to right (garlic-roh.cpp:57-71); the
     //      first W-1 of them here, the W-th enters in the first tile below.
     double acc = 0.0;
     if (wave == 0) {
+        // 64 SNPs per round, every load of a round issued before the first add: 5 genotype words
+        // (funnel-shifted to the round's first SNP), then 64 independent term gathers, then the
+        // ordered adds -- two memory round trips per 64 terms instead of two per 16
         int l = a;
         const int lend = a + W - 1;
         while (l < lend) {
             const int64_t G = Gbase + l;
-            const int off = (int)(G & 15);
-            const uint32_t word = gcol[(G >> 4) * npad];
-            const int n = min(16 - off, lend - l);
-            double t[16];
+            const int sh = 2 * (int)(G & 15);
+            const uint32_t *wp = gcol + (G >> 4) * WAVE;
+            uint32_t wd[5];
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int qq = min(q, n - 1);
-                const uint32_t g = (word >> (2 * (off + qq))) & 3u;
-                t[q] = p.tab[(G + qq) * 4 + g];
+            for (int q = 0; q < 5; q++) wd[q] = wp[q * WAVE];
+            uint32_t al[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) al[q] = __builtin_amdgcn_alignbit(wd[q + 1], wd[q], sh);
+            const int n = min(64, lend - l);
+            double t[64];
+#pragma unroll
+            for (int q = 0; q < 64; q++) {
+                const uint32_t g = (al[q >> 4] >> (2 * (q & 15))) & 3u;
+                t[q] = p.tab[(G + min(q, n - 1)) * 4 + ((q < n) ? g : 3u)];
             }
 #pragma unroll
-            for (int q = 0; q < 16; q++) acc += (q < n) ? t[q] : 0.0;
+            for (int q = 0; q < 64; q++) acc += (q < n) ? t[q] : 0.0;
             l += n;
         }
     }
@@ -435,11 +455,10 @@ lod_chain_kernel(ChainArgs p)
         // entering-SNP stream starts at local locus s0+W-1, leaving-SNP stream at s0-1
         const int64_t Glead = Gbase + s0 + W - 1;
         const int64_t Gtrail = Gbase + s0 - 1;
-        st.npad = npad;
         st.sh_lead = 2 * (int)(Glead & 15);
         st.sh_trail = 2 * (int)(Gtrail & 15);
-        st.lead_row = p.packed + col0 + (Glead >> 4) * npad;
-        st.trail_row = p.packed + col0 + (Gtrail >> 4) * npad;
+        st.lead_w = Glead >> 4;
+        st.trail_w = Gtrail >> 4;
         st.lead_tab = p.tab + Glead * 4;
         st.trail_tab = p.tab + Gtrail * 4;
     }
@@ -455,9 +474,9 @@ lod_chain_kernel(ChainArgs p)
         const int last = (phase == 0) ? s0 : b;
         while (s0 <= last && s0 <= b) {
             if (wave == 0) {
-                uint32_t lc = st.lead_row[lane];
-                uint32_t tc = st.trail_row[lane];
-                fill_regs(smem, st, lane);
+                uint32_t lc = gcol[st.lead_w * WAVE];
+                uint32_t tc = gcol[st.trail_w * WAVE];
+                fill_regs(smem, st, gcol, lane);
                 const TileBits tb = tile_consume<0>(smem, lc, tc, st, lane);
                 tile_steps<true, 0>(smem, tile, acc, tb, s0, a, b, lane);
                 tile_store<true, ALIGNED16>(tile, s0, a, b, lane, rows_valid, out_tile, pitch);
@@ -466,29 +485,40 @@ lod_chain_kernel(ChainArgs p)
             s0 += TILE;
             out_tile += TILE;
         }
-        if (phase == 1 || !ALIGNED16 || !c.fast) continue;
+        // The hand-scheduled loop needs 256 B-aligned output rows, a block-aligned first
+        // individual (one sequential genotype stream) and a window that fits its genotype ring.
+        if (phase == 1 || !ALIGNED16 || !c.fast || (col0 & 63) != 0) continue;
+        if (st.lead_w - st.trail_w > GARLIC_CHAIN_MAX_DW) continue;
 
         int ntiles = (b + 1 - s0) / TILE;
         if (ntiles >= 2) {
-            const uint64_t rowinc = (uint64_t)(2 * npad) * 4;
-            // genotype word +0 of the first full tile, both streams (POST funnel-shifts the words)
-            uint32_t lc = st.lead_row[lane];
-            uint32_t tc = st.trail_row[lane];
+            // genotype word +0 of the first full tile, both streams (PRE funnel-shifts the words)
+            uint32_t lc = gcol[st.lead_w * WAVE];
+            uint32_t tc = gcol[st.trail_w * WAVE];
+            // genotype ring of the loop: word row w lives at ring row w % WROWS, fetched in
+            // chunks of CHROWS rows (1 KB requests).  Initial fill = chunk of the leaving stream's first word
+            // .. one chunk past the entering stream's row of tile NSLOT-1.
+            const int64_t chunk0 = st.trail_w / GARLIC_CHAIN_CHROWS;
+            const int64_t chunkI = (st.lead_w + 2 * GARLIC_CHAIN_NSLOT) / GARLIC_CHAIN_CHROWS + 1;
+            const uint32_t *pchunk =
+                p.packed + packed_index(GARLIC_CHAIN_CHROWS * chunk0, col0, p.nwordrows);
+            const uint32_t wmask = GARLIC_CHAIN_WROWS - 1;
             // all waves enter together; the block starts by draining each wave's own memory
             // operations, its stage barriers order the LDS hand-offs (TILE buffer 0 above
             // included: the loop first writes it two barriers in)
             asm volatile(GARLIC_CHAIN_LOOP_ASM
                          : [acc] "+v"(acc)
                          : [wave] "s"(wave), [lane] "v"(lane), [lc] "v"(lc), [tc] "v"(tc),
-                           [plead] "s"(st.lead_row),
-                           [ptrail] "s"(st.trail_row), [pltab] "s"(st.lead_tab),
-                           [pttab] "s"(st.trail_tab), [rowinc] "s"(rowinc), [out] "s"(out_tile),
+                           [pchunk] "s"(pchunk), [nchunk0] "s"((uint32_t)(chunkI - chunk0 + 1) * (GARLIC_CHAIN_CHROWS / 4)),
+                           [roff0] "s"((uint32_t)((GARLIC_CHAIN_CHROWS * chunk0) & wmask) * 256u),
+                           [laddr0] "s"((uint32_t)(st.lead_w & wmask) * 256u),
+                           [taddr0] "s"((uint32_t)(st.trail_w & wmask) * 256u),
+                           [pltab] "s"(st.lead_tab), [pttab] "s"(st.trail_tab), [out] "s"(out_tile),
                            [ntiles] "s"(ntiles), [shl] "s"(st.sh_lead), [sht] "s"(st.sh_trail),
-                           [npad4] "s"((uint32_t)(npad * 4)), [pitch8] "s"((uint32_t)(pitch * 8)),
-                           [rows] "s"(rows_valid)
+                           [pitch8] "s"((uint32_t)(pitch * 8)), [rows] "s"(rows_valid)
                          : GARLIC_CHAIN_LOOP_CLOBBERS);
-            st.lead_row += (int64_t)(2 * ntiles) * npad;
-            st.trail_row += (int64_t)(2 * ntiles) * npad;
+            st.lead_w += 2 * ntiles;
+            st.trail_w += 2 * ntiles;
             st.lead_tab += (int64_t)(4 * TILE) * ntiles;
             st.trail_tab += (int64_t)(4 * TILE) * ntiles;
             s0 += ntiles * TILE;

@@ -27,13 +27,14 @@ struct VariantArgs {
     const ChrDev *chrs;
     double *out;
     int64_t nind_pad;
+    int64_t nwordrows;
     int32_t ind_begin, ind_count, winsize, ncodes, use_gl;
 };
 
 // per-SNP term of this lane's individual; G = padded global locus index
 __device__ __forceinline__ double variant_term(const VariantArgs &p, int64_t G, int64_t col)
 {
-    const uint32_t word = p.packed[(G >> 4) * p.nind_pad + col];
+    const uint32_t word = p.packed[packed_index(G >> 4, col, p.nwordrows)];
     const uint32_t g = (word >> (2 * (int)(G & 15))) & 3u;
     if (p.use_gl) {
         const uint32_t code = p.codes[G * p.nind_pad + col];

@@ -60,6 +60,20 @@ def test_individual_counts(gpu_ctx, nind):
         check_against_oracle(out, *data, 25, 0.01, max_gap)
 
 
+@pytest.mark.parametrize("W", [640, 990, 1010, 1025, 1040, 1100, 1600])
+def test_wide_windows_around_the_genotype_ring_limit(gpu_ctx, W):
+    """The tuned loop keeps the leaving SNP stream in an LDS genotype ring; windows wider than the
+    ring fall back to the generic path.  Both sides of the limit (about 1000 SNPs), block-aligned
+    and unaligned first individual."""
+    rng = np.random.default_rng(W)
+    max_gap = 10 ** 9
+    data = make_multichr(rng, [5000, 3100], 140, max_gap, gaps=0)
+    for ind_begin, ind_count in ((0, 140), (64, 70), (37, 64)):
+        out, _ = run_gpu(gpu_ctx, *data, W, 0.001, max_gap, pitch_align=32, ind_begin=ind_begin,
+                         ind_count=ind_count)
+        check_against_oracle(out, *data, W, 0.001, max_gap, lo=ind_begin, hi=ind_begin + ind_count)
+
+
 def test_individual_subrange(gpu_ctx):
     rng = np.random.default_rng(5)
     max_gap = 200000

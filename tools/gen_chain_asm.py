@@ -52,15 +52,28 @@ import os
 ABL = os.environ.get("GARLIC_ABLATE", "")
 STORE_FLAGS = os.environ.get("GARLIC_STORE_FLAGS", "nt")  # non-temporal: the scores are written once and never re-read here (measured -2.7 %)
 
+LOAD_FLAGS = os.environ.get("GARLIC_LOAD_FLAGS", "")
 NSLOT = int(os.environ.get("GARLIC_NSLOT", "8"))
 NTILE = int(os.environ.get("GARLIC_NTILE", "4"))
-RING = 4096
-SLOT = 7168
-SL_LTAB, SL_TTAB = 0, 1024
-SL_LW1, SL_LW2, SL_TW1, SL_TW2 = 2048, 2304, 2560, 2816
-SL_EXPL, SL_EXPT = 3072, 5120
+NFLY = int(os.environ.get("GARLIC_NFLY", "3"))   # tiles of LDS-DMA requests PRE leaves in flight
+assert 3 * NFLY <= 63 and NSLOT - NFLY >= 3 and NSLOT % 2 == 0
+WROWS = int(os.environ.get("GARLIC_WROWS", "128"))   # genotype ring: word rows (256 B each), power of 2
+WMASK = WROWS * 256 - 1
+CH = int(os.environ.get("GARLIC_CHUNK", "4"))        # 1 KB requests per genotype chunk (4 word rows each)
+CHROWS, CHPERIOD = 4 * CH, 2 * CH                    # rows per chunk; one chunk every CHPERIOD tiles
+assert NSLOT % CHPERIOD == 0
 FLAGS = 3584          # +0 tiles_done, +4 tiles_stored, +8 inputs_landed
-TILE_BASE = RING + NSLOT * SLOT
+# three rings indexed by the same slot number (tile k -> slot k % NSLOT).  The two rings that are
+# LDS-DMA targets / read with immediate offsets stay below 64 KB (16-bit DS offset field).
+TAB_BASE, TAB_SLOT = 4096, 2048         # term rows: lead 1024, trail 1024
+T_LTAB, T_TTAB = 0, 1024
+# genotype ring: word row w of the item's stream lives at WORD_BASE + (w % WROWS) * 256, filled by
+# 1 KB (4-row) LDS-DMA chunks; both SNP streams (entering / leaving) read it at their own row
+WORD_BASE = TAB_BASE + NSLOT * TAB_SLOT
+EXP_BASE, EXP_SLOT = WORD_BASE + WROWS * 256, 4096         # expanded offsets: lead 2048, trail 2048
+E_EXPL, E_EXPT = 0, 2048
+TILE_BASE = EXP_BASE + NSLOT * EXP_SLOT
+assert EXP_BASE <= 65536
 TILE_BUF = 64 * 34 * 8
 TPITCH_B = 34 * 8
 LDS_TOTAL = TILE_BASE + NTILE * TILE_BUF
@@ -81,9 +94,10 @@ V_X = 100                   # POST: 16 expanded dwords being built + 4 scratch (
 V_LC, V_TC = 214, 215
 V_FLAG, V_TMP0, V_TMP1 = 216, 218, 219   # TMP pair 64-bit aligned (ds_read2 dst)
 V_TRD2 = 122                # POST: second tile-read base
+V_LADDR, V_TADDR = 194, 195 # PRE: ring byte offset (+ lane*4) of word +0 of the next tile to expand
+V_A1L, V_A1T = 124, 125     # PRE: ring offsets of word +1
 # ---- fixed SGPRs
-S_PLEAD, S_PTRAIL, S_PLTAB, S_PTTAB = 40, 42, 44, 46
-S_ROWINC = 48
+S_PCHUNK, S_ROFF, S_NCH, S_PLTAB, S_PTTAB = 40, 42, 43, 44, 46
 S_OUT = 50
 S_CNT = 52
 S_SHL, S_SHT = 53, 54
@@ -161,8 +175,8 @@ def gen_R(g, slot, n):
     last = 0
     for i in range(8):
         j = 8 * n + i
-        g.lds(f"ds_read_b64 {pair(buf + 4 * i)}, v{V_ADDR + 2 * i} offset:{RING + slot * SLOT + SL_TTAB + 32 * j}")
-        last = g.lds(f"ds_read_b64 {pair(buf + 4 * i + 2)}, v{V_ADDR + 2 * i + 1} offset:{RING + slot * SLOT + SL_LTAB + 32 * j}")
+        g.lds(f"ds_read_b64 {pair(buf + 4 * i)}, v{V_ADDR + 2 * i} offset:{TAB_BASE + slot * TAB_SLOT + T_TTAB + 32 * j}")
+        last = g.lds(f"ds_read_b64 {pair(buf + 4 * i + 2)}, v{V_ADDR + 2 * i + 1} offset:{TAB_BASE + slot * TAB_SLOT + T_LTAB + 32 * j}")
     return last
 
 
@@ -189,11 +203,11 @@ def gen_C(g, n, a_ops, tbuf):
 
 def gen_exp_reads(g, slot, eset):
     """CHAIN: the tile's 16 expanded-offset dwords (this lane's 32 B per stream)"""
-    base = RING + slot * SLOT
+    base = slot * EXP_SLOT       # V_LANE32 holds EXP_BASE + lane*32
     last = 0
     for h in range(2):
-        g.lds(f"ds_read_b128 {quad(V_E[eset] + 4 * h)}, v{V_LANE32} offset:{base + SL_EXPL + 16 * h}")
-        last = g.lds(f"ds_read_b128 {quad(V_E[eset] + 8 + 4 * h)}, v{V_LANE32} offset:{base + SL_EXPT + 16 * h}")
+        g.lds(f"ds_read_b128 {quad(V_E[eset] + 4 * h)}, v{V_LANE32} offset:{base + E_EXPL + 16 * h}")
+        last = g.lds(f"ds_read_b128 {quad(V_E[eset] + 8 + 4 * h)}, v{V_LANE32} offset:{base + E_EXPT + 16 * h}")
     return last
 
 
@@ -255,6 +269,7 @@ def gen_chain(g):
     e(f"s_mov_b32 s{S_K}, 0")
     e(f"v_mov_b64 {pair(V_ACC + 2)}, %[acc]")
     e(f"v_lshlrev_b32_e32 v{V_LANE32}, 5, %[lane]")
+    e(f"v_add_u32_e32 v{V_LANE32}, {EXP_BASE}, v{V_LANE32}")
     e(f"v_mul_u32_u24_e32 v{V_TWR}, {TPITCH_B}, %[lane]")
     e(f"v_add_u32_e32 v{V_TWR}, {TILE_BASE}, v{V_TWR}")
     e(f"v_mov_b32_e32 v{V_FLAG}, {FLAGS}")
@@ -296,44 +311,64 @@ def gen_chain(g):
     e("s_branch DONE_%=")
 
 
-# ------------------------------------------------------------------ POST
-def gen_prefetch(g, slot):
-    """6 LDS-DMA requests for one tile into ring slot `slot`, then advance the prefetch pointers.
-    An SALU write of M0 needs a wait state before the LDS-DMA reads it (gfx9 family)."""
+# ------------------------------------------------------------------ PRE helpers
+def gen_chunk(g):
+    """one 1 KB LDS-DMA request: the next 4 word rows of the item's genotype stream into the
+    genotype ring.  An SALU write of M0 needs a wait state before the LDS-DMA reads it."""
+    e = g.emit
+    e(f"s_add_u32 m0, s{S_ROFF}, {WORD_BASE}")
+    e("s_nop 0")
+    e((f"global_load_lds_dwordx4 v{V_LANE16}, s[{S_PCHUNK}:{S_PCHUNK + 1}] " + LOAD_FLAGS).rstrip())
+    e(f"s_add_u32 s{S_PCHUNK}, s{S_PCHUNK}, 1024")
+    e(f"s_addc_u32 s{S_PCHUNK + 1}, s{S_PCHUNK + 1}, 0")
+    e(f"s_add_u32 s{S_ROFF}, s{S_ROFF}, 1024")
+    e(f"s_and_b32 s{S_ROFF}, s{S_ROFF}, {WMASK}")
+
+
+def gen_prefetch(g, slot, chunk):
+    """requests for one tile into ring slot `slot`: its 2 x 32 term rows, and (every other tile)
+    the next genotype chunk"""
     if "nodma" in ABL:
         return
-    base = RING + slot * SLOT
-    seq = [
-        (base + SL_LW1, f"global_load_lds_dword v{V_VOFFA}, s[{S_PLEAD}:{S_PLEAD + 1}]"),
-        (base + SL_LW2, f"global_load_lds_dword v{V_VOFFB}, s[{S_PLEAD}:{S_PLEAD + 1}]"),
-        (base + SL_TW1, f"global_load_lds_dword v{V_VOFFA}, s[{S_PTRAIL}:{S_PTRAIL + 1}]"),
-        (base + SL_TW2, f"global_load_lds_dword v{V_VOFFB}, s[{S_PTRAIL}:{S_PTRAIL + 1}]"),
-        (base + SL_LTAB, f"global_load_lds_dwordx4 v{V_LANE16}, s[{S_PLTAB}:{S_PLTAB + 1}]"),
-        (base + SL_TTAB, f"global_load_lds_dwordx4 v{V_LANE16}, s[{S_PTTAB}:{S_PTTAB + 1}]"),
-    ]
-    for m0, ld in seq:
+    if chunk and "nochunk" not in ABL:
+        for _ in range(CH):
+            gen_chunk(g)
+    tb = TAB_BASE + slot * TAB_SLOT
+    if "notab" in ABL:
+        return
+    for m0, ptr in ((tb + T_LTAB, S_PLTAB), (tb + T_TTAB, S_PTTAB)):
         g.emit(f"s_mov_b32 m0, {m0}")
         g.emit("s_nop 0")
-        g.emit(ld)
-    for p, inc in ((S_PLEAD, None), (S_PTRAIL, None), (S_PLTAB, 1024), (S_PTTAB, 1024)):
-        if inc is None:
-            g.emit(f"s_add_u32 s{p}, s{p}, s{S_ROWINC}")
-            g.emit(f"s_addc_u32 s{p + 1}, s{p + 1}, s{S_ROWINC + 1}")
-        else:
-            g.emit(f"s_add_u32 s{p}, s{p}, {inc}")
-            g.emit(f"s_addc_u32 s{p + 1}, s{p + 1}, 0")
+        g.emit((f"global_load_lds_dwordx4 v{V_LANE16}, s[{ptr}:{ptr + 1}] " + LOAD_FLAGS).rstrip())
+        g.emit(f"s_add_u32 s{ptr}, s{ptr}, 1024")
+        g.emit(f"s_addc_u32 s{ptr + 1}, s{ptr + 1}, 0")
+
+
+def loads_in_flight(slot):
+    """PRE's vector-memory operations retire in issue order: after iteration `slot` issued its
+    requests, the NFLY youngest iterations' requests may stay in flight (2 per tile + 1 chunk
+    per even tile)"""
+    ntab = 0 if "notab" in ABL else 2
+    nch = 0 if "nochunk" in ABL else CH
+    return sum(ntab + (nch if ((slot - d) % NSLOT) % CHPERIOD == 0 else 0) for d in range(NFLY))
 
 
 def post_expand(g, slot):
-    """POST: funnel-shift the tile's genotype words (both streams) and expand each 2-bit genotype
-    into one byte = genotype*8; this lane's 32 bytes per stream go to the slot's EXP areas
-    (8 VALU per 4 genotypes; POST is HBM-bound and has the issue slots)."""
+    """PRE: read the tile's genotype words (+1, +2; word +0 is carried) of both streams from the
+    genotype ring, funnel-shift them and expand each 2-bit genotype into one byte = genotype*8;
+    this lane's 32 bytes per stream go to the slot's EXP areas."""
     if "noexpand" in ABL:
         return
     e = g.emit
-    b = (RING + slot * SLOT) // 256
-    g.lds(f"ds_read2st64_b32 v[{V_WL1}:{V_WL2}], v{V_LANE4} offset0:{b + SL_LW1 // 256} offset1:{b + SL_LW2 // 256}")
-    w = g.lds(f"ds_read2st64_b32 v[{V_WT1}:{V_WT2}], v{V_LANE4} offset0:{b + SL_TW1 // 256} offset1:{b + SL_TW2 // 256}")
+    for a1, a0 in ((V_A1L, V_LADDR), (V_A1T, V_TADDR)):
+        e(f"v_add_u32_e32 v{a1}, 0x100, v{a0}")
+        e(f"v_and_b32_e32 v{a1}, {WMASK}, v{a1}")
+        e(f"v_add_u32_e32 v{a0}, 0x100, v{a1}")
+        e(f"v_and_b32_e32 v{a0}, {WMASK}, v{a0}")
+    g.lds(f"ds_read_b32 v{V_WL1}, v{V_A1L} offset:{WORD_BASE}")
+    g.lds(f"ds_read_b32 v{V_WL2}, v{V_LADDR} offset:{WORD_BASE}")
+    g.lds(f"ds_read_b32 v{V_WT1}, v{V_A1T} offset:{WORD_BASE}")
+    w = g.lds(f"ds_read_b32 v{V_WT2}, v{V_TADDR} offset:{WORD_BASE}")
     g.wait_lds(w)
     e(f"v_alignbit_b32 v{V_LL}, v{V_WL1}, v{V_LC}, s{S_SHL}")
     e(f"v_alignbit_b32 v{V_LH}, v{V_WL2}, v{V_WL1}, s{S_SHL}")
@@ -353,12 +388,13 @@ def post_expand(g, slot):
             e(f"v_lshl_or_b32 v{t[2]}, v{t[3]}, 8, v{t[2]}")
             e(f"v_lshl_or_b32 v{dst}, v{t[2]}, 16, v{t[0]}")
             e(f"v_lshlrev_b32_e32 v{dst}, 3, v{dst}")
-    base = RING + slot * SLOT
-    for stream, area in enumerate((SL_EXPL, SL_EXPT)):
+    base = slot * EXP_SLOT             # V_LANE32P holds EXP_BASE + lane*32
+    for stream, area in enumerate((E_EXPL, E_EXPT)):
         for h in range(2):
             g.lds(f"ds_write_b128 v{V_LANE32P}, {quad(V_X + 8 * stream + 4 * h)} offset:{base + area + 16 * h}")
 
 
+# ------------------------------------------------------------------ POST
 def post_tile(g, slot, uid):
     """POST, one tile k (tile buffer = k % NTILE): transposed write-out.  Its stores are never waited
     for; when HBM pushes back the wave simply blocks at the store issue (which is why nothing else
@@ -436,7 +472,8 @@ def gen_post(g):
 # ------------------------------------------------------------------ PRE
 def pre_tile(g, slot, uid):
     """PRE, iteration k: once CHAIN has finished tile k its ring slot is free -> request tile
-    k+NSLOT into it; the inputs requested 3 iterations ago (tile k+NSLOT-3) have landed -> expand."""
+    k+NSLOT into it; the inputs requested NFLY iterations ago (tile k+NSLOT-NFLY) have landed ->
+    expand them."""
     e = g.emit
     e(f"PRE_POLL_{uid}_%=:")
     e(f"ds_read_b32 v{V_TMP0}, v{V_FLAG}")
@@ -448,27 +485,25 @@ def pre_tile(g, slot, uid):
     e(f"s_branch PRE_POLL_{uid}_%=")
     e(f"PRE_GO_{uid}_%=:")
     g.drained()
-    gen_prefetch(g, slot)
-    # this wave's only vector-memory operations are its LDS-DMA requests (6 per tile), retired in
-    # order: 3 younger tiles may stay in flight
-    e("s_waitcnt vmcnt(18)")
-    post_expand(g, (slot + NSLOT - 3) % NSLOT)
+    gen_prefetch(g, slot, slot % CHPERIOD == 0)
+    e(f"s_waitcnt vmcnt({loads_in_flight(slot)})")
+    post_expand(g, (slot + NSLOT - NFLY) % NSLOT)
     e(f"s_add_u32 s{S_K}, s{S_K}, 1")
-    e(f"s_add_u32 s{S_F1}, s{S_K}, {NSLOT - 4}")
+    e(f"s_add_u32 s{S_F1}, s{S_K}, {NSLOT - NFLY - 1}")
     e(f"v_mov_b32_e32 v{V_TMP1}, s{S_F1}")
     e("s_waitcnt lgkmcnt(0)")
     g.drained()
-    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP1} offset:8")   # inputs_ready = k + NSLOT - 3
+    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP1} offset:8")   # inputs_ready = k + NSLOT - NFLY
 
 
 def gen_pre(g):
     e = g.emit
     e("ROLE_PRE_%=:")
-    e(f"s_mov_b64 s[{S_PLEAD}:{S_PLEAD + 1}], %[plead]")
-    e(f"s_mov_b64 s[{S_PTRAIL}:{S_PTRAIL + 1}], %[ptrail]")
+    e(f"s_mov_b64 s[{S_PCHUNK}:{S_PCHUNK + 1}], %[pchunk]")
+    e(f"s_mov_b32 s{S_ROFF}, %[roff0]")
+    e(f"s_mov_b32 s{S_NCH}, %[nchunk0]")
     e(f"s_mov_b64 s[{S_PLTAB}:{S_PLTAB + 1}], %[pltab]")
     e(f"s_mov_b64 s[{S_PTTAB}:{S_PTTAB + 1}], %[pttab]")
-    e(f"s_mov_b64 s[{S_ROWINC}:{S_ROWINC + 1}], %[rowinc]")
     e(f"s_mov_b32 s{S_CNT}, %[ntiles]")
     e(f"s_mov_b32 s{S_K}, 0")
     e(f"s_mov_b32 s{S_SHL}, %[shl]")
@@ -479,18 +514,25 @@ def gen_pre(g):
     e(f"v_lshlrev_b32_e32 v{V_LANE4}, 2, %[lane]")
     e(f"v_lshlrev_b32_e32 v{V_LANE16}, 4, %[lane]")
     e(f"v_lshlrev_b32_e32 v{V_LANE32P}, 5, %[lane]")
-    e(f"v_add_u32_e32 v{V_VOFFA}, %[npad4], v{V_LANE4}")
-    e(f"v_add_u32_e32 v{V_VOFFB}, %[npad4], v{V_VOFFA}")
+    e(f"v_add_u32_e32 v{V_LANE32P}, {EXP_BASE}, v{V_LANE32P}")
+    e(f"v_add_u32_e32 v{V_LADDR}, %[laddr0], v{V_LANE4}")
+    e(f"v_add_u32_e32 v{V_TADDR}, %[taddr0], v{V_LANE4}")
     e("s_barrier")  # CHAIN has reset the counters
-    for slot in range(NSLOT):  # ring: tiles 0..NSLOT-1
-        gen_prefetch(g, slot)
+    if "nodma" not in ABL:
+        e("PRE_FILL_%=:")   # genotype ring: the chunks covering both streams' first NSLOT tiles
+        gen_chunk(g)
+        e(f"s_sub_u32 s{S_NCH}, s{S_NCH}, 1")
+        e(f"s_cmp_lg_u32 s{S_NCH}, 0")
+        e("s_cbranch_scc1 PRE_FILL_%=")
+    for slot in range(NSLOT):  # term rows of tiles 0..NSLOT-1
+        gen_prefetch(g, slot, False)
     e("s_waitcnt vmcnt(0)")
     g.drained()
-    for slot in range(NSLOT - 3):  # tiles 0..NSLOT-4 expanded up front; the loop stays ahead
+    for slot in range(NSLOT - NFLY):  # tiles 0..NSLOT-NFLY-1 expanded up front; the loop stays ahead
         post_expand(g, slot)
     e("s_waitcnt lgkmcnt(0)")
     g.drained()
-    e(f"v_mov_b32_e32 v{V_TMP0}, {NSLOT - 4}")
+    e(f"v_mov_b32_e32 v{V_TMP0}, {NSLOT - NFLY - 1}")
     e(f"ds_write_b32 v{V_FLAG}, v{V_TMP0} offset:8")
     e("PRE_LOOP_%=:")
     for idx in range(NSLOT):
@@ -530,6 +572,11 @@ def main():
         f.write("// One inline-asm block: steady-state loop of lod_chain_kernel, 3 waves in 3 roles (gfx950).\n")
         f.write(f"#define GARLIC_CHAIN_LDS_TOTAL {LDS_TOTAL}\n")
         f.write(f"#define GARLIC_CHAIN_LDS_TILE0 {TILE_BASE}\n")
+        f.write(f"#define GARLIC_CHAIN_NSLOT {NSLOT}\n")
+        f.write(f"#define GARLIC_CHAIN_WROWS {WROWS}\n")
+        # entering-stream word row minus leaving-stream word row the genotype ring can span
+        f.write(f"#define GARLIC_CHAIN_MAX_DW {WROWS - 2 * NSLOT - 3 * CHROWS}\n")
+        f.write(f"#define GARLIC_CHAIN_CHROWS {CHROWS}\n")
         f.write("#define GARLIC_CHAIN_LOOP_ASM \\\n")
         for ln in lines:
             if ln.startswith(";"):

@@ -3,7 +3,7 @@ cp garlic_amd/libgarlic_hip.so /tmp/orig.so
 for f in build/var/*.so; do
   cp $f garlic_amd/libgarlic_hip.so
   for k in ${WORKERS:-256}; do
-  r=$(GARLIC_WORKERS=$k python bench.py --steps 5 --warmup 2 --no-cpu --inds ${INDS:-1000} 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['roofline']['kernel_ms'])")
+  r=$(GARLIC_WORKERS=$k python bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu --inds ${INDS:-1000} 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['roofline']['kernel_ms'])")
   echo "$(basename $f) K=$k $r"
   done
 done
