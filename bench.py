@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--inds", type=int, default=0, help="individuals per GPU (default: workload's)")
-    ap.add_argument("--cpu-inds", type=int, default=96, help="individuals in the CPU-baseline sample")
+    ap.add_argument("--cpu-inds", type=int, default=512, help="individuals in the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
