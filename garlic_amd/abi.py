@@ -174,6 +174,20 @@ class Panel:
         check(lib().garlic_panel_set_gl(self.handle, _vp(gl.ctypes.data), gl.strides[0] // 8, locus_begin,
                                         gl.shape[0], HOST))
 
+    def set_gl_device(self, ptr, ld, locus_begin, locus_count):
+        """ptr: device address of float64 [locus_count][ld] per-genotype error probabilities."""
+        check(lib().garlic_panel_set_gl(self.handle, _vp(ptr), ld, locus_begin, locus_count, DEVICE))
+
+    def set_ld_device(self, winsize, ptr):
+        """ptr: device address of float64 [nloci][winsize] LD weights."""
+        check(lib().garlic_panel_set_ld(self.handle, winsize, _vp(ptr), DEVICE))
+
+    def wlod_windows_device(self, out_ptr, winsize, error, max_gap, M, mu, ind_begin=0, ind_count=None,
+                            pitch_align=32, use_gl=False):
+        ind_count = self.nind - ind_begin if ind_count is None else ind_count
+        check(lib().garlic_wlod_windows(self.handle, winsize, error, max_gap, int(use_gl), M, mu, ind_begin,
+                                        ind_count, pitch_align, _vp(out_ptr), DEVICE))
+
     def set_ld(self, winsize, ld):
         """ld: float64 [nloci][winsize] LD weights of wLOD (all chromosomes concatenated)."""
         ld = np.ascontiguousarray(ld, dtype=np.float64)

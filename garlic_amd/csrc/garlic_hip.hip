@@ -150,6 +150,15 @@ struct garlic_panel {
     bool have_ld = false, wlod_use_gl = false;
     int32_t ld_winsize = 0;
     DevBuf<double> d_rld, d_decay, d_stage64;
+    // tuned wLOD path: skewed reciprocal weights, per-SNP score rows, window mask, tile index
+    DevBuf<double> d_skew, d_wtab;
+    DevBuf<uint8_t> d_valid;
+    DevBuf<int32_t> d_tile_base;
+    std::vector<double> h_tab, h_decay;            // host copies the score rows are built from
+    bool wtab_valid = false;
+    double wtab_error = 0.0, wtab_mu = 0.0;
+    int32_t wtab_M = 0;
+    int64_t wtab_rows = 0;
     bool decay_valid = false;
     int32_t decay_M = 0;
     double decay_mu = 0;
@@ -162,6 +171,8 @@ struct garlic_panel {
         int mode = -1;
         int32_t W = 0, max_gap = 0, ind_begin = 0, ind_count = 0, pitch_align = 0;
         size_t n_items = 0, n_fill = 0;
+        bool wlod_fast = false;
+        int32_t n_tiles = 0;
         int64_t n_runs = 0, n_valid = 0;
     } plan;
 };
@@ -231,6 +242,8 @@ int ensure_term_table(garlic_panel *p, double error)
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     p->tab_valid = true;
     p->tab_error = error;
+    p->h_tab.swap(tab);
+    p->wtab_valid = false;
     return GARLIC_OK;
 }
 
@@ -351,6 +364,34 @@ int ensure_decay_table(garlic_panel *p, int32_t M, double mu)
     p->decay_valid = true;
     p->decay_M = M;
     p->decay_mu = mu;
+    p->h_decay.swap(dec);
+    p->wtab_valid = false;
+    return GARLIC_OK;
+}
+
+// ---- wLOD, tuned path: score of every genotype per SNP, (lod * nomut) * norec in the reference's
+// order (garlic-roh.cpp:249) -- the same three doubles the per-individual expression multiplies
+int ensure_score_rows(garlic_panel *p, double error, int32_t M, double mu, int32_t W)
+{
+    const int64_t rows = GOFF + p->nloci + std::max<int64_t>(GPAD_BACK, W + 64);
+    if (p->wtab_valid && rows <= p->wtab_rows && p->wtab_M == M &&
+        memcmp(&p->wtab_error, &error, sizeof error) == 0 && memcmp(&p->wtab_mu, &mu, sizeof mu) == 0)
+        return GARLIC_OK;
+    std::vector<double> w((size_t)rows * 4, 0.0);
+    const double *t = p->h_tab.data(), *d = p->h_decay.data();
+    const int64_t have = std::min<int64_t>(rows, GOFF + p->nloci + GPAD_BACK);
+    double *wp = w.data();
+    parallel_for(have, 1 << 16, [=](int64_t lo, int64_t hi) {
+        for (int64_t G = lo; G < hi; G++)
+            for (int g = 0; g < 4; g++) wp[G * 4 + g] = (t[G * 4 + g] * d[2 * G]) * d[2 * G + 1];
+    });
+    int rc;
+    if ((rc = p->d_wtab.reserve(w.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(p->d_wtab.p, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice,
+                           p->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    p->wtab_valid = true;
+    p->wtab_error = error; p->wtab_M = M; p->wtab_mu = mu; p->wtab_rows = rows;
     return GARLIC_OK;
 }
 
@@ -380,6 +421,12 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
             return fail(GARLIC_ERR_STATE, "wLOD needs LD weights for winsize %d (garlic_panel_set_ld)", W);
         if ((rc = ensure_decay_table(p, M, mu))) return rc;
     }
+    // tuned wLOD kernel: one LDS score row per SNP (needs the plain --error table) and R = 16
+    // window accumulators per lane; TGLS-weighted and very narrow windows keep the generic kernel
+    const size_t wlod_lds = sizeof(double) * (size_t)(W + TILE) * 4;
+    const bool wlod_fast = mode == MODE_WLOD && !use_gl && W >= WLOD_R && wlod_lds <= 64 * 1024 &&
+                           !getenv("GARLIC_WLOD_GENERIC");
+    if (wlod_fast && (rc = ensure_score_rows(p, error, M, mu, W))) return rc;
 
     Layout L = make_layout(p, pitch_align, ind_count);
     for (int c = 0; c < p->nchr; c++)
@@ -388,7 +435,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
 
     const bool reuse = p->plan.valid && p->plan.mode == (int)mode && p->plan.W == W &&
                        p->plan.max_gap == max_gap && p->plan.ind_begin == ind_begin &&
-                       p->plan.ind_count == ind_count && p->plan.pitch_align == pitch_align;
+                       p->plan.ind_count == ind_count && p->plan.pitch_align == pitch_align &&
+                       p->plan.wlod_fast == wlod_fast;
     const int nblk = (ind_count + WAVE - 1) / WAVE;
     std::vector<Run> runs;
     std::vector<FillItem> fill;
@@ -424,6 +472,20 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         if ((rc = p->d_counter.reserve(1))) return rc;
         p->plan.valid = false;
     }
+    std::vector<uint8_t> valid;
+    std::vector<int32_t> tile_base;
+    if (wlod_fast && !reuse) {
+        valid.assign((size_t)p->nloci, 0);
+        for (const Run &r : runs)
+            memset(valid.data() + p->chr_off[r.chr] + r.a, 1, (size_t)(r.b - r.a + 1));
+        tile_base.resize(p->nchr + 1);
+        tile_base[0] = 0;
+        for (int c = 0; c < p->nchr; c++)
+            tile_base[c + 1] = tile_base[c] + (p->chr_nloci[c] + TILE - 1) / TILE;
+        p->plan.n_tiles = tile_base[p->nchr];
+        if ((rc = p->d_valid.reserve(valid.size()))) return rc;
+        if ((rc = p->d_tile_base.reserve(tile_base.size()))) return rc;
+    }
     // Persistent workgroups (3 waves each: CHAIN, POST, PRE), one per CU; items are pulled longest
     // first, so the short runs pack behind the long ones instead of competing with them for HBM
     // bandwidth.
@@ -448,15 +510,32 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         if (n_fill)
             HIP_TRY(hipMemcpyAsync(p->d_fill.p, fill.data(), sizeof(FillItem) * n_fill,
                                    hipMemcpyHostToDevice, ctx->stream));
+        if (wlod_fast) {
+            HIP_TRY(hipMemcpyAsync(p->d_valid.p, valid.data(), valid.size(), hipMemcpyHostToDevice,
+                                   ctx->stream));
+            HIP_TRY(hipMemcpyAsync(p->d_tile_base.p, tile_base.data(), sizeof(int32_t) * tile_base.size(),
+                                   hipMemcpyHostToDevice, ctx->stream));
+        }
     }
-    if (n_fill) {
+    if (n_fill && !wlod_fast) {   // the tuned wLOD kernel writes MISSING itself
         dim3 grid((unsigned)n_fill, (unsigned)((ind_count + FILL_ROWS - 1) / FILL_ROWS));
         hipLaunchKernelGGL(fill_missing_kernel, grid, dim3(256), 0, ctx->stream, p->d_fill.p,
                            p->d_chrs.p, ind_count, d_out);
     }
     if (n_items) HIP_TRY(hipMemsetAsync(p->d_counter.p, 0, sizeof(int32_t), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev_k0, ctx->stream));
-    if (n_items && mode == MODE_LOD) {
+    if (wlod_fast) {
+        WlodArgs a{p->d_valid.p, p->d_chrs.p, p->d_tile_base.p, p->nwordrows, p->nchr, ind_begin, ind_count, W, nblk};
+        const uint32_t *a_packed = p->d_packed.p;
+        const double *a_wtab = p->d_wtab.p, *a_skew = p->d_skew.p;
+        const unsigned wl_grid = (unsigned)((int64_t)p->plan.n_tiles * nblk);
+        if (aligned16)
+            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, true>), dim3(wl_grid), dim3(WAVE), wlod_lds, ctx->stream,
+                               a_packed, a_wtab, a_skew, d_out, a);
+        else
+            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, false>), dim3(wl_grid), dim3(WAVE), wlod_lds, ctx->stream,
+                               a_packed, a_wtab, a_skew, d_out, a);
+    } else if (n_items && mode == MODE_LOD) {
         ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p,     p->d_chrs.p,     d_out, p->nind_pad, p->nwordrows,
                     ind_begin,     ind_count,  W,               (int32_t)n_items, p->d_counter.p};
         if (aligned16)
@@ -499,6 +578,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     p->plan.valid = true;
     p->plan.mode = (int)mode; p->plan.W = W; p->plan.max_gap = max_gap; p->plan.ind_begin = ind_begin;
     p->plan.ind_count = ind_count; p->plan.pitch_align = pitch_align;
+    p->plan.wlod_fast = wlod_fast;
     p->plan.n_items = n_items; p->plan.n_fill = n_fill; p->plan.n_runs = n_runs; p->plan.n_valid = n_valid;
     st.n_valid_windows = n_valid;
     st.n_missing = p->nloci - n_valid;
@@ -644,6 +724,7 @@ int garlic_panel_destroy(garlic_panel *p)
     p->d_blk_offsets.release(); p->d_total.release(); p->d_boundaries.release();
     p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release(); p->d_row_counts.release(); p->d_codes.release(); p->d_tabgl.release();
     p->d_rld.release(); p->d_decay.release(); p->d_stage64.release();
+    p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tile_base.release();
     p->d_out.release();
     delete p;
     return GARLIC_OK;
@@ -795,6 +876,14 @@ int garlic_panel_set_ld(garlic_panel *p, int32_t winsize, const double *ld, int3
         src = p->d_stage64.p;
     }
     hipLaunchKernelGGL(reciprocal_kernel, dim3(2048), dim3(256), 0, s, src, p->d_rld.p, (int64_t)n);
+    // the same reciprocals, skewed: the weights SNP l has in the windows that contain it become
+    // one contiguous row (tuned wLOD kernel); rows past the panel stay 0
+    const size_t nskew = ((size_t)p->nloci + winsize + 64) * winsize;
+    if ((rc = p->d_skew.reserve(nskew))) return rc;
+    HIP_TRY(hipMemsetAsync(p->d_skew.p, 0, sizeof(double) * nskew, s));
+    for (int c = 0; c < p->nchr; c++)
+        hipLaunchKernelGGL(skew_reciprocal_kernel, dim3(1024), dim3(256), 0, s, src, p->d_skew.p,
+                           p->chr_off[c], p->chr_off[c + 1], winsize);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     p->d_stage64.release();

@@ -146,6 +146,151 @@ wlod_kernel(VariantArgs p, int ring)
     }
 }
 
+// ---- wLOD, tuned path (no per-genotype likelihoods, winsize >= R).
+// Every window is an independent ordered sum, so the work is FP64-VALU bound: 2 instructions
+// (v_mul_f64, v_add_f64 -- the product is rounded before the add, garlic-roh.cpp:262-268) per
+// (window, term).  Lane = individual; a wave keeps R window accumulators per lane in registers and
+// walks the SNPs l once: the lane's score sc[l] (one LDS look-up of the per-SNP row
+// wtab[l][genotype] = (lod * nomut) * norec, tabulated on the host with the reference's operation
+// order) feeds the R windows that contain l, each with its own weight.  The weights of one SNP
+// for R consecutive windows are contiguous in the skewed table D[l][j] = 1/LD[l-j][j] and
+// wave-uniform, so they arrive through the scalar cache and cost no vector instruction.
+//
+//   grid.x = 32-window tiles of all chromosomes, grid.y = 64-individual blocks; the tile is
+//   transposed through LDS so that every store covers whole row segments, and windows that hold
+//   no score (mask byte 0) are written as MISSING by the same store: no separate fill pass.
+constexpr int WLOD_R = 16;   // window accumulators per lane (weights of one step: 32 SGPRs)
+
+struct WlodArgs {
+    const uint8_t *valid;      // [nloci] 1 = window holds a score
+    const ChrDev *chrs;
+    const int32_t *tile_base;  // [nchr + 1] first tile of each chromosome
+    int64_t nwordrows;
+    int32_t nchr, ind_begin, ind_count, winsize, nblk;
+};
+
+template <int R>
+__device__ __forceinline__ void wlod_group(const double *rows, const uint32_t *gcol, int64_t maxw,
+                                           int64_t G, const double *__restrict__ Dg, int W,
+                                           double (&acc)[R])
+{
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.0;
+    int64_t wrow = G >> 4;
+    int bit = 2 * (int)(G & 15);
+    uint32_t word = gcol[min(wrow, maxw) * WAVE];
+    uint32_t nextw = gcol[min(wrow + 1, maxw) * WAVE];
+    // score of this lane's individual at SNP s+i; genotype words are fetched one word (16 SNPs) ahead
+    auto score = [&](int i) -> double {
+        const uint32_t g = (word >> bit) & 3u;
+        const double sc = rows[i * 4 + g];
+        bit += 2;
+        if (bit == 32) {
+            bit = 0;
+            word = nextw;
+            wrow++;
+            nextw = gcol[min(wrow + 1, maxw) * WAVE];
+        }
+        return sc;
+    };
+    // SNP s+i is term j = i - r of window r; windows enter one by one ...
+#pragma unroll
+    for (int i = 0; i < R - 1; i++) {
+        const double sc = score(i);
+        const double *Dr = Dg + (int64_t)i * W;
+#pragma unroll
+        for (int r = 0; r <= i; r++) acc[r] += sc * Dr[i - r];
+    }
+    // ... all R windows take every SNP (weights: 2 x s_load_dwordx16; the wave stalls on them, the
+    // other waves of the SIMD -- LDS use is 4 KB per wave -- fill the gap) ...
+    for (int i = R - 1; i < W; i++) {
+        const double sc = score(i);
+        const double *Dr = Dg + (int64_t)i * W + (i - (R - 1));
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] += sc * Dr[(R - 1) - r];
+    }
+    // ... and leave one by one
+#pragma unroll
+    for (int d = 0; d < R - 1; d++) {
+        const double sc = score(W + d);
+        const double *Dr = Dg + (int64_t)(W + d) * W;
+#pragma unroll
+        for (int r = d + 1; r < R; r++) acc[r] += sc * Dr[W + d - r];
+    }
+}
+
+template <int R, bool ALIGNED16>
+__global__ void __launch_bounds__(WAVE)
+wlod_tile_kernel(const uint32_t *__restrict__ packed,
+                 const double *__restrict__ wtab,   // [GOFF + nloci + pad][4]
+                 const double *__restrict__ D,      // [nloci + pad][W], D[l][j] = 1.0 / LD[l - j][j]
+                 double *__restrict__ out, WlodArgs p)
+{   // the read-only tables are separate __restrict__ arguments: only then are the wave-uniform
+    // weight loads provably unclobbered by the score stores and issued as scalar loads
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    const int lane = threadIdx.x, W = p.winsize;
+    double *rows = dyn;                                   // [W + TILE][4]
+    // consecutive workgroups = the 64-individual blocks of one tile: they share its weights in L2
+    const int tile_idx = (int)(blockIdx.x / (unsigned)p.nblk);
+    const int ind0 = (int)(blockIdx.x % (unsigned)p.nblk) * WAVE;
+    int chr = 0;
+    while (chr + 1 < p.nchr && tile_idx >= p.tile_base[chr + 1]) chr++;
+    const ChrDev c = p.chrs[chr];
+    const int s0 = (tile_idx - p.tile_base[chr]) * TILE;
+    const bool row_ok = ind0 + lane < p.ind_count;
+    const int64_t col = (int64_t)p.ind_begin + ind0 + lane;
+    const uint32_t *gcol = packed + packed_index(0, col, p.nwordrows);
+    const int64_t G0 = c.loc_base + GOFF + s0;
+    const bool has = lane < TILE && s0 + lane < c.nloci && p.valid[c.loc_base + s0 + lane] != 0;
+    const uint32_t vm = (uint32_t)__ballot(has);
+    double *out_row = out + c.out_base + (int64_t)(ind0 + lane) * c.out_pitch + s0;
+    if (vm != 0) {
+        const double2 *src = reinterpret_cast<const double2 *>(wtab + G0 * 4);
+        double2 *dst = reinterpret_cast<double2 *>(rows);
+        for (int k = lane; k < (W + TILE - 1) * 2; k += WAVE) dst[k] = src[k];
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int grp = 0; grp < TILE / R; grp++) {
+        double acc[R];
+        const uint32_t gm = (vm >> (grp * R)) & ((1u << R) - 1u);
+        if (gm != 0)
+            wlod_group<R>(rows + grp * R * 4, gcol, p.nwordrows - 1, G0 + grp * R,
+                          D + (c.loc_base + s0 + grp * R) * (int64_t)W, W, acc);
+        // windows without a score are MISSING (garlic-roh.cpp:232); each lane writes its own row,
+        // 32 contiguous bytes per store
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = ((gm >> r) & 1u) ? acc[r] : MISSING_D;
+        const int sg = s0 + grp * R;
+        if (!row_ok) continue;
+#pragma unroll
+        for (int r = 0; r < R; r += 4) {
+            if (ALIGNED16 && sg + r + 3 < c.nloci) {
+                *reinterpret_cast<double2 *>(out_row + grp * R + r) = make_double2(acc[r], acc[r + 1]);
+                *reinterpret_cast<double2 *>(out_row + grp * R + r + 2) = make_double2(acc[r + 2], acc[r + 3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (sg + r + e < c.nloci) out_row[grp * R + r + e] = acc[r + e];
+            }
+        }
+    }
+}
+
+// D[l][j] = 1.0 / LD[l - j][j] for the windows s = l - j of SNP l's own chromosome [lo, hi)
+__global__ void skew_reciprocal_kernel(const double *__restrict__ ld, double *__restrict__ D,
+                                       int64_t lo, int64_t hi, int W)
+{
+    const int64_t n = (hi - lo) * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t l = lo + i / W;
+        const int j = (int)(i % W);
+        const int64_t s = l - j;
+        D[l * W + j] = (s >= lo) ? 1.0 / ld[s * W + j] : 0.0;
+    }
+}
+
 // ---- KDE feed: ordered compaction of every step-th scored window (garlic-data.cpp:2026-2069).
 // One wavefront per (chromosome, individual) row; lanes walk the sampled loci 64 at a time and
 // rank the keepers with a ballot (integer work: exact whatever the order).

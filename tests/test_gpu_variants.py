@@ -101,6 +101,32 @@ def test_wlod_random_multichr_with_gl(gpu_ctx):
                 assert ol.bits_equal(np.ascontiguousarray(out[c]), want), (use_gl, c)
 
 
+@pytest.mark.parametrize("W", [15, 16, 17, 31, 100, 250])
+def test_wlod_tile_kernel_shapes(gpu_ctx, W):
+    """tuned wLOD kernel (W >= 16; 15 takes the generic one): chromosomes shorter than / equal to /
+    just above the window, gaps and centromeres inside tiles, ragged individual counts, unaligned
+    sub-ranges, dense and padded output layouts"""
+    rng = np.random.default_rng(900 + W)
+    mg = 60000
+    sizes = [700, 1, W - 1, W, W + 1, 333, 1029]
+    nind = 150
+    chroms = [ol.random_panel(rng, n, nind, max_gap=mg, gaps=3 if n > 300 else 0) for n in sizes]
+    gpos = [np.cumsum(np.diff(c[2], prepend=0) * 1e-6 * rng.uniform(0.8, 1.2, size=c[2].shape[0])) for c in chroms]
+    lds = [rng.uniform(1.0, max(2.0, W / 4.0), size=(n, W)) for n in sizes]
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms],
+                      gpos=np.concatenate(gpos))
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        panel.set_ld(W, np.concatenate(lds, axis=0))
+        want = [ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, 0.001, mg, 1e-9, 7)
+                for c, (g, f, p, cs, ce) in enumerate(chroms)]
+        for pa, i0, cnt in ((1, 0, nind), (32, 0, nind), (2, 37, 70), (32, 64, 86)):
+            out = panel.wlod_windows(W, 0.001, mg, 7, 1e-9, pitch_align=pa, ind_begin=i0, ind_count=cnt)
+            for c in range(len(sizes)):
+                assert ol.bits_equal(np.ascontiguousarray(out[c]), want[c][i0:i0 + cnt]), (pa, i0, c)
+
+
 def test_kde_feed_flatten_on_device(gpu_ctx):
     """garlic_lod_flatten = convertWinData2DoubleData (garlic-data.cpp:2026): order chr -> ind -> locus,
     every step-th window, MISSING and NaN dropped -- against the golden and the oracle."""
