@@ -153,7 +153,7 @@ struct garlic_panel {
     // tuned wLOD path: skewed reciprocal weights, per-SNP score rows, window mask, tile index
     DevBuf<double> d_skew, d_wtab;
     DevBuf<uint8_t> d_valid;
-    DevBuf<int32_t> d_tile_base;
+    DevBuf<int2> d_tiles;
     std::vector<double> h_tab, h_decay;            // host copies the score rows are built from
     bool wtab_valid = false;
     double wtab_error = 0.0, wtab_mu = 0.0;
@@ -424,7 +424,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // tuned wLOD kernel: one LDS score row per SNP (needs the plain --error table) and R = 16
     // window accumulators per lane; TGLS-weighted and very narrow windows keep the generic kernel
     const size_t wlod_lds = sizeof(double) * (size_t)(W + TILE) * 4;
-    const bool wlod_fast = mode == MODE_WLOD && !use_gl && W >= WLOD_R && wlod_lds <= 64 * 1024 &&
+    const bool wlod_fast = mode == MODE_WLOD && !use_gl && W >= WLOD_R && W + 64 <= GPAD_BACK &&
                            !getenv("GARLIC_WLOD_GENERIC");
     if (wlod_fast && (rc = ensure_score_rows(p, error, M, mu, W))) return rc;
 
@@ -473,18 +473,16 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         p->plan.valid = false;
     }
     std::vector<uint8_t> valid;
-    std::vector<int32_t> tile_base;
+    std::vector<int2> tiles;
     if (wlod_fast && !reuse) {
         valid.assign((size_t)p->nloci, 0);
         for (const Run &r : runs)
             memset(valid.data() + p->chr_off[r.chr] + r.a, 1, (size_t)(r.b - r.a + 1));
-        tile_base.resize(p->nchr + 1);
-        tile_base[0] = 0;
         for (int c = 0; c < p->nchr; c++)
-            tile_base[c + 1] = tile_base[c] + (p->chr_nloci[c] + TILE - 1) / TILE;
-        p->plan.n_tiles = tile_base[p->nchr];
+            for (int s0 = 0; s0 < p->chr_nloci[c]; s0 += TILE) tiles.push_back(make_int2(c, s0));
+        p->plan.n_tiles = (int32_t)tiles.size();
         if ((rc = p->d_valid.reserve(valid.size()))) return rc;
-        if ((rc = p->d_tile_base.reserve(tile_base.size()))) return rc;
+        if ((rc = p->d_tiles.reserve(tiles.size()))) return rc;
     }
     // Persistent workgroups (3 waves each: CHAIN, POST, PRE), one per CU; items are pulled longest
     // first, so the short runs pack behind the long ones instead of competing with them for HBM
@@ -513,7 +511,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         if (wlod_fast) {
             HIP_TRY(hipMemcpyAsync(p->d_valid.p, valid.data(), valid.size(), hipMemcpyHostToDevice,
                                    ctx->stream));
-            HIP_TRY(hipMemcpyAsync(p->d_tile_base.p, tile_base.data(), sizeof(int32_t) * tile_base.size(),
+            HIP_TRY(hipMemcpyAsync(p->d_tiles.p, tiles.data(), sizeof(int2) * tiles.size(),
                                    hipMemcpyHostToDevice, ctx->stream));
         }
     }
@@ -525,15 +523,17 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     if (n_items) HIP_TRY(hipMemsetAsync(p->d_counter.p, 0, sizeof(int32_t), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev_k0, ctx->stream));
     if (wlod_fast) {
-        WlodArgs a{p->d_valid.p, p->d_chrs.p, p->d_tile_base.p, p->nwordrows, p->nchr, ind_begin, ind_count, W, nblk};
+        const int nquad = (nblk + WLOD_WAVES - 1) / WLOD_WAVES;
+        WlodArgs a{p->d_valid.p, p->d_chrs.p, p->d_tiles.p, p->nwordrows, p->nchr, ind_begin, ind_count, W, nquad,
+                   (uint32_t)((int64_t)p->plan.n_tiles * nquad)};
         const uint32_t *a_packed = p->d_packed.p;
-        const double *a_wtab = p->d_wtab.p, *a_skew = p->d_skew.p;
-        const unsigned wl_grid = (unsigned)((int64_t)p->plan.n_tiles * nblk);
+        const double *a_wtab = p->d_wtab.p, *a_skew = p->d_skew.p + SKEW_FRONT;
+        const unsigned wl_grid = (a.n_work + 7u) / 8u * 8u;
         if (aligned16)
-            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, true>), dim3(wl_grid), dim3(WAVE), wlod_lds, ctx->stream,
+            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, true>), dim3(wl_grid), dim3(WLOD_WAVES * WAVE), wlod_lds, ctx->stream,
                                a_packed, a_wtab, a_skew, d_out, a);
         else
-            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, false>), dim3(wl_grid), dim3(WAVE), wlod_lds, ctx->stream,
+            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, false>), dim3(wl_grid), dim3(WLOD_WAVES * WAVE), wlod_lds, ctx->stream,
                                a_packed, a_wtab, a_skew, d_out, a);
     } else if (n_items && mode == MODE_LOD) {
         ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p,     p->d_chrs.p,     d_out, p->nind_pad, p->nwordrows,
@@ -724,7 +724,7 @@ int garlic_panel_destroy(garlic_panel *p)
     p->d_blk_offsets.release(); p->d_total.release(); p->d_boundaries.release();
     p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release(); p->d_row_counts.release(); p->d_codes.release(); p->d_tabgl.release();
     p->d_rld.release(); p->d_decay.release(); p->d_stage64.release();
-    p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tile_base.release();
+    p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release();
     p->d_out.release();
     delete p;
     return GARLIC_OK;
@@ -878,12 +878,14 @@ int garlic_panel_set_ld(garlic_panel *p, int32_t winsize, const double *ld, int3
     hipLaunchKernelGGL(reciprocal_kernel, dim3(2048), dim3(256), 0, s, src, p->d_rld.p, (int64_t)n);
     // the same reciprocals, skewed: the weights SNP l has in the windows that contain it become
     // one contiguous row (tuned wLOD kernel); rows past the panel stay 0
-    const size_t nskew = ((size_t)p->nloci + winsize + 64) * winsize;
+    // (SKEW_FRONT doubles of zero padding in front: the kernel's first steps read up to 15
+    // elements before a row)
+    const size_t nskew = SKEW_FRONT + ((size_t)p->nloci + winsize + 64) * winsize;
     if ((rc = p->d_skew.reserve(nskew))) return rc;
     HIP_TRY(hipMemsetAsync(p->d_skew.p, 0, sizeof(double) * nskew, s));
     for (int c = 0; c < p->nchr; c++)
-        hipLaunchKernelGGL(skew_reciprocal_kernel, dim3(1024), dim3(256), 0, s, src, p->d_skew.p,
-                           p->chr_off[c], p->chr_off[c + 1], winsize);
+        hipLaunchKernelGGL(skew_reciprocal_kernel, dim3(1024), dim3(256), 0, s, src,
+                           p->d_skew.p + SKEW_FRONT, p->chr_off[c], p->chr_off[c + 1], winsize);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     p->d_stage64.release();

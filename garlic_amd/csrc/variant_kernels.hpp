@@ -13,6 +13,8 @@
 //         IEEE division done once on the device.
 #pragma once
 #include "lod_kernels.hpp"
+#include "wlod_loop_gfx950.inc"
+
 
 namespace garlic {
 
@@ -160,67 +162,51 @@ wlod_kernel(VariantArgs p, int ring)
 //   transposed through LDS so that every store covers whole row segments, and windows that hold
 //   no score (mask byte 0) are written as MISSING by the same store: no separate fill pass.
 constexpr int WLOD_R = 16;   // window accumulators per lane (weights of one step: 32 SGPRs)
+constexpr int WLOD_WAVES = 4;  // waves (64-individual blocks) per workgroup
+constexpr int SKEW_FRONT = 16; // doubles of padding in front of the skewed weight table
 
 struct WlodArgs {
     const uint8_t *valid;      // [nloci] 1 = window holds a score
     const ChrDev *chrs;
-    const int32_t *tile_base;  // [nchr + 1] first tile of each chromosome
+    const int2 *tiles;         // per 32-window tile: {chromosome, first window (chromosome-local)}
     int64_t nwordrows;
-    int32_t nchr, ind_begin, ind_count, winsize, nblk;
+    int32_t nchr, ind_begin, ind_count, winsize, nquad;   // nquad = workgroups per tile
+    uint32_t n_work;           // tiles x nquad
 };
 
+// Ordered sums of windows s .. s+15 for this lane's individual: acc[r] = sum_j sc[s+r+j] * D[s+r+j][j],
+// j ascending from +0.0 (garlic-roh.cpp:255-272).  The whole loop is the hand-scheduled block of
+// wlod_loop_gfx950.inc (tools/gen_wlod_asm.py); this wrapper only prepares its operands.
+//   rows  LDS score rows, row i = SNP s+i         gcol  this lane's genotype column (word row w at gcol[w*64])
+//   G     padded global index of SNP s             Ds    D + (unpadded global index of SNP s) * W
 template <int R>
-__device__ __forceinline__ void wlod_group(const double *rows, const uint32_t *gcol, int64_t maxw,
-                                           int64_t G, const double *__restrict__ Dg, int W,
-                                           double (&acc)[R])
+__device__ __forceinline__ void wlod_group(const double *rows, const uint32_t *gcol, int64_t G,
+                                           const double *Ds, int W, double (&acc)[R])
 {
-#pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = 0.0;
-    int64_t wrow = G >> 4;
-    int bit = 2 * (int)(G & 15);
-    uint32_t word = gcol[min(wrow, maxw) * WAVE];
-    uint32_t nextw = gcol[min(wrow + 1, maxw) * WAVE];
-    // score of this lane's individual at SNP s+i; genotype words are fetched one word (16 SNPs) ahead
-    auto score = [&](int i) -> double {
-        const uint32_t g = (word >> bit) & 3u;
-        const double sc = rows[i * 4 + g];
-        bit += 2;
-        if (bit == 32) {
-            bit = 0;
-            word = nextw;
-            wrow++;
-            nextw = gcol[min(wrow + 1, maxw) * WAVE];
-        }
-        return sc;
-    };
-    // SNP s+i is term j = i - r of window r; windows enter one by one ...
-#pragma unroll
-    for (int i = 0; i < R - 1; i++) {
-        const double sc = score(i);
-        const double *Dr = Dg + (int64_t)i * W;
-#pragma unroll
-        for (int r = 0; r <= i; r++) acc[r] += sc * Dr[i - r];
-    }
-    // ... all R windows take every SNP (weights: 2 x s_load_dwordx16; the wave stalls on them, the
-    // other waves of the SIMD -- LDS use is 4 KB per wave -- fill the gap) ...
-    for (int i = R - 1; i < W; i++) {
-        const double sc = score(i);
-        const double *Dr = Dg + (int64_t)i * W + (i - (R - 1));
-#pragma unroll
-        for (int r = 0; r < R; r++) acc[r] += sc * Dr[(R - 1) - r];
-    }
-    // ... and leave one by one
-#pragma unroll
-    for (int d = 0; d < R - 1; d++) {
-        const double sc = score(W + d);
-        const double *Dr = Dg + (int64_t)(W + d) * W;
-#pragma unroll
-        for (int r = d + 1; r < R; r++) acc[r] += sc * Dr[W + d - r];
-    }
+    static_assert(R == 16, "the hand-scheduled loop keeps 16 weights per step in SGPRs");
+    // genotype words of this lane, one word (16 SNPs) of look-ahead; gaddr = next row to fetch
+    uint64_t gaddr = reinterpret_cast<uint64_t>(gcol + (G >> 4) * WAVE);
+    uint32_t bit = 2 * (uint32_t)(G & 15);
+    double sc, scn, t0, t1;
+    uint32_t vt, word, nextw;
+    uint32_t n = (uint32_t)(W - (R - 1));        // steps in which all 16 windows are active
+    uint32_t row = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) double *)rows);
+    const double *dp = Ds - (R - 1);             // step 0: elements 15-r of {D[s][-15] .. D[s][0]}
+    const uint32_t stride = (uint32_t)(W + 1) * 8u;
+    asm volatile(GARLIC_WLOD_LOOP_ASM
+                 : [a0] "=&v"(acc[0]), [a1] "=&v"(acc[1]), [a2] "=&v"(acc[2]), [a3] "=&v"(acc[3]),
+                   [a4] "=&v"(acc[4]), [a5] "=&v"(acc[5]), [a6] "=&v"(acc[6]), [a7] "=&v"(acc[7]),
+                   [a8] "=&v"(acc[8]), [a9] "=&v"(acc[9]), [a10] "=&v"(acc[10]), [a11] "=&v"(acc[11]),
+                   [a12] "=&v"(acc[12]), [a13] "=&v"(acc[13]), [a14] "=&v"(acc[14]), [a15] "=&v"(acc[15]),
+                   [sc] "=&v"(sc), [scn] "=&v"(scn), [t0] "=&v"(t0), [t1] "=&v"(t1), [vt] "=&v"(vt),
+                   [word] "=&v"(word), [nextw] "=&v"(nextw), [gaddr] "+v"(gaddr), [bit] "+s"(bit),
+                   [row] "+s"(row), [n] "+s"(n)
+                 : [dp] "s"(dp), [stride] "s"(stride), [rowbytes] "s"((uint64_t)(WAVE * 4))
+                 : GARLIC_WLOD_LOOP_CLOBBERS);
 }
 
 template <int R, bool ALIGNED16>
-__global__ void __launch_bounds__(WAVE)
+__global__ void __launch_bounds__(WLOD_WAVES * WAVE) __attribute__((amdgpu_num_vgpr(64)))   // 8 waves per SIMD
 wlod_tile_kernel(const uint32_t *__restrict__ packed,
                  const double *__restrict__ wtab,   // [GOFF + nloci + pad][4]
                  const double *__restrict__ D,      // [nloci + pad][W], D[l][j] = 1.0 / LD[l - j][j]
@@ -228,50 +214,61 @@ wlod_tile_kernel(const uint32_t *__restrict__ packed,
 {   // the read-only tables are separate __restrict__ arguments: only then are the wave-uniform
     // weight loads provably unclobbered by the score stores and issued as scalar loads
     extern __shared__ __attribute__((aligned(16))) double dyn[];
-    const int lane = threadIdx.x, W = p.winsize;
+    // workgroup = WLOD_WAVES waves = that many 64-individual blocks of ONE tile: they share the
+    // staged score rows (LDS per wave stays small enough for 8 waves per SIMD at any W) and
+    // walk the same weights at the same time (scalar-cache hits for all but the first)
+    const int lane = threadIdx.x & (WAVE - 1), W = p.winsize;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *rows = dyn;                                   // [W + TILE][4]
-    // consecutive workgroups = the 64-individual blocks of one tile: they share its weights in L2
-    const int tile_idx = (int)(blockIdx.x / (unsigned)p.nblk);
-    const int ind0 = (int)(blockIdx.x % (unsigned)p.nblk) * WAVE;
-    int chr = 0;
-    while (chr + 1 < p.nchr && tile_idx >= p.tile_base[chr + 1]) chr++;
-    const ChrDev c = p.chrs[chr];
-    const int s0 = (tile_idx - p.tile_base[chr]) * TILE;
-    const bool row_ok = ind0 + lane < p.ind_count;
+    // Workgroups go round-robin over the 8 XCDs (one L2 each): give every XCD one contiguous
+    // range of the work, so that the 64-individual blocks of a tile -- same weights, same score
+    // rows -- meet in one L2.
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned v = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (v >= p.n_work) return;
+    const int tile_idx = (int)(v / (unsigned)p.nquad);
+    const int ind0 = ((int)(v % (unsigned)p.nquad) * WLOD_WAVES + wave) * WAVE;
+    const bool active = ind0 < p.ind_count;      // the last workgroup of a tile may have idle waves
+    const int2 td = p.tiles[tile_idx];
+    const ChrDev c = p.chrs[td.x];
+    const int s0 = td.y;
     const int64_t col = (int64_t)p.ind_begin + ind0 + lane;
     const uint32_t *gcol = packed + packed_index(0, col, p.nwordrows);
     const int64_t G0 = c.loc_base + GOFF + s0;
     const bool has = lane < TILE && s0 + lane < c.nloci && p.valid[c.loc_base + s0 + lane] != 0;
     const uint32_t vm = (uint32_t)__ballot(has);
-    double *out_row = out + c.out_base + (int64_t)(ind0 + lane) * c.out_pitch + s0;
-    if (vm != 0) {
+    if (vm != 0) {   // same for every wave of the workgroup
         const double2 *src = reinterpret_cast<const double2 *>(wtab + G0 * 4);
         double2 *dst = reinterpret_cast<double2 *>(rows);
-        for (int k = lane; k < (W + TILE - 1) * 2; k += WAVE) dst[k] = src[k];
+        for (int k = threadIdx.x; k < (W + TILE - 1) * 2; k += WLOD_WAVES * WAVE) dst[k] = src[k];
         __syncthreads();
     }
+    if (!active) return;
+    // Each lane writes its own row, 16 contiguous bytes per store; the 8 stores of a group land
+    // in the same 128-B line of that row and merge in L2.  (Measured alternatives, none faster:
+    // transposing through LDS to 64-B row pieces, non-temporal stores -- 3x slower, they defeat the
+    // L2 merge --, deferring the stores behind the next group's first loads.)
+    const bool row_ok = ind0 + lane < p.ind_count;
+    double *out_row = out + c.out_base + (int64_t)(ind0 + lane) * c.out_pitch + s0;
 #pragma unroll 1
     for (int grp = 0; grp < TILE / R; grp++) {
         double acc[R];
         const uint32_t gm = (vm >> (grp * R)) & ((1u << R) - 1u);
         if (gm != 0)
-            wlod_group<R>(rows + grp * R * 4, gcol, p.nwordrows - 1, G0 + grp * R,
+            wlod_group<R>(rows + grp * R * 4, gcol, G0 + grp * R,
                           D + (c.loc_base + s0 + grp * R) * (int64_t)W, W, acc);
-        // windows without a score are MISSING (garlic-roh.cpp:232); each lane writes its own row,
-        // 32 contiguous bytes per store
+        // windows without a score are MISSING (garlic-roh.cpp:232)
 #pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = ((gm >> r) & 1u) ? acc[r] : MISSING_D;
-        const int sg = s0 + grp * R;
+        for (int r = 0; r < R; r++) acc[r] = (gm != 0 && ((gm >> r) & 1u)) ? acc[r] : MISSING_D;
         if (!row_ok) continue;
+        const int sg = s0 + grp * R;
 #pragma unroll
-        for (int r = 0; r < R; r += 4) {
-            if (ALIGNED16 && sg + r + 3 < c.nloci) {
+        for (int r = 0; r < R; r += 2) {
+            if (ALIGNED16 && sg + r + 1 < c.nloci) {
                 *reinterpret_cast<double2 *>(out_row + grp * R + r) = make_double2(acc[r], acc[r + 1]);
-                *reinterpret_cast<double2 *>(out_row + grp * R + r + 2) = make_double2(acc[r + 2], acc[r + 3]);
             } else {
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (sg + r + e < c.nloci) out_row[grp * R + r + e] = acc[r + e];
+                if (sg + r < c.nloci) out_row[grp * R + r] = acc[r];
+                if (sg + r + 1 < c.nloci) out_row[grp * R + r + 1] = acc[r + 1];
             }
         }
     }

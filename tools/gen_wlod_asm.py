@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Generates garlic_amd/csrc/wlod_loop_gfx950.inc: the whole ordered-sum loop of the tuned wLOD
+kernel (wlod_group in variant_kernels.hpp) -- 16 consecutive windows x 64 individuals per wave --
+as one inline-asm block for gfx950.
+
+Why by hand: the loop is FP64-VALU bound (per SNP and wave 16 x {v_mul_f64, v_add_f64}: the product
+is rounded, then added, garlic-roh.cpp:262-268), but its 16 weights per SNP come through the scalar
+cache, and hipcc waits for a scalar load right where it issues it: every SNP step then costs one or
+two L2 round trips per wave (measured: 0.42 of the arithmetic rate at 8 waves per SIMD, 0.20 at
+W = 400); asked to prefetch in source, it spills SGPRs lane by lane or falls back to vector loads.
+Here the weights (2 x s_load_dwordx16) and the score look-up (ds_read_b64) of step i+1 are issued
+BEFORE the arithmetic of step i and waited for after it; scalar loads return out of order, so the
+wait is lgkmcnt(0).  Ping-pong SGPR tuples / score registers by step parity, no moves.
+
+Step i (SNP s+i, i = 0 .. W+14) serves window r (start s+r) iff 0 <= i-r < W, with weight
+D[s+i][i-r] = element 15-r of the 16 contiguous doubles at  Dp_i = D + (s+i)*W + i - 15:
+    i < 15        windows 0..i      (unrolled; elements of absent windows are the previous row's
+                                     tail: loaded, never used)
+    15 <= i < W   all 16 windows    (loop, two steps per iteration)
+    i >= W        windows i-W+1..15 (unrolled, in two copies: the parity of W decides which tuple
+                                     the first of them finds its weights in)
+Per step, besides the arithmetic:
+    Dp += (W + 1) * 8;  N <- s_load x2 (Dp)                       next step's weights
+    t = (bfe(word, bit, 2) << 3) + row;  scN <- ds_read_b64(t)   next step's score
+    row += 32; bit += 2; if bit == 32: word = nextw, nextw = *gaddr, gaddr += 256, bit = 0
+    s_waitcnt lgkmcnt(0)
+Vector registers and the loop's scalar state are asm operands (the compiler allocates them); the
+two weight tuples A = s[36:67], B = s[68:99] and the weight pointer s[34:35] are fixed SGPRs
+declared as clobbers (inline asm cannot name a sub-register of a 512-bit operand).
+"""
+import os
+
+R = 16
+BASE = {"A": 36, "B": 68}
+S_DP = 34
+
+
+def weight(t, r):
+    """SGPR pair of window r's weight: element 15 - r of the 16 contiguous doubles of tuple t"""
+    lo = BASE[t] + 2 * (15 - r)
+    return f"s[{lo}:{lo + 1}]"
+
+
+def tup(t, half):
+    lo = BASE[t] + 16 * half
+    return f"s[{lo}:{lo + 15}]"
+
+
+def regs_of(parity):
+    """(current tuple, next tuple, current score, next score) of a step with this index parity"""
+    return ("A", "B", "sc", "scn") if parity == 0 else ("B", "A", "scn", "sc")
+
+
+class Gen:
+    def __init__(self):
+        self.out = []
+        self.uid = 0
+
+    def e(self, s):
+        self.out.append(s)
+
+    def switch_wait(self):
+        """before nextw (requested 16 steps earlier) is consumed at a word switch"""
+        self.e("s_waitcnt vmcnt(0)")
+
+    def step(self, parity, windows, prefetch=True):
+        cur, nxt, sc, scn = regs_of(parity)
+        e = self.e
+        self.uid += 1
+        uid = self.uid
+        if prefetch:
+            e(f"s_add_u32 s{S_DP}, s{S_DP}, %[stride]")
+            e(f"s_addc_u32 s{S_DP + 1}, s{S_DP + 1}, 0")
+            e(f"s_load_dwordx16 {tup(nxt, 0)}, s[{S_DP}:{S_DP + 1}], 0x0")
+            e(f"s_load_dwordx16 {tup(nxt, 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
+            e("v_bfe_u32 %[vt], %[word], %[bit], 2")
+            e("v_lshl_add_u32 %[vt], %[vt], 3, %[row]")
+            e(f"ds_read_b64 %[{scn}], %[vt]")
+            e("s_add_u32 %[row], %[row], 32")
+            e("s_add_u32 %[bit], %[bit], 2")
+            e("s_cmp_eq_u32 %[bit], 32")
+            e(f"s_cbranch_scc0 WL_SAMEWORD_{uid}_%=")
+            e("s_mov_b32 %[bit], 0")
+            self.switch_wait()
+            e("v_mov_b32_e32 %[word], %[nextw]")
+            e("global_load_dword %[nextw], %[gaddr], off")
+            e("v_lshl_add_u64 %[gaddr], %[gaddr], 0, %[rowbytes]")
+            e(f"WL_SAMEWORD_{uid}_%=:")
+        ws = list(windows)
+        for k in range(0, len(ws), 2):     # two products in flight: no back-to-back dependency
+            pair = ws[k:k + 2]
+            for t, r in zip(("t0", "t1"), pair):
+                e(f"v_mul_f64 %[{t}], %[{sc}], {weight(cur, r)}")
+            for t, r in zip(("t0", "t1"), pair):
+                e(f"v_add_f64 %[a{r}], %[a{r}], %[{t}]")
+        if prefetch:
+            e("s_waitcnt lgkmcnt(0)")
+
+
+def main():
+    g = Gen()
+    e = g.e
+    # ---- pipeline fill: weights and score of step 0
+    # (the lane's first two genotype words are requested here too, so that their latency overlaps
+    # with the first weights')
+    e("global_load_dword %[word], %[gaddr], off")
+    e("global_load_dword %[nextw], %[gaddr], off offset:256")
+    e(f"s_mov_b64 s[{S_DP}:{S_DP + 1}], %[dp]")
+    e(f"s_load_dwordx16 {tup('A', 0)}, s[{S_DP}:{S_DP + 1}], 0x0")
+    e(f"s_load_dwordx16 {tup('A', 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
+    e("v_lshl_add_u64 %[gaddr], %[gaddr], 0, %[rowbytes]")
+    e("v_lshl_add_u64 %[gaddr], %[gaddr], 0, %[rowbytes]")
+    e("s_waitcnt vmcnt(0)")
+    e("v_bfe_u32 %[vt], %[word], %[bit], 2")
+    e("v_lshl_add_u32 %[vt], %[vt], 3, %[row]")
+    e("ds_read_b64 %[sc], %[vt]")
+    e("s_add_u32 %[row], %[row], 32")
+    e("s_add_u32 %[bit], %[bit], 2")
+    e("s_cmp_eq_u32 %[bit], 32")
+    e("s_cbranch_scc0 WL_SAMEWORD_0_%=")
+    e("s_mov_b32 %[bit], 0")
+    g.switch_wait()
+    e("v_mov_b32_e32 %[word], %[nextw]")
+    e("global_load_dword %[nextw], %[gaddr], off")
+    e("v_lshl_add_u64 %[gaddr], %[gaddr], 0, %[rowbytes]")
+    e("WL_SAMEWORD_0_%=:")
+    for r in range(R):
+        e(f"v_mov_b64_e32 %[a{r}], 0")
+    e("s_waitcnt lgkmcnt(0)")
+    # ---- windows enter one by one: steps 0..14
+    for i in range(R - 1):
+        g.step(i % 2, range(0, i + 1))
+    # ---- steps 15 .. W-1: all windows (n = W - 15 >= 1 of them); step 15 is odd
+    e("WL_LOOP_%=:")
+    g.step(1, range(R))
+    e("s_sub_u32 %[n], %[n], 1")
+    e("s_cmp_eq_u32 %[n], 0")
+    e("s_cbranch_scc1 WL_TAIL_EVEN_%=")          # next step index is even
+    g.step(0, range(R))
+    e("s_sub_u32 %[n], %[n], 1")
+    e("s_cmp_lg_u32 %[n], 0")
+    e("s_cbranch_scc1 WL_LOOP_%=")
+    # ---- windows leave one by one: steps W .. W+14, first step odd (fall through) or even
+    for first, label in ((1, None), (0, "WL_TAIL_EVEN_%=")):
+        if label:
+            e(label + ":")
+        for d in range(R - 1):
+            g.step((first + d) % 2, range(d + 1, R), prefetch=(d < R - 2))
+        if first == 1:
+            e("s_branch WL_DONE_%=")
+    e("WL_DONE_%=:")
+    # the look-ahead genotype word requested at the last switch is never consumed: let it land
+    # before the compiler reuses its register (everything older retired long ago)
+    e("s_waitcnt vmcnt(0)")
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "..", "garlic_amd", "csrc", "wlod_loop_gfx950.inc")
+    with open(path, "w") as f:
+        f.write("// GENERATED by tools/gen_wlod_asm.py -- do not edit; see that file for the schedule.\n")
+        f.write("// wlod_group<16>: the ordered sums of 16 consecutive windows x 64 individuals, one SNP\n")
+        f.write("// per step, the next step's weights and score requested before this step's FP64 work.\n")
+        f.write("#define GARLIC_WLOD_LOOP_ASM \\\n")
+        for ln in g.out:
+            f.write('    "%s\\n\\t" \\\n' % ln)
+        f.write('    ""\n')
+        regs = ['"s%d"' % r for r in range(S_DP, 100)] + ['"scc"', '"vcc"']
+        f.write("#define GARLIC_WLOD_LOOP_CLOBBERS \\\n    ")
+        f.write(", \\\n    ".join(", ".join(regs[i:i + 12]) for i in range(0, len(regs), 12)) + "\n")
+    n = sum(1 for x in g.out if not x.endswith(":"))
+    print(f"wrote {os.path.normpath(path)}: {n} instructions")
+
+
+if __name__ == "__main__":
+    main()
