@@ -549,8 +549,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                       p->d_items.p,  p->d_chrs.p, d_out,        p->nind_pad,  p->nwordrows, ind_begin,    ind_count,
                       W,             (int32_t)p->gl_values.size(), use_gl ? 1 : 0};
         if (mode == MODE_LOD_GL) {
-            hipLaunchKernelGGL(lod_chain_gl_kernel, dim3((unsigned)n_items), dim3(WAVE), 0,
-                               ctx->stream, a);
+            hipLaunchKernelGGL(lod_chain_gl_kernel, dim3((unsigned)((n_items + GL_WAVES - 1) / GL_WAVES)),
+                               dim3(GL_WAVES * WAVE), 0, ctx->stream, a, (int)n_items);
         } else {
             const int ring = W + TILE;
             const size_t lds = sizeof(double) * ((size_t)ring * WAVE + ((W + 1) & ~1) + (size_t)WAVE * TPITCH);

@@ -62,36 +62,65 @@ __device__ __forceinline__ void variant_store(const double *tile, int s0, int a,
 }
 
 // ---- TGLS: rolling sum with per-genotype error (garlic-roh.cpp:91-95)
-__global__ void __launch_bounds__(WAVE)
-lod_chain_gl_kernel(VariantArgs p)
+// One wave per work item (run x 64 individuals).  Measured: grouping the 64-individual blocks of a
+// run into one workgroup (shared L1 for the ncodes x 32 B term rows) was 15 % slower -- the kernel
+// is bound by the three dependent memory rounds per tile at one wave per SIMD, not by L2 traffic.
+constexpr int GL_WAVES = 1;
+__global__ void __launch_bounds__(GL_WAVES * WAVE)
+lod_chain_gl_kernel(VariantArgs p, int n_items)
 {
-    __shared__ double tile[WAVE * TPITCH];
-    const ChainItem it = p.items[blockIdx.x];
+    __shared__ double tiles[GL_WAVES][WAVE * TPITCH];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blockIdx.x * GL_WAVES + wave;
+    if (item >= n_items) return;
+    double *tile = tiles[wave];
+    const ChainItem it = p.items[item];
     if (it.chr < 0) return;
     const ChrDev c = p.chrs[it.chr];
-    const int lane = threadIdx.x, W = p.winsize, a = it.a, b = it.b;
+    const int lane = threadIdx.x & (WAVE - 1), W = p.winsize, a = it.a, b = it.b;
     const int rows_valid = min(WAVE, p.ind_count - it.ind0);
     const int64_t col = (int64_t)p.ind_begin + it.ind0 + lane;
     const int64_t Gbase = c.loc_base + GOFF;
     double acc = 0.0;
     for (int l = a; l < a + W - 1; l++) acc += variant_term(p, Gbase + l, col); // first window, W-1 terms
     double *out_row0 = p.out + c.out_base + (int64_t)it.ind0 * c.out_pitch;
+    // Per 32-window tile the 64 terms (32 entering, 32 leaving) are fetched in three rounds of
+    // independent loads -- genotype words + dictionary codes, then the term gathers -- so a tile
+    // costs three memory round trips instead of 64 x 2; pad rows keep every address in bounds,
+    // masks are applied to the loaded values.
     for (int s0 = a & ~(TILE - 1); s0 <= b; s0 += TILE) {
+        const int64_t Gin = Gbase + s0 + W - 1, Gout = Gbase + s0 - 1;
+        uint32_t idx_in[TILE], idx_out[TILE];
+#pragma unroll
+        for (int j = 0; j < TILE; j++) {
+            const uint32_t wi = p.packed[packed_index((Gin + j) >> 4, col, p.nwordrows)];
+            const uint32_t wo = p.packed[packed_index((Gout + j) >> 4, col, p.nwordrows)];
+            const uint32_t ci = p.codes[(Gin + j) * p.nind_pad + col];
+            const uint32_t co = p.codes[(Gout + j) * p.nind_pad + col];
+            idx_in[j] = ci * 4 + ((wi >> (2 * (int)((Gin + j) & 15))) & 3u);
+            idx_out[j] = co * 4 + ((wo >> (2 * (int)((Gout + j) & 15))) & 3u);
+        }
         double t_in[TILE], t_out[TILE];
+#pragma unroll
+        for (int j = 0; j < TILE; j++) {
+            t_in[j] = p.tabgl[(Gin + j) * p.ncodes * 4 + idx_in[j]];
+            t_out[j] = p.tabgl[(Gout + j) * p.ncodes * 4 + idx_out[j]];
+        }
 #pragma unroll
         for (int j = 0; j < TILE; j++) {
             const int s = s0 + j;
             const bool in = (s >= a && s <= b);
-            t_in[j] = in ? variant_term(p, Gbase + s + W - 1, col) : 0.0;
-            t_out[j] = (in && s > a) ? variant_term(p, Gbase + s - 1, col) : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < TILE; j++) {
-            acc = (acc - t_out[j]) + t_in[j];
+            const double ti = in ? t_in[j] : 0.0;
+            const double to = (in && s > a) ? t_out[j] : 0.0;
+            acc = (acc - to) + ti;
             tile[lane * TPITCH + j] = acc;
         }
-        __syncthreads(); // one wave per block: orders the LDS writes above before the reads below
+        // the tile is this wave's own: order its LDS writes before the transposed reads
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         variant_store(tile, s0, a, b, lane, rows_valid, out_row0 + s0, c.out_pitch);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
