@@ -24,6 +24,7 @@ SYMBOLS = [
     "garlic_panel_set_freq", "garlic_panel_set_genotypes", "garlic_panel_set_gl",
     "garlic_panel_set_ld", "garlic_lod_out_layout", "garlic_lod_windows",
     "garlic_wlod_windows", "garlic_lod_flatten", "garlic_last_call_stats",
+    "garlic_panel_compute_ld", "garlic_ld_counts", "garlic_ld_finish",
 ]
 
 
@@ -74,6 +75,9 @@ def lib():
                                       C.c_double, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32]
     L.garlic_lod_flatten.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int64, _i64p]
     L.garlic_last_call_stats.argtypes = [_vp, C.POINTER(CallStats)]
+    L.garlic_panel_compute_ld.argtypes = [_vp, C.c_int32, _i32p, C.c_int32, _vp, C.c_int32]
+    L.garlic_ld_counts.argtypes = [_vp, C.c_int32, _i32p, C.c_int32, _vp, _vp, C.c_int32]
+    L.garlic_ld_finish.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, C.c_int32]
     for name in SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int and name not in ("garlic_hip_abi_version",):
@@ -193,6 +197,50 @@ class Panel:
         ld = np.ascontiguousarray(ld, dtype=np.float64)
         assert ld.shape == (self.nloci, winsize)
         check(lib().garlic_panel_set_ld(self.handle, winsize, _vp(ld.ctypes.data), HOST))
+
+    @staticmethod
+    def _sub(sub_idx):
+        if sub_idx is None:
+            return None, 0
+        sub = np.ascontiguousarray(sub_idx, dtype=np.int32)
+        return sub, int(sub.shape[0])
+
+    def compute_ld(self, winsize, sub_idx=None, want_output=True):
+        """calcHR2LD on the device (sub_idx: the --ld-subsample individuals, None = all); installs
+        the weights for wlod_windows and returns them as float64 [nloci][winsize]."""
+        sub, n = self._sub(sub_idx)
+        out = np.empty((self.nloci, winsize), dtype=np.float64) if want_output else None
+        check(lib().garlic_panel_compute_ld(self.handle, winsize, _ptr(sub, _i32p), n,
+                                            _vp(out.ctypes.data) if want_output else None, HOST))
+        return out
+
+    def ld_counts(self, winsize, sub_idx=None):
+        """Integer part of the LD weights for this shard's individuals: (locus_counts [nloci][2],
+        pair_counts [nloci][winsize][2]) int32; sum over shards, then ld_finish."""
+        sub, n = self._sub(sub_idx)
+        loc = np.empty((self.nloci, 2), dtype=np.int32)
+        pair = np.empty((self.nloci, winsize, 2), dtype=np.int32)
+        check(lib().garlic_ld_counts(self.handle, winsize, _ptr(sub, _i32p), n, _vp(loc.ctypes.data),
+                                     _vp(pair.ctypes.data), HOST))
+        return loc, pair
+
+    def ld_finish(self, winsize, locus_counts, pair_counts, want_output=True):
+        loc = np.ascontiguousarray(locus_counts, dtype=np.int32)
+        pair = np.ascontiguousarray(pair_counts, dtype=np.int32)
+        assert loc.shape == (self.nloci, 2) and pair.shape == (self.nloci, winsize, 2)
+        out = np.empty((self.nloci, winsize), dtype=np.float64) if want_output else None
+        check(lib().garlic_ld_finish(self.handle, winsize, _vp(loc.ctypes.data), _vp(pair.ctypes.data),
+                                     _vp(out.ctypes.data) if want_output else None, HOST))
+        return out
+
+    def ld_counts_device(self, winsize, locus_ptr, pair_ptr, sub_idx=None):
+        sub, n = self._sub(sub_idx)
+        check(lib().garlic_ld_counts(self.handle, winsize, _ptr(sub, _i32p), n, _vp(locus_ptr),
+                                     _vp(pair_ptr), DEVICE))
+
+    def ld_finish_device(self, winsize, locus_ptr, pair_ptr, ld_ptr=None):
+        check(lib().garlic_ld_finish(self.handle, winsize, _vp(locus_ptr), _vp(pair_ptr),
+                                     _vp(ld_ptr) if ld_ptr else None, DEVICE))
 
     def out_layout(self, pitch_align=1, nind_out=None):
         nind_out = self.nind if nind_out is None else nind_out

@@ -8,6 +8,7 @@
 #include "../../include/garlic_hip.h"
 #include "lod_kernels.hpp"
 #include "variant_kernels.hpp"
+#include "ld_kernels.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -860,21 +861,13 @@ int garlic_panel_set_gl(garlic_panel *p, const double *gl, int64_t ld, int64_t l
     return GARLIC_OK;
 }
 
-int garlic_panel_set_ld(garlic_panel *p, int32_t winsize, const double *ld, int32_t where)
+// reciprocals of device-resident LD weights, plain and skewed (what the wLOD kernels read)
+static int install_ld(garlic_panel *p, int32_t winsize, const double *src)
 {
-    if (!p || !ld) return fail(GARLIC_ERR_INVALID, "panel and ld are required");
-    if (winsize <= 1) return fail(GARLIC_ERR_INVALID, "winsize must be > 1");
     int rc;
-    if ((rc = set_device(p->ctx))) return rc;
     hipStream_t s = p->ctx->stream;
     const size_t n = (size_t)p->nloci * winsize;
     if ((rc = p->d_rld.reserve(n))) return rc;
-    const double *src = ld;
-    if (where == GARLIC_HOST) {
-        if ((rc = p->d_stage64.reserve(n))) return rc;
-        HIP_TRY(hipMemcpyAsync(p->d_stage64.p, ld, sizeof(double) * n, hipMemcpyHostToDevice, s));
-        src = p->d_stage64.p;
-    }
     hipLaunchKernelGGL(reciprocal_kernel, dim3(2048), dim3(256), 0, s, src, p->d_rld.p, (int64_t)n);
     // the same reciprocals, skewed: the weights SNP l has in the windows that contain it become
     // one contiguous row (tuned wLOD kernel); rows past the panel stay 0
@@ -888,10 +881,164 @@ int garlic_panel_set_ld(garlic_panel *p, int32_t winsize, const double *ld, int3
                            p->d_skew.p + SKEW_FRONT, p->chr_off[c], p->chr_off[c + 1], winsize);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
-    p->d_stage64.release();
     p->have_ld = true;
     p->ld_winsize = winsize;
     return GARLIC_OK;
+}
+
+int garlic_panel_set_ld(garlic_panel *p, int32_t winsize, const double *ld, int32_t where)
+{
+    if (!p || !ld) return fail(GARLIC_ERR_INVALID, "panel and ld are required");
+    if (winsize <= 1) return fail(GARLIC_ERR_INVALID, "winsize must be > 1");
+    int rc;
+    if ((rc = set_device(p->ctx))) return rc;
+    const size_t n = (size_t)p->nloci * winsize;
+    const double *src = ld;
+    if (where == GARLIC_HOST) {
+        if ((rc = p->d_stage64.reserve(n))) return rc;
+        HIP_TRY(hipMemcpyAsync(p->d_stage64.p, ld, sizeof(double) * n, hipMemcpyHostToDevice,
+                               p->ctx->stream));
+        src = p->d_stage64.p;
+    }
+    rc = install_ld(p, winsize, src);
+    p->d_stage64.release();
+    return rc;
+}
+
+// ---- LD weights on the device (ld_kernels.hpp)
+static int ld_check(garlic_panel *p, int32_t winsize)
+{
+    if (!p) return fail(GARLIC_ERR_INVALID, "panel is NULL");
+    if (winsize <= 1) return fail(GARLIC_ERR_INVALID, "winsize must be > 1");
+    if ((int64_t)p->nloci * winsize * 2 >= ((int64_t)1 << 40))
+        return fail(GARLIC_ERR_INVALID, "LD table of %lld x %d too large", (long long)p->nloci, winsize);
+    return set_device(p->ctx);
+}
+
+int garlic_ld_counts(garlic_panel *p, int32_t winsize, const int32_t *sub_idx, int32_t n_sub,
+                     int32_t *locus_counts, int32_t *pair_counts, int32_t where)
+{
+    int rc;
+    if ((rc = ld_check(p, winsize))) return rc;
+    if (!locus_counts || !pair_counts) return fail(GARLIC_ERR_INVALID, "count buffers are required");
+    if (n_sub < 0 || (n_sub > 0 && !sub_idx)) return fail(GARLIC_ERR_INVALID, "bad LD subsample");
+    hipStream_t s = p->ctx->stream;
+    const int nblk = (int)(p->nind_pad / WAVE);
+    // LD subsample as one bit per individual (order and repeats do not matter for counts of a set;
+    // the reference draws distinct indices, garlic-data.cpp:361-362)
+    std::vector<uint64_t> sub((size_t)nblk, 0);
+    if (n_sub == 0) {
+        for (int i = 0; i < p->nind; i++) sub[i >> 6] |= (uint64_t)1 << (i & 63);
+    } else {
+        for (int k = 0; k < n_sub; k++) {
+            const int i = sub_idx[k];
+            if (i < 0 || i >= p->nind)
+                return fail(GARLIC_ERR_INVALID, "LD subsample index %d outside panel of %d", i, p->nind);
+            if (sub[i >> 6] & ((uint64_t)1 << (i & 63)))
+                return fail(GARLIC_ERR_INVALID, "LD subsample index %d given twice", i);
+            sub[i >> 6] |= (uint64_t)1 << (i & 63);
+        }
+    }
+    DevBuf<uint64_t> d_sub, d_m, d_h;
+    DevBuf<int32_t> d_loc, d_pair;
+    auto done = [&](int code) { d_sub.release(); d_m.release(); d_h.release(); d_loc.release(); d_pair.release(); return code; };
+    const size_t npl = (size_t)nblk * p->nloci, npair = (size_t)p->nloci * winsize * 2;
+    if ((rc = d_sub.reserve(nblk)) || (rc = d_m.reserve(npl)) || (rc = d_h.reserve(npl))) return done(rc);
+    int32_t *loc = locus_counts, *pair = pair_counts;
+    if (where == GARLIC_HOST) {
+        if ((rc = d_loc.reserve((size_t)p->nloci * 2)) || (rc = d_pair.reserve(npair))) return done(rc);
+        loc = d_loc.p; pair = d_pair.p;
+    }
+    hipError_t e = hipMemcpyAsync(d_sub.p, sub.data(), sizeof(uint64_t) * nblk, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(pair, 0, sizeof(int32_t) * npair, s);
+    if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
+    hipLaunchKernelGGL(ld_planes_kernel, dim3((unsigned)p->nwordrows), dim3(256), 0, s, p->d_packed.p,
+                       p->nwordrows, nblk, d_sub.p, p->nloci, d_m.p, d_h.p, loc);
+    for (int c = 0; c < p->nchr; c++)
+        hipLaunchKernelGGL(ld_pair_kernel, dim3((unsigned)p->chr_nloci[c]), dim3(256), 0, s, d_m.p, d_h.p,
+                           nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1], winsize, pair);
+    e = hipGetLastError();
+    if (e == hipSuccess && where == GARLIC_HOST) {
+        e = hipMemcpyAsync(locus_counts, loc, sizeof(int32_t) * p->nloci * 2, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(pair_counts, pair, sizeof(int32_t) * npair, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
+    return done(GARLIC_OK);
+}
+
+int garlic_ld_finish(garlic_panel *p, int32_t winsize, const int32_t *locus_counts,
+                     const int32_t *pair_counts, double *ld_out, int32_t where)
+{
+    int rc;
+    if ((rc = ld_check(p, winsize))) return rc;
+    if (!locus_counts || !pair_counts) return fail(GARLIC_ERR_INVALID, "count buffers are required");
+    hipStream_t s = p->ctx->stream;
+    const size_t n = (size_t)p->nloci * winsize;
+    DevBuf<int32_t> d_loc, d_pair;
+    DevBuf<double> d_hf, d_fwd, d_bwd, d_ld;
+    auto done = [&](int code) { d_loc.release(); d_pair.release(); d_hf.release(); d_fwd.release(); d_bwd.release(); d_ld.release(); return code; };
+    const int32_t *loc = locus_counts, *pair = pair_counts;
+    hipError_t e = hipSuccess;
+    if (where == GARLIC_HOST) {
+        if ((rc = d_loc.reserve((size_t)p->nloci * 2)) || (rc = d_pair.reserve(n * 2))) return done(rc);
+        e = hipMemcpyAsync(d_loc.p, locus_counts, sizeof(int32_t) * p->nloci * 2, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(d_pair.p, pair_counts, sizeof(int32_t) * n * 2, hipMemcpyHostToDevice, s);
+        loc = d_loc.p; pair = d_pair.p;
+    }
+    if ((rc = d_hf.reserve(p->nloci)) || (rc = d_fwd.reserve(n)) || (rc = d_bwd.reserve(n))) return done(rc);
+    double *ld = ld_out;
+    if (where == GARLIC_HOST || !ld_out) {
+        if ((rc = d_ld.reserve(n))) return done(rc);
+        ld = d_ld.p;
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(ld, 0, sizeof(double) * n, s);   // initLDData zero-fills
+    if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
+    hipLaunchKernelGGL(ld_homfreq_kernel, dim3((unsigned)((p->nloci + 255) / 256)), dim3(256), 0, s, loc,
+                       p->nloci, d_hf.p);
+    for (int c = 0; c < p->nchr; c++) {
+        const int64_t lo = p->chr_off[c], hi = p->chr_off[c + 1];
+        hipLaunchKernelGGL(ld_hr2_kernel, dim3((unsigned)(hi - lo)), dim3(256), 0, s, pair, d_hf.p, lo, hi,
+                           winsize, d_fwd.p, d_bwd.p);
+        if (hi - lo >= winsize)
+            hipLaunchKernelGGL(ld_sum_kernel, dim3((unsigned)(hi - lo - winsize + 1)), dim3(256), 0, s,
+                               d_fwd.p, d_bwd.p, lo, winsize, ld);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
+    if ((rc = install_ld(p, winsize, ld))) return done(rc);
+    if (where == GARLIC_HOST && ld_out) {
+        e = hipMemcpyAsync(ld_out, ld, sizeof(double) * n, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
+    }
+    return done(GARLIC_OK);
+}
+
+int garlic_panel_compute_ld(garlic_panel *p, int32_t winsize, const int32_t *sub_idx, int32_t n_sub,
+                            double *ld_out, int32_t where)
+{
+    int rc;
+    if ((rc = ld_check(p, winsize))) return rc;
+    DevBuf<int32_t> d_loc, d_pair;
+    auto done = [&](int code) { d_loc.release(); d_pair.release(); return code; };
+    if ((rc = d_loc.reserve((size_t)p->nloci * 2)) || (rc = d_pair.reserve((size_t)p->nloci * winsize * 2)))
+        return done(rc);
+    if ((rc = garlic_ld_counts(p, winsize, sub_idx, n_sub, d_loc.p, d_pair.p, GARLIC_DEVICE))) return done(rc);
+    if (where == GARLIC_DEVICE || !ld_out)
+        return done(garlic_ld_finish(p, winsize, d_loc.p, d_pair.p, ld_out, GARLIC_DEVICE));
+    // host output: finish on the device, then copy out
+    DevBuf<double> d_ld;
+    if ((rc = d_ld.reserve((size_t)p->nloci * winsize))) return done(rc);
+    rc = garlic_ld_finish(p, winsize, d_loc.p, d_pair.p, d_ld.p, GARLIC_DEVICE);
+    if (rc == GARLIC_OK) {
+        hipError_t e = hipMemcpy(ld_out, d_ld.p, sizeof(double) * p->nloci * winsize, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(GARLIC_ERR_HIP, "LD copy-out: %s", hipGetErrorString(e));
+    }
+    d_ld.release();
+    return done(rc);
 }
 
 int garlic_lod_out_layout(garlic_panel *p, int32_t pitch_align, int32_t nind_out, int64_t *chr_base,

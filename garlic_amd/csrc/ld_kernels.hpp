@@ -1,0 +1,151 @@
+// LD weights of wLOD on the device: calcLDData / calcHR2LD / hr2 (src/garlic-data.cpp:330-583),
+// the unphased homozygosity-correlation variant GARLIC uses unless --phased is given.
+//
+//   homFreq[l]  = #(genotype 0 or 2) / #(non-missing) over ALL individuals      (:656-676)
+//   hr2(i, j)   = 0 unless 0 < homFreq < 1 at both SNPs; else with
+//                   total = #(both non-missing), HAB = #(both non-missing and both homozygous)
+//                 over the LD subsample:  HAB /= total;  H = HAB - HA*HB;
+//                 min(1, H*H / (HA*(1-HA)*HB*(1-HB)))                               (:558-583)
+//   LD[s][k]    = sum_{i = s .. s+W-1, in this order, from 0.0}  (i == s+k ? 1 : hr2(i, s+k))
+//                 for s <= nloci_c - W, 0 elsewhere                                  (:474-527)
+//
+// Split so that individuals can be sharded over GPUs: everything that depends on genotypes is an
+// INTEGER count (exact, order-free), summed over shards by the caller (RCCL all-reduce); the
+// floating-point part is replicated and runs in the reference's operation order.
+//
+//   ld_planes_kernel   packed 2-bit genotypes -> per-SNP bit planes over individuals (ballots),
+//                      per-SNP {homozygous, non-missing} counts of the shard
+//   ld_pair_kernel     pair counts {total, HAB} for j - i = 1 .. W-1 (AND + popcount on the planes)
+//   ld_hr2_kernel      counts -> hr2(i, i+d) and hr2(i+d, i)   (the formula is not symmetric in
+//                      floating point: the denominator is multiplied in argument order)
+//   ld_sum_kernel      the ordered window sums
+#pragma once
+#include "lod_kernels.hpp"
+
+namespace garlic {
+
+// One workgroup per genotype word row (16 SNPs); wave w takes the 64-individual blocks w, w+4, ...
+// planes: [blk][nloci] 64-bit masks, bit = individual of the block;  M = non-missing and in the LD
+// subsample, H = M and homozygous.  counts: [nloci][2] = {homozygous, non-missing} over every
+// individual of the shard (homFreq does not use the subsample, garlic-data.cpp:656).
+__global__ void __launch_bounds__(256)
+ld_planes_kernel(const uint32_t *__restrict__ packed, int64_t nwordrows, int nblk,
+                 const uint64_t *__restrict__ submask, int64_t nloci, uint64_t *__restrict__ planeM,
+                 uint64_t *__restrict__ planeH, int32_t *__restrict__ counts)
+{
+    __shared__ int32_t red[4][16][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t w = blockIdx.x;
+    const int64_t l0 = w * 16 - GOFF;           // unpadded global index of the word's first SNP
+    int32_t hom = 0, tot = 0;                    // lane q < 16 owns SNP l0 + q
+    for (int blk = wave; blk < nblk; blk += 4) {
+        const uint32_t word = packed[(blk * nwordrows + w) * WAVE + lane];
+        const uint64_t sub = submask[blk];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const uint32_t code = (word >> (2 * q)) & 3u;
+            const uint64_t m = __ballot(code != 3u);
+            const uint64_t h = __ballot(code == 0u || code == 2u);
+            if (lane == q) {
+                hom += __popcll(h);
+                tot += __popcll(m);
+                const int64_t l = l0 + q;
+                if (l >= 0 && l < nloci) {
+                    planeM[(int64_t)blk * nloci + l] = m & sub;
+                    planeH[(int64_t)blk * nloci + l] = h & sub;
+                }
+            }
+        }
+    }
+    if (lane < 16) { red[wave][lane][0] = hom; red[wave][lane][1] = tot; }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int64_t l = l0 + threadIdx.x;
+        if (l >= 0 && l < nloci) {
+            counts[2 * l + 0] = red[0][threadIdx.x][0] + red[1][threadIdx.x][0] + red[2][threadIdx.x][0] + red[3][threadIdx.x][0];
+            counts[2 * l + 1] = red[0][threadIdx.x][1] + red[1][threadIdx.x][1] + red[2][threadIdx.x][1] + red[3][threadIdx.x][1];
+        }
+    }
+}
+
+// pair[(i * W + d) * 2 + {0,1}] = {total, HAB} of SNPs (i, i+d), d = 1 .. W-1, both inside the
+// chromosome [lo, hi); d = 0 and pairs leaving the chromosome stay 0.  One workgroup per SNP i,
+// threads over d: plane words of i are broadcast, those of i+d consecutive.
+__global__ void __launch_bounds__(256)
+ld_pair_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__ planeH, int nblk,
+               int64_t nloci, int64_t lo, int64_t hi, int W, int32_t *__restrict__ pair)
+{
+    const int64_t i = lo + blockIdx.x;
+    for (int d = 1 + threadIdx.x; d < W; d += blockDim.x) {
+        const int64_t j = i + d;
+        int32_t tot = 0, hab = 0;
+        if (j < hi) {
+            for (int blk = 0; blk < nblk; blk++) {
+                const int64_t base = (int64_t)blk * nloci;
+                tot += __popcll(planeM[base + i] & planeM[base + j]);
+                hab += __popcll(planeH[base + i] & planeH[base + j]);
+            }
+        }
+        pair[(i * W + d) * 2 + 0] = tot;
+        pair[(i * W + d) * 2 + 1] = hab;
+    }
+}
+
+__global__ void ld_homfreq_kernel(const int32_t *__restrict__ counts, int64_t nloci, double *__restrict__ hf)
+{
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nloci) return;
+    double hom = (double)counts[2 * l], total = (double)counts[2 * l + 1];
+    hom /= total;                                   // 0/0 = NaN as on the host: such SNPs give hr2 = 0
+    hf[l] = hom;
+}
+
+// garlic-data.cpp:558-583 with the two counts already taken
+__device__ __forceinline__ double hr2_from_counts(double HA, double HB, int32_t hab, int32_t tot)
+{
+    if (!(HA > 0 && HA < 1 && HB > 0 && HB < 1)) return 0.0;
+    double HAB = (double)hab;
+    const double total = (double)tot;
+    HAB /= total;
+    const double H = HAB - HA * HB;
+    const double v = H * H / (HA * (1 - HA) * HB * (1 - HB));
+    return (v > 1) ? 1.0 : v;
+}
+
+// fwd[i * W + d] = hr2(i, i + d);  bwd[(i + d) * W + d] = hr2(i + d, i)      (d = 1 .. W-1)
+__global__ void __launch_bounds__(256)
+ld_hr2_kernel(const int32_t *__restrict__ pair, const double *__restrict__ hf, int64_t lo, int64_t hi,
+              int W, double *__restrict__ fwd, double *__restrict__ bwd)
+{
+    const int64_t i = lo + blockIdx.x;
+    const double HA = hf[i];
+    for (int d = 1 + threadIdx.x; d < W; d += blockDim.x) {
+        const int64_t j = i + d;
+        if (j >= hi) continue;
+        const int32_t tot = pair[(i * W + d) * 2], hab = pair[(i * W + d) * 2 + 1];
+        const double HB = hf[j];
+        fwd[i * W + d] = hr2_from_counts(HA, HB, hab, tot);
+        bwd[j * W + d] = hr2_from_counts(HB, HA, hab, tot);
+    }
+}
+
+// LD[s][k], one workgroup per window start s (threads over k), s <= hi - W
+__global__ void __launch_bounds__(256)
+ld_sum_kernel(const double *__restrict__ fwd, const double *__restrict__ bwd, int64_t lo, int W,
+              double *__restrict__ ld)
+{
+    const int64_t s = lo + blockIdx.x;
+    for (int k = threadIdx.x; k < W; k += blockDim.x) {
+        const int64_t t = s + k;
+        double acc = 0.0;
+        for (int64_t i = s; i < s + W; i++) {
+            double term = 1.0;                               // i == site: += 1 (garlic-data.cpp:524)
+            if (i < t) term = fwd[i * W + (t - i)];
+            else if (i > t) term = bwd[i * W + (i - t)];
+            acc += term;
+        }
+        ld[s * W + k] = acc;
+    }
+}
+
+} // namespace garlic

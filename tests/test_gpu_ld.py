@@ -1,0 +1,105 @@
+"""GPU parity: LD weights (calcHR2LD) computed on the device vs the CPU oracle, bit for bit, and
+the sharded two-step form (integer counts summed over shards)."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from garlic_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def make_panel(ctx, chroms, nind):
+    panel = abi.Panel(ctx, [c[0].shape[0] for c in chroms], nind)
+    panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms],
+                  gpos=np.concatenate([c[2] for c in chroms]) * 1e-6)
+    panel.set_freq(np.concatenate([c[1] for c in chroms]))
+    panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+    return panel
+
+
+def oracle_ld(chroms, W, sub=None):
+    out = []
+    for g, *_ in chroms:
+        ld = ol.oracle_hr2_ld(g, W, idx=sub)
+        out.append(ld)
+    return np.concatenate(out, axis=0)
+
+
+def same(a, b):
+    """bit-equal; NaNs (a pair no individual of the subsample has both genotypes for: 0/0) must sit at
+    the same places -- their sign bit is the one thing x86 and gfx950 disagree on (0/0 is -nan there,
+    +nan here), and GARLIC only ever tests them with isnan (garlic-data.cpp:2040)"""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    if a.shape != b.shape or not np.array_equal(np.isnan(a), np.isnan(b)):
+        return False
+    ok = ~np.isnan(a)
+    return np.array_equal(a[ok].view(np.uint64), b[ok].view(np.uint64))
+
+
+@pytest.mark.parametrize("W", [2, 7, 30, 100])
+@pytest.mark.parametrize("nind", [40, 64, 150])
+def test_ld_matches_oracle(gpu_ctx, W, nind):
+    rng = np.random.default_rng(17 * W + nind)
+    sizes = [400, 1, max(1, W - 1), W, W + 1, 257]
+    chroms = [ol.random_panel(rng, n, nind, max_gap=10 ** 9, gaps=0, miss=0.05) for n in sizes]
+    # monomorphic and all-heterozygous SNPs (homFreq 1 / 0 -> hr2 = 0), an all-missing SNP (NaN homFreq)
+    g0 = chroms[0][0]
+    g0[5, :] = 2
+    g0[9, :] = 1
+    g0[13, :] = -9
+    with make_panel(gpu_ctx, chroms, nind) as panel:
+        got = panel.compute_ld(W)
+        assert same(got, oracle_ld(chroms, W))
+        sub = np.sort(rng.choice(nind, size=max(2, nind // 3), replace=False)).astype(np.int32)
+        got = panel.compute_ld(W, sub_idx=sub)
+        assert same(got, oracle_ld(chroms, W, sub))
+
+
+def test_ld_feeds_wlod(gpu_ctx):
+    """compute_ld installs the weights: wLOD from them == oracle wLOD from oracle LD"""
+    rng = np.random.default_rng(3)
+    W, nind, mg = 20, 70, 200000
+    chroms = [ol.random_panel(rng, n, nind, max_gap=mg, mono=0.0) for n in (600, 300)]
+    gpos = [c[2] * 1e-6 for c in chroms]
+    with make_panel(gpu_ctx, chroms, nind) as panel:
+        ld = panel.compute_ld(W)
+        out = panel.wlod_windows(W, 0.001, mg, 7, 1e-9, pitch_align=32)
+    off = 0
+    for c, (g, f, p, cs, ce) in enumerate(chroms):
+        ldc = ld[off:off + g.shape[0]]
+        off += g.shape[0]
+        assert same(ldc, ol.oracle_hr2_ld(g, W))
+        want = ol.oracle_calc_wlod(g, f, p, gpos[c], ldc, cs, ce, W, 0.001, mg, 1e-9, 7)
+        assert same(out[c], want)
+
+
+def test_ld_sharded_counts_sum_to_the_whole(gpu_ctx):
+    """two shards of individuals: counts add up, both shards finish to the full-panel LD"""
+    rng = np.random.default_rng(11)
+    W, nind = 25, 130
+    chroms = [ol.random_panel(rng, n, nind, max_gap=10 ** 9, gaps=0, miss=0.03) for n in (300, 180)]
+    sub = np.sort(rng.choice(nind, size=60, replace=False)).astype(np.int32)
+    want = oracle_ld(chroms, W, sub)
+    cut = 70
+    parts = []
+    for lo, hi in ((0, cut), (cut, nind)):
+        shard = [(g[:, lo:hi].copy(), f, p, cs, ce) for g, f, p, cs, ce in chroms]
+        parts.append((make_panel(gpu_ctx, shard, hi - lo), sub[(sub >= lo) & (sub < hi)] - lo))
+    counts = [panel.ld_counts(W, sub_idx=s) for panel, s in parts]
+    loc = counts[0][0] + counts[1][0]
+    pair = counts[0][1] + counts[1][1]
+    for panel, _ in parts:
+        assert same(panel.ld_finish(W, loc, pair), want)
+        panel.close()
+
+
+def test_ld_bad_subsample_is_refused(gpu_ctx):
+    rng = np.random.default_rng(1)
+    chroms = [ol.random_panel(rng, 50, 10, max_gap=10 ** 9, gaps=0)]
+    with make_panel(gpu_ctx, chroms, 10) as panel:
+        for bad in ([0, 10], [-1], [3, 3]):
+            with pytest.raises(abi.GarlicError) as e:
+                panel.compute_ld(5, sub_idx=np.array(bad, dtype=np.int32))
+            assert e.value.code == abi.ERR_INVALID
