@@ -11,7 +11,9 @@
 #include <cstring>
 #include <iostream>
 #include <sstream>
+#include <random>
 #include <thread>
+#include <ctime>
 
 namespace garlic_host {
 
@@ -236,6 +238,41 @@ void releaseLDData(LDData *d)
     for (int l = 0; l < d->nloci; l++) delete[] d->LD[l];
     delete[] d->LD;
     delete d;
+}
+
+void releaseLDData(std::vector<LDData *> *v)
+{
+    if (!v) return;
+    for (auto d : *v) releaseLDData(d);
+    delete v;
+}
+
+std::vector<GenoFreqData *> *calculateGenoFreq(std::vector<HapData *> *haps)
+{   // garlic-data.cpp:648-676
+    std::vector<GenoFreqData *> *out = new std::vector<GenoFreqData *>;
+    for (auto h : *haps) {
+        GenoFreqData *g = new GenoFreqData;
+        g->nloci = h->nloci;
+        g->homFreq = new double[h->nloci];
+        for (int l = 0; l < h->nloci; l++) {
+            double total = 0, hom = 0;
+            for (int i = 0; i < h->nind; i++)
+                if (h->data[l][i] != -9) {
+                    if (h->data[l][i] == 2 || h->data[l][i] == 0) hom++;
+                    total++;
+                }
+            hom /= total;
+            g->homFreq[l] = hom;
+        }
+        out->push_back(g);
+    }
+    return out;
+}
+void releaseGenoFreq(std::vector<GenoFreqData *> *v)
+{
+    if (!v) return;
+    for (auto g : *v) { delete[] g->homFreq; delete g; }
+    delete v;
 }
 
 WinData *initWinData(unsigned int nind, unsigned int nloci)
@@ -512,33 +549,83 @@ int filterMonomorphicSites(std::vector<MapData *> **maps, std::vector<HapData *>
     return total;
 }
 
-int loadAndInterpolateMap(const std::string &mapfile, std::vector<MapData *> *maps)
+// genetic-map scaffold: 4 columns chr snpid gpos ppos, one block per chromosome in file order
+// (garlic-data.cpp:760-844)
+std::vector<GenMapScaffold *> *loadMapScaffold(const std::string &mapfile, centromere *centro)
 {
-    // scaffold: 4 columns chr snpid gpos ppos (garlic-data.cpp:760-844)
-    std::map<std::string, std::vector<std::pair<int, double>>> scaf;
+    std::vector<GenMapScaffold *> *out = new std::vector<GenMapScaffold *>;
     LineReader in(mapfile);
     std::string line, chr, id;
+    int n = 0;
     while (in.next(line)) {
-        if (countFields(line) != 4) fail("map file requires four columns: " + mapfile);
+        n++;
+        if (countFields(line) != 4)
+            fail("line " + std::to_string(n) + " of " + mapfile + " does not have the 4 expected columns");
         std::stringstream ss(line);
-        double g, p;
+        double g;
+        int p;
         ss >> chr >> id >> g >> p;
-        scaf[checkChrName(chr)].push_back({(int)p, g});
+        chr = checkChrName(chr);
+        if (out->empty() || out->back()->chr != chr) {
+            GenMapScaffold *sc = new GenMapScaffold;
+            sc->chr = chr;
+            sc->centroStart = centro->centromereStart(chr);
+            sc->centroEnd = centro->centromereEnd(chr);
+            out->push_back(sc);
+        }
+        out->back()->physicalPos.push_back(p);
+        out->back()->geneticPos.push_back(g);
     }
+    return out;
+}
+void releaseGenMapScaffold(std::vector<GenMapScaffold *> *v)
+{
+    if (!v) return;
+    for (auto s : *v) delete s;
+    delete v;
+}
+
+// --weighted keeps a site iff its frequency is in (0,1), it lies inside the scaffold's span and
+// not strictly inside the centromere (garlic-data.cpp:1066-1098)
+int filterMonomorphicAndOOBSites(std::vector<MapData *> **maps, std::vector<HapData *> **haps,
+                                 std::vector<FreqData *> **freqs, std::vector<GenoLikeData *> **gls,
+                                 std::vector<GenMapScaffold *> *scaffold, bool USE_GL)
+{
+    int total = 0;
+    for (size_t c = 0; c < (*maps)->size(); c++) {
+        const FreqData *f = (*freqs)->at(c);
+        const MapData *m = (*maps)->at(c);
+        const GenMapScaffold *sc = scaffold->at(c);
+        std::vector<char> keep(f->nloci);
+        for (int l = 0; l < f->nloci; l++) {
+            const int q = m->physicalPos[l];
+            keep[l] = (f->freq[l] > 0 && f->freq[l] < 1) && !(q < sc->physicalPos.front()) &&
+                      !(q > sc->physicalPos.back()) && !(q > sc->centroStart && q < sc->centroEnd);
+        }
+        filterSites(c, keep, *maps, *haps, *freqs, USE_GL ? *gls : nullptr);
+        total += (*maps)->at(c)->nloci;
+    }
+    return total;
+}
+
+// exact scaffold positions take the scaffold's value, the others are linearly interpolated between
+// their neighbours with the reference's expression (garlic-data.cpp:718-757)
+int interpolateGeneticmap(std::vector<MapData *> *maps, std::vector<GenMapScaffold *> *scaffold)
+{
     int interpolated = 0;
-    for (auto m : *maps) {
-        auto it = scaf.find(m->chr);
-        if (it == scaf.end()) fail("no genetic map for " + m->chr);
-        const auto &s = it->second;
+    for (size_t c = 0; c < maps->size(); c++) {
+        MapData *m = maps->at(c);
+        const GenMapScaffold *sc = scaffold->at(c);
+        const std::vector<int> &pp = sc->physicalPos;
         size_t k = 0;
         for (int l = 0; l < m->nloci; l++) {
             const int q = m->physicalPos[l];
-            if (q < s.front().first || q > s.back().first)
-                fail("Sites outside of map scaffold must be filtered out before interpolation.");
-            while (k + 1 < s.size() && s[k + 1].first <= q) k++;
-            if (s[k].first == q) { m->geneticPos[l] = s[k].second; continue; } // exact hit (garlic-data.cpp:733-737)
-            const double x0 = s[k].first, y0 = s[k].second, x1 = s[k + 1].first, y1 = s[k + 1].second;
-            m->geneticPos[l] = (((y1 - y0) / (x1 - x0)) * q + (y0 - ((y1 - y0) / (x1 - x0)) * x0)); // :754-757
+            if (q < pp.front() || q > pp.back())
+                fail("Sites outside of map scaffold should have been filtered out.");
+            while (k + 1 < pp.size() && pp[k + 1] <= q) k++;
+            if (pp[k] == q) { m->geneticPos[l] = sc->geneticPos[k]; continue; }
+            const double x0 = pp[k], y0 = sc->geneticPos[k], x1 = pp[k + 1], y1 = sc->geneticPos[k + 1];
+            m->geneticPos[l] = (((y1 - y0) / (x1 - x0)) * q + (y0 - ((y1 - y0) / (x1 - x0)) * x0));
             interpolated++;
         }
     }
@@ -640,7 +727,7 @@ LodEngine::~LodEngine()
 
 std::vector<WinData *> *LodEngine::lodWindows(int winsize, double error, int MAX_GAP)
 {
-    return run(nullptr, winsize, error, MAX_GAP, 0, 0.0);
+    return run(false, winsize, error, MAX_GAP, 0, 0.0);
 }
 
 std::vector<WinData *> *LodEngine::wlodWindows(std::vector<LDData *> *lds, int winsize, double error, int MAX_GAP,
@@ -655,13 +742,60 @@ std::vector<WinData *> *LodEngine::wlodWindows(std::vector<LDData *> *lds, int w
         for (int l = 0; l < lds->at(c)->nloci; l++, o++)
             memcpy(&flat[(size_t)o * winsize], lds->at(c)->LD[l], sizeof(double) * winsize);
     for (auto &s : impl->shards) check(garlic_panel_set_ld(s.panel, winsize, flat.data(), GARLIC_HOST), "garlic_panel_set_ld");
-    return run(lds, winsize, error, MAX_GAP, M, mu);
+    return run(true, winsize, error, MAX_GAP, M, mu);
 }
 
-std::vector<WinData *> *LodEngine::run(std::vector<LDData *> *lds, int winsize, double error, int MAX_GAP, int M,
-                                       double mu)
+std::vector<WinData *> *LodEngine::wlodWindowsResident(int winsize, double error, int MAX_GAP, int M, double mu)
 {
-    const bool weighted = lds != nullptr;
+    return run(true, winsize, error, MAX_GAP, M, mu);
+}
+
+std::vector<LDData *> *LodEngine::ldWeights(int winsize, const std::vector<int> &subsample, bool want_host)
+{
+    std::cerr << "Calculating LD weights with winsize " << winsize << ".\n";
+    int64_t nloci = 0;
+    for (int n : impl->chr_nloci) nloci += n;
+    // every shard counts over its own individuals; the counts are integers, so their sum over
+    // shards is exact whatever the order (with one process per GPU this is an RCCL all-reduce)
+    std::vector<int32_t> loc((size_t)nloci * 2, 0), pair((size_t)nloci * winsize * 2, 0), l1, p1;
+    for (auto &s : impl->shards) {
+        std::vector<int32_t> sub;
+        for (int g : subsample)
+            if (g >= s.ind_begin && g < s.ind_begin + s.nind) sub.push_back(g - s.ind_begin);
+        const bool single = impl->shards.size() == 1;
+        std::vector<int32_t> &lo = single ? loc : l1, &pa = single ? pair : p1;
+        lo.resize(loc.size()); pa.resize(pair.size());
+        if (!subsample.empty() && sub.empty()) {   // none of the subsample lives here: only homFreq counts
+            // (an empty list would mean "all": count everything, then drop the pair counts)
+            check(garlic_ld_counts(s.panel, winsize, nullptr, 0, lo.data(), pa.data(), GARLIC_HOST), "garlic_ld_counts");
+            std::fill(pa.begin(), pa.end(), 0);
+        } else {
+            check(garlic_ld_counts(s.panel, winsize, sub.empty() ? nullptr : sub.data(), (int32_t)sub.size(),
+                                   lo.data(), pa.data(), GARLIC_HOST), "garlic_ld_counts");
+        }
+        if (!single) {
+            for (size_t i = 0; i < loc.size(); i++) loc[i] += lo[i];
+            for (size_t i = 0; i < pair.size(); i++) pair[i] += pa[i];
+        }
+    }
+    std::vector<double> flat;
+    if (want_host) flat.resize((size_t)nloci * winsize);
+    for (size_t k = 0; k < impl->shards.size(); k++)
+        check(garlic_ld_finish(impl->shards[k].panel, winsize, loc.data(), pair.data(),
+                               (want_host && k == 0) ? flat.data() : nullptr, GARLIC_HOST), "garlic_ld_finish");
+    if (!want_host) return nullptr;
+    std::vector<LDData *> *out = new std::vector<LDData *>;
+    int64_t o = 0;
+    for (int n : impl->chr_nloci) {
+        LDData *d = initLDData(n, winsize);
+        for (int l = 0; l < n; l++, o++) memcpy(d->LD[l], &flat[(size_t)o * winsize], sizeof(double) * winsize);
+        out->push_back(d);
+    }
+    return out;
+}
+
+std::vector<WinData *> *LodEngine::run(bool weighted, int winsize, double error, int MAX_GAP, int M, double mu)
+{
     std::cerr << "Calculating LOD scores with winsize " << winsize << ".\n";
     std::vector<WinData *> *win = initWinData(impl->maps, impl->nind);
     const int nchr = (int)impl->chr_nloci.size();
@@ -699,6 +833,31 @@ std::vector<WinData *> *LodEngine::run(std::vector<LDData *> *lds, int winsize, 
     for (auto &e : errors)
         if (!e.empty()) { releaseWinData(win); fail("garlic_lod_windows: " + e); }
     return win;
+}
+
+std::vector<int> drawLdSubsample(int nind, int ldSubsample, unsigned long long seed)
+{
+    std::vector<int> out;
+    if (ldSubsample >= nind || ldSubsample <= 0) return out;   // all (garlic-data.cpp:351-356)
+    // selection sampling: ldSubsample of nind, each subset equally likely, indices ascending --
+    // the contract of gsl_ran_choose; the stream itself cannot match a time-seeded GSL generator
+    std::mt19937_64 rng(seed ? seed : (unsigned long long)time(nullptr));
+    int need = ldSubsample;
+    for (int i = 0; i < nind && need > 0; i++) {
+        const double u = std::generate_canonical<double, 53>(rng);
+        if ((double)(nind - i) * u < (double)need) { out.push_back(i); need--; }
+    }
+    return out;
+}
+
+std::vector<LDData *> *calcLDData(std::vector<HapData *> *haps, std::vector<FreqData *> *freqs,
+                                  std::vector<MapData *> *maps, std::vector<GenoFreqData *> * /*genoFreq*/,
+                                  centromere *centro, int winsize, int /*MAX_GAP*/, bool PHASED,
+                                  int /*numThreads*/, int ldSubsample)
+{
+    if (PHASED) fail("--phased (r2 from haplotype phase) is not available: this engine holds unphased genotypes");
+    LodEngine engine(haps, freqs, maps, nullptr, centro, false, g_options.devices);
+    return engine.ldWeights(winsize, drawLdSubsample(haps->at(0)->nind, ldSubsample, g_options.ld_seed));
 }
 
 std::vector<WinData *> *calcLODWindows(std::vector<HapData *> *haps, std::vector<FreqData *> *freqs,

@@ -50,6 +50,10 @@ struct LDData {            // src/garlic-data.h:103-108
     int nloci;
     int winsize;
 };
+struct GenoFreqData {      // src/garlic-data.h:75-79
+    double *homFreq;       // fraction of homozygous genotypes among the non-missing, per locus
+    int nloci;
+};
 struct WinData {           // src/garlic-data.h:81-87
     double **data;         // [ind][locus], MISSING where no score
     int nind;
@@ -93,6 +97,9 @@ void releaseGLData(GenoLikeData *d);
 void releaseGLData(std::vector<GenoLikeData *> *v);
 LDData *initLDData(int nloci, int winsize);
 void releaseLDData(LDData *d);
+void releaseLDData(std::vector<LDData *> *v);
+std::vector<GenoFreqData *> *calculateGenoFreq(std::vector<HapData *> *hapDataByChr);   // garlic-data.cpp:648
+void releaseGenoFreq(std::vector<GenoFreqData *> *v);
 WinData *initWinData(unsigned int nind, unsigned int nloci);          // throws 0 on empty shapes
 std::vector<WinData *> *initWinData(std::vector<MapData *> *mapDataByChr, int nind);
 void releaseWinData(WinData *d);
@@ -116,12 +123,28 @@ void writeFreqData(const std::string &freqOutfile, std::vector<FreqData *> *freq
 int filterMonomorphicSites(std::vector<MapData *> **mapDataByChr, std::vector<HapData *> **hapDataByChr,
                            std::vector<FreqData *> **freqDataByChr,
                            std::vector<GenoLikeData *> **GLDataByChr, bool USE_GL); // :871
-// genetic map for --weighted: 4 columns chr snpid gpos ppos, linear interpolation (:702-844)
-int loadAndInterpolateMap(const std::string &mapfile, std::vector<MapData *> *mapDataByChr);
+// genetic map for --weighted: scaffold of 4 columns chr snpid gpos ppos (:760-844), out-of-bounds /
+// centromere / monomorphic filter (:916-960, 1066-1098), linear interpolation (:702-757)
+struct GenMapScaffold {
+    std::vector<int> physicalPos;
+    std::vector<double> geneticPos;
+    std::string chr;
+    int centroStart = 0, centroEnd = 0;
+};
+std::vector<GenMapScaffold *> *loadMapScaffold(const std::string &mapfile, centromere *centro);
+void releaseGenMapScaffold(std::vector<GenMapScaffold *> *v);
+int filterMonomorphicAndOOBSites(std::vector<MapData *> **mapDataByChr, std::vector<HapData *> **hapDataByChr,
+                                 std::vector<FreqData *> **freqDataByChr,
+                                 std::vector<GenoLikeData *> **GLDataByChr,
+                                 std::vector<GenMapScaffold *> *scaffoldMapByChr, bool USE_GL);
+int interpolateGeneticmap(std::vector<MapData *> *mapDataByChr, std::vector<GenMapScaffold *> *scaffoldMapByChr);
 
 // ---- the path (drop-in signatures)
 struct LodOptions {
     std::vector<int> devices;   // HIP device ordinals; empty = {0}.  Individuals shard contiguously.
+    // --ld-subsample draw: the reference seeds its generator with time(NULL)
+    // (garlic-data.cpp:346); 0 does the same here, any other value makes the draw repeatable.
+    unsigned long long ld_seed = 0;
 };
 void setLodOptions(const LodOptions &o);
 
@@ -139,6 +162,17 @@ std::vector<WinData *> *calcwLODWindows(std::vector<HapData *> *hapDataByChr,
                                         int winsize, double error, int MAX_GAP, bool USE_GL, int M,
                                         double mu, int numThreads);
 
+// LD weights of wLOD (garlic-data.cpp:330-375).  Same arguments as the reference; the counts come
+// from the device(s), so genoFreqDataByChr is not read (the device recomputes the same fractions
+// from the genotypes) and numThreads is ignored.  PHASED (calcR2LD) is refused: `throw 0`.
+std::vector<LDData *> *calcLDData(std::vector<HapData *> *hapDataByChr, std::vector<FreqData *> *freqDataByChr,
+                                  std::vector<MapData *> *mapDataByChr,
+                                  std::vector<GenoFreqData *> *genoFreqDataByChr, centromere *centro,
+                                  int winsize, int MAX_GAP, bool PHASED, int numThreads, int ldSubsample);
+// the individuals calcLDData would use: all when ldSubsample <= 0 or >= nind, else ldSubsample
+// distinct indices in increasing order (what gsl_ran_choose returns, garlic-data.cpp:361-362)
+std::vector<int> drawLdSubsample(int nind, int ldSubsample, unsigned long long seed);
+
 // A panel kept on the device(s) across window sizes (exploreWinsizes / selectWinsize call the
 // path once per candidate winsize on the same data, garlic-roh.cpp:726-751,798-837,881-920).
 class LodEngine {
@@ -150,12 +184,16 @@ public:
     std::vector<WinData *> *lodWindows(int winsize, double error, int MAX_GAP);
     std::vector<WinData *> *wlodWindows(std::vector<LDData *> *ldDataByChr, int winsize, double error,
                                         int MAX_GAP, int M, double mu);
+    // LD weights for winsize from the resident genotypes (subsample: panel-wide individual indices,
+    // empty = all); they stay installed on the device(s) for wlodWindowsResident.  Returns the
+    // reference-shaped host copy when want_host is set, else NULL.
+    std::vector<LDData *> *ldWeights(int winsize, const std::vector<int> &subsample, bool want_host = true);
+    std::vector<WinData *> *wlodWindowsResident(int winsize, double error, int MAX_GAP, int M, double mu);
     LodEngine(const LodEngine &) = delete;
     LodEngine &operator=(const LodEngine &) = delete;
 
 private:
-    std::vector<WinData *> *run(std::vector<LDData *> *lds, int winsize, double error, int MAX_GAP, int M,
-                                double mu);
+    std::vector<WinData *> *run(bool weighted, int winsize, double error, int MAX_GAP, int M, double mu);
     struct Impl;
     Impl *impl;
 };

@@ -25,8 +25,10 @@ struct Args {
     double error = -1;             // :34 (must be in (0,1) unless TGLS)
     int winsize = 0;               // :38
     std::vector<int> winsize_multi;
-    bool auto_winsize = false, weighted = false, raw_lod = false, kde_thinning = true;
+    bool auto_winsize = false, weighted = false, raw_lod = false, kde_thinning = true, phased = false;
     int auto_winsize_step = 10, max_gap = 200000, M = 7, threads = 1, kde_subsample = 20, gpus = 1;
+    int ld_subsample = 0;          // src/garlic-cli.cpp:137
+    unsigned long long ld_seed = 0; // extension: 0 = time-seeded like the reference
     double mu = 1e-9, overlap_frac = 0.25;
 };
 
@@ -37,7 +39,7 @@ struct Args {
                  "         (--error E | --tgls F --gl-type GQ|GL|PL) (--winsize W | --winsize-multi W1 W2 ...)\n"
                  "         [--auto-winsize] [--auto-winsize-step N] [--max-gap N] [--overlap-frac X]\n"
                  "         [--freq-file F] [--tped-missing C] [--raw-lod] [--kde-subsample N] [--no-kde-thinning]\n"
-                 "         [--weighted --map F --M N --mu X --threads N] [--gpus N]\n";
+                 "         [--weighted --map F --M N --mu X --ld-subsample N --ld-seed S --threads N] [--gpus N]\n";
     exit(1);
 }
 
@@ -70,6 +72,9 @@ Args parse(int argc, char **argv)
         else if (f == "--M") a.M = atoi(val().c_str());
         else if (f == "--mu") a.mu = atof(val().c_str());
         else if (f == "--threads") a.threads = atoi(val().c_str());
+        else if (f == "--ld-subsample") a.ld_subsample = atoi(val().c_str());
+        else if (f == "--ld-seed") a.ld_seed = strtoull(val().c_str(), nullptr, 10);
+        else if (f == "--phased") a.phased = !a.phased;
         else if (f == "--raw-lod") a.raw_lod = !a.raw_lod;
         else if (f == "--kde-subsample") a.kde_subsample = atoi(val().c_str());
         else if (f == "--no-kde-thinning") a.kde_thinning = !a.kde_thinning;
@@ -121,18 +126,37 @@ int main(int argc, char **argv)
         if (USE_GL) gls = readTGLSData(a.tgls, numLoci, numInd, maps, a.gl_type); // rows in pre-filter TPED order
         if (a.freq_file != "none") { releaseFreqData(freqs); freqs = readFreqData(a.freq_file, maps); }
         else writeFreqData(a.out + ".freq", freqs, maps);                        // garlic-main.cpp:245-253
-        if (a.weighted) loadAndInterpolateMap(a.map, maps);
-        const int kept = filterMonomorphicSites(&maps, &haps, &freqs, &gls, USE_GL);
-        std::cerr << "Filtered monomorphic sites: " << kept << " loci kept\n";
+        int kept;
+        if (a.weighted) {   // garlic-main.cpp:233-239, 267-276
+            std::vector<GenMapScaffold *> *scaffold = loadMapScaffold(a.map, &centro);
+            if (scaffold->size() != maps->size()) {
+                std::cerr << "ERROR: Scaffold genetic map does not have the same number of chromosomes as data.\n";
+                return 1;
+            }
+            kept = filterMonomorphicAndOOBSites(&maps, &haps, &freqs, &gls, scaffold, USE_GL);
+            const int ni = interpolateGeneticmap(maps, scaffold);
+            std::cerr << "Number of genetic map locations interpolated: " << ni << "\n";
+            releaseGenMapScaffold(scaffold);
+        } else {
+            kept = filterMonomorphicSites(&maps, &haps, &freqs, &gls, USE_GL);
+        }
+        std::cerr << "Filtered monomorphic" << (a.weighted ? " or out of bounds" : "") << " sites: " << kept << " loci kept\n";
 
         std::vector<int> devices;
         for (int d = 0; d < a.gpus; d++) devices.push_back(d);
-        if (a.weighted) { std::cerr << "ERROR: --weighted (wLOD) is not available in this build\n"; return 1; }
+        if (a.weighted && a.phased) { std::cerr << "ERROR: --phased needs haplotype phase, which this engine does not hold\n"; return 1; }
 
         std::vector<int> sizes = a.winsize_multi.empty() ? std::vector<int>{a.winsize} : a.winsize_multi;
         LodEngine engine(haps, freqs, maps, gls, &centro, USE_GL, devices); // one upload, many window sizes
+        const std::vector<int> ldsub = a.weighted ? drawLdSubsample(numInd, a.ld_subsample, a.ld_seed) : std::vector<int>();
         for (int W : sizes) {
-            std::vector<WinData *> *win = engine.lodWindows(W, a.error, a.max_gap);
+            std::vector<WinData *> *win;
+            if (a.weighted) {   // garlic-main.cpp:346-357: LD weights per window size, then wLOD
+                engine.ldWeights(W, ldsub, false);
+                win = engine.wlodWindowsResident(W, a.error, a.max_gap, a.M, a.mu);
+            } else {
+                win = engine.lodWindows(W, a.error, a.max_gap);
+            }
             if (a.raw_lod) writeWinData(win, ind, maps, sizes.size() == 1 ? a.out : a.out + "." + std::to_string(W) + "SNPs");
             DoubleData *feed = convertWinData2DoubleData(win, a.kde_thinning ? W : 1);
             writeFeed(a.out + "." + std::to_string(W) + "SNPs.lod.f64", feed);

@@ -51,6 +51,26 @@ def test_freq_and_raw_lod_match_reference_binary(tmp_path):
     assert n_same / n_tok > 0.999, (n_same, n_tok)
 
 
+def test_weighted_raw_lod_matches_reference_binary(tmp_path):
+    """--weighted end to end: genetic-map interpolation, LD weights (all individuals), wLOD -- against
+    the raw windows the reference's prebuilt binary wrote for the same command (6 printed digits)."""
+    out = run_tool(tmp_path, "--winsize", "30", "--raw-lod", "--weighted", "--map", os.path.join(E2E, "tiny.map"))
+    n_tok = n_same = 0
+    for ref in sorted(glob.glob(os.path.join(E2E, "refw.POP.*.raw.lod.windows.gz"))):
+        mine = out + os.path.basename(ref)[4:]
+        a, b = read_rows(ref), read_rows(mine)
+        assert len(a) == len(b) == 24
+        for ra, rb in zip(a, b):
+            assert len(ra) == len(rb)
+            assert [x == "NA" for x in ra] == [x == "NA" for x in rb]
+            va = np.array([float(x) for x in ra if x != "NA"])
+            vb = np.array([float(x) for x in rb if x != "NA"])
+            assert np.allclose(va, vb, rtol=2e-5, atol=2e-6)
+            n_tok += len(ra)
+            n_same += sum(x == y for x, y in zip(ra, rb))
+    assert n_tok > 100000 and n_same / n_tok > 0.999, (n_same, n_tok)
+
+
 def test_kde_feed_matches_oracle(tmp_path):
     """<out>.<W>SNPs.lod.f64 = convertWinData2DoubleData of the scores (garlic-data.cpp:2026), bit exact."""
     out = run_tool(tmp_path, "--winsize-multi", "20", "45")

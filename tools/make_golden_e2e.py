@@ -62,8 +62,24 @@ def main():
     shutil.copy(os.path.join(tmp, "ref.freq.gz"), os.path.join(OUT, "ref.freq.gz"))
     for p in glob.glob(os.path.join(tmp, "ref.*.raw.lod.windows.gz")):
         shutil.copy(p, os.path.join(OUT, os.path.basename(p)))
+    # --weighted: genetic map (chr snpid gpos ppos, ~1 cM/Mb with jitter, every 3rd SNP so that the
+    # rest is interpolated), LD weights from all individuals (--ld-subsample 0: no random draw)
+    rng2 = np.random.default_rng(20260106)
+    with open(os.path.join(OUT, "tiny.map"), "w") as f:
+        for line in lines[::3]:
+            t = line.split()[:4]
+            f.write(f"{t[0]} {t[1]} {int(t[3]) * 1e-6 * rng2.uniform(0.9, 1.1):.8f} {t[3]}\n")
+    cmdw = cmd[:-1] + [os.path.join(tmp, "refw"), "--weighted", "--map", os.path.join(OUT, "tiny.map"),
+                       "--threads", "8"]
+    r = subprocess.run(cmdw, capture_output=True, text=True)
+    print(r.stdout[-400:], r.stderr[-800:])
+    for p in glob.glob(os.path.join(tmp, "refw.*.raw.lod.windows.gz")):
+        print(" ", os.path.basename(p), os.path.getsize(p))
+        shutil.copy(p, os.path.join(OUT, os.path.basename(p)))
     with open(os.path.join(OUT, "COMMAND.txt"), "w") as f:
-        f.write("garlic v1.1.6a prebuilt binary:\n" + " ".join(os.path.basename(x) if x.startswith("/") else x for x in cmd) + "\n")
+        f.write("garlic v1.1.6a prebuilt binary:\n")
+        for c in (cmd, cmdw):
+            f.write(" ".join(os.path.basename(x) if x.startswith("/") else x for x in c) + "\n")
     shutil.rmtree(tmp)
 
 
