@@ -40,3 +40,32 @@ def gather_rows(local_rows, nind, group=None):
                 full[b:e] = parts[r][: e - b].numpy()
             out.append(full)
     return out
+
+
+def split_subsample(sub_idx, nind, world, rank):
+    """The part of a panel-wide LD subsample (sorted individual indices, src/garlic-data.cpp:361)
+    that lives in `rank`'s block, as shard-local indices; None (= everyone) stays None."""
+    if sub_idx is None:
+        return None
+    sub = np.asarray(sub_idx, dtype=np.int64)
+    b, e = shard_range(nind, world, rank)
+    return (sub[(sub >= b) & (sub < e)] - b).astype(np.int32)
+
+
+def allreduce_ld_counts(locus_counts, pair_counts, group=None):
+    """The one collective of the weighted path: LD weights count individuals (hr2,
+    src/garlic-data.cpp:558-583), and a shard only sees its own.  Sums the integer count arrays of
+    garlic_ld_counts element-wise over all ranks, in place -- exact in any order, so every rank then
+    finishes (garlic_ld_finish) to bit-identical weights.  Accepts torch tensors (int32; device
+    tensors with the nccl = RCCL backend, host tensors with gloo) or numpy arrays (summed through a
+    host tensor)."""
+    import torch
+    import torch.distributed as dist
+
+    outs = []
+    for a in (locus_counts, pair_counts):
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32))
+        assert t.dtype == torch.int32
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        outs.append(t if isinstance(a, torch.Tensor) else t.numpy())
+    return outs[0], outs[1]

@@ -55,3 +55,76 @@ def test_two_rank_shard_and_gather(tmp_path, nind):
     out = tmp_path / "result.txt"
     mp.spawn(_worker, args=(2, _free_port(), nind, 20, str(out)), nprocs=2, join=True)
     assert out.read_text() == "ok"
+
+
+def _ld_counts_numpy(geno, W, sub):
+    """what garlic_ld_counts returns for a shard: integer counts only"""
+    nloci = geno.shape[0]
+    nm = geno != -9
+    hom = nm & (geno != 1)
+    loc = np.stack([hom.sum(1), nm.sum(1)], axis=1).astype(np.int32)
+    pair = np.zeros((nloci, W, 2), dtype=np.int32)
+    s_nm, s_hom = nm[:, sub], hom[:, sub]
+    for d in range(1, W):
+        pair[:nloci - d, d, 0] = (s_nm[:nloci - d] & s_nm[d:]).sum(1)
+        pair[:nloci - d, d, 1] = (s_hom[:nloci - d] & s_hom[d:]).sum(1)
+    return loc, pair
+
+
+def _ld_finish_numpy(loc, pair, W):
+    """what garlic_ld_finish does with the summed counts (garlic-data.cpp:474-583), scalar FP64"""
+    nloci = loc.shape[0]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        hf = loc[:, 0].astype(np.float64) / loc[:, 1].astype(np.float64)
+
+        def hr2(i, j):
+            HA, HB = hf[i], hf[j]
+            if not (0 < HA < 1 and 0 < HB < 1):
+                return 0.0
+            lo, d = min(i, j), abs(i - j)
+            HAB = np.float64(pair[lo, d, 1]) / np.float64(pair[lo, d, 0])
+            H = HAB - HA * HB
+            v = H * H / (HA * (1 - HA) * HB * (1 - HB))
+            return 1.0 if v > 1 else v
+
+        ld = np.zeros((nloci, W))
+        for s in range(nloci - W + 1):
+            for k in range(W):
+                acc = np.float64(0.0)
+                for i in range(s, s + W):
+                    acc = acc + (1.0 if i == s + k else hr2(i, s + k))
+                ld[s, k] = acc
+    return ld
+
+
+def _ld_worker(rank, world, port, nind, W, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import oracle_lib as ol
+    from garlic_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(7)
+    geno = ol.random_panel(rng, 90, nind, max_gap=10 ** 9, gaps=0, miss=0.05)[0]
+    sub = np.sort(rng.choice(nind, size=nind // 2, replace=False)).astype(np.int32)
+    b, e = shard.shard_range(nind, world, rank)
+    loc, pair = _ld_counts_numpy(geno[:, b:e], W, shard.split_subsample(sub, nind, world, rank))
+    loc, pair = shard.allreduce_ld_counts(loc, pair)            # the path's one collective
+    ld = _ld_finish_numpy(loc, pair, W)
+    ok = ol.bits_equal(ld, ol.oracle_hr2_ld(geno, W, idx=sub))  # every rank holds the full-panel weights
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(ok))
+    if rank == 0:
+        with open(out_path, "w") as fh:
+            fh.write("ok" if all(flags) else "mismatch")
+    dist.destroy_process_group()
+
+
+def test_two_rank_ld_counts_allreduce(tmp_path):
+    """LD weights shard as integer counts + one all-reduce; the replicated floating-point finish then
+    equals the single-process oracle bit for bit on every rank"""
+    out = tmp_path / "ld.txt"
+    mp.spawn(_ld_worker, args=(2, _free_port(), 21, 6, str(out)), nprocs=2, join=True)
+    assert out.read_text() == "ok"

@@ -65,7 +65,18 @@ def main():
         else:
             panel.wlod_windows_device(out.data_ptr(), W, error, max_gap, 7, 1e-9)
 
-    for mode in args.modes.split(","):
+    if "ld" in args.modes.split(","):
+        # LD weights (calcHR2LD) from the resident genotypes, all individuals; wall clock of the call
+        import time
+        panel.compute_ld(W, want_output=False)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            panel.compute_ld(W, want_output=False)
+        dt = (time.perf_counter() - t0) / args.steps
+        print(json.dumps({"mode": "ld", "snps": nloci, "inds": nind, "winsize": W, "call_ms": dt * 1e3,
+                          "loci_per_s": nloci / dt, "pair_counts_per_s": nloci * (W - 1) / dt,
+                          "ld_sums_terms_per_s": nloci * W * W / dt}))
+    for mode in [m for m in args.modes.split(",") if m != "ld"]:
         run(mode)
         ms = []
         for _ in range(args.steps):
