@@ -538,13 +538,31 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                                a_packed, a_wtab, a_skew, d_out, a);
     } else if (n_items && mode == MODE_LOD) {
         ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p,     p->d_chrs.p,     d_out, p->nind_pad, p->nwordrows,
-                    ind_begin,     ind_count,  W,               (int32_t)n_items, p->d_counter.p};
+                    ind_begin,     ind_count,  W,               (int32_t)n_items, p->d_counter.p, nullptr};
+        DevBuf<int64_t> d_trace;   // debugging aid: GARLIC_TRACE=<file> dumps per-item timestamps
+        const char *trace_path = getenv("GARLIC_TRACE");
+        if (trace_path && d_trace.reserve(4 * n_items) == GARLIC_OK) {
+            (void)hipMemsetAsync(d_trace.p, 0, sizeof(int64_t) * 4 * n_items, ctx->stream);
+            a.trace = d_trace.p;
+        }
         if (aligned16)
             hipLaunchKernelGGL(lod_chain_kernel<true>, dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
                                ctx->stream, a);
         else
             hipLaunchKernelGGL(lod_chain_kernel<false>, dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
                                ctx->stream, a);
+        if (a.trace) {
+            std::vector<int64_t> tr(4 * n_items);
+            (void)hipMemcpyAsync(tr.data(), d_trace.p, sizeof(int64_t) * tr.size(), hipMemcpyDeviceToHost, ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
+            if (FILE *f = fopen(trace_path, "w")) {
+                for (size_t i = 0; i < n_items; i++)
+                    fprintf(f, "%zu %lld %lld %lld %lld %d\n", i, (long long)tr[4 * i], (long long)tr[4 * i + 1],
+                            (long long)tr[4 * i + 2], (long long)tr[4 * i + 3], 0);
+                fclose(f);
+            }
+            d_trace.release();
+        }
     } else if (n_items) {
         VariantArgs a{p->d_packed.p, p->d_tab.p,  p->d_tabgl.p, p->d_codes.p, p->d_decay.p, p->d_rld.p,
                       p->d_items.p,  p->d_chrs.p, d_out,        p->nind_pad,  p->nwordrows, ind_begin,    ind_count,

@@ -250,6 +250,7 @@ struct ChainArgs {
     int32_t winsize;
     int32_t n_items;          // work-list length
     int32_t *next_item;       // device counter (zeroed per launch): the persistent waves' queue head
+    int64_t *trace;           // optional (GARLIC_TRACE): per item {worker, t_begin, t_asm, t_end} in 100 MHz ticks
 };
 
 // LDS map (bytes).  One workgroup = 3 waves (CHAIN, POST, PRE roles) working on one item; the hand-scheduled loop
@@ -406,6 +407,10 @@ lod_chain_kernel(ChainArgs p)
         __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(smem + LDS_ITEM));
     __syncthreads();
     if (item_idx >= p.n_items) return;
+    if (p.trace && threadIdx.x == 0) {
+        p.trace[4 * item_idx + 0] = blockIdx.x;
+        p.trace[4 * item_idx + 1] = wall_clock64();
+    }
     const ChainItem it = p.items[item_idx];
     const ChrDev c = p.chrs[it.chr];
     const int W = p.winsize;
@@ -503,6 +508,7 @@ lod_chain_kernel(ChainArgs p)
             const uint32_t *pchunk =
                 p.packed + packed_index(GARLIC_CHAIN_CHROWS * chunk0, col0, p.nwordrows);
             const uint32_t wmask = GARLIC_CHAIN_WROWS - 1;
+            if (p.trace && threadIdx.x == 0) p.trace[4 * item_idx + 2] = wall_clock64();
             // all waves enter together; the block starts by draining each wave's own memory
             // operations, its stage barriers order the LDS hand-offs (TILE buffer 0 above
             // included: the loop first writes it two barriers in)
@@ -526,6 +532,7 @@ lod_chain_kernel(ChainArgs p)
             __syncthreads(); // the tail tile reuses LDS regions the loop's roles were reading
         }
     }
+    if (p.trace && threadIdx.x == 0) p.trace[4 * item_idx + 3] = wall_clock64();
     } // next item
 }
 

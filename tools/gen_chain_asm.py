@@ -79,23 +79,26 @@ TPITCH_B = 34 * 8
 LDS_TOTAL = TILE_BASE + NTILE * TILE_BUF
 
 # ---- fixed VGPRs (clobbered by the block; each wave has its own register file)
-V_BUF = [100, 132]          # CHAIN: two term buffers, 16 x 64-bit each
-V_ADDR = 164                # CHAIN: 16 LDS byte offsets
-V_ACC = 180                 # CHAIN: P0 = [180:181], P1 = [182:183]
-V_LL, V_LH, V_TL, V_TH = 184, 185, 186, 187   # POST: funnel-shifted genotype bits
-V_WL1, V_WL2, V_WT1, V_WT2 = 188, 189, 190, 191
-V_LANE4, V_LANE16, V_VOFFA, V_VOFFB, V_TWR, V_TRD = 192, 193, 194, 195, 196, 197
-V_LANE32 = 192              # CHAIN only (CHAIN has no V_LANE4): lane * 32
-V_LANE32P = 217             # POST: lane * 32
-V_STOFF = 198               # POST: 16 store offsets
-V_ST = 24                   # POST: 64 VGPRs of store data
-V_E = [220, 236]            # CHAIN: two sets of 16 expanded-offset dwords (lead 8, trail 8)
-V_X = 100                   # POST: 16 expanded dwords being built + 4 scratch (POST has no V_BUF)
-V_LC, V_TC = 214, 215
-V_FLAG, V_TMP0, V_TMP1 = 216, 218, 219   # TMP pair 64-bit aligned (ds_read2 dst)
-V_TRD2 = 122                # POST: second tile-read base
-V_LADDR, V_TADDR = 194, 195 # PRE: ring byte offset (+ lane*4) of word +0 of the next tile to expand
-V_A1L, V_A1T = 124, 125     # PRE: ring offsets of word +1
+# Every role is a different wave with its own register file, so the three roles reuse one compact
+# range v64..v185: the kernel's register count decides how many workgroups fit a CU.
+V_BUF = [64, 96]            # CHAIN: two term buffers, 16 x 64-bit each
+V_ADDR = 128                # CHAIN: 16 LDS byte offsets
+V_ACC = 144                 # CHAIN: P0 = [144:145], P1 = [146:147]
+V_E = [148, 164]            # CHAIN: two sets of 16 expanded-offset dwords (lead 8, trail 8)
+V_LANE32 = 180              # CHAIN: EXP_BASE + lane * 32
+V_TWR = 181                 # CHAIN: tile write address
+V_ST = 64                   # POST: 64 VGPRs of store data
+V_STOFF = 128               # POST: 16 store offsets
+V_TRD, V_TRD2 = 144, 145    # POST: tile-read bases
+V_X = 64                    # PRE: 16 expanded dwords being built + 4 scratch
+V_LL, V_LH, V_TL, V_TH = 84, 85, 86, 87   # PRE: funnel-shifted genotype bits
+V_WL1, V_WL2, V_WT1, V_WT2 = 88, 89, 90, 91
+V_LANE4, V_LANE16 = 92, 93
+V_LADDR, V_TADDR = 94, 95   # PRE: ring byte offset (+ lane*4) of word +0 of the next tile to expand
+V_A1L, V_A1T = 96, 97       # PRE: ring offsets of word +1
+V_LANE32P = 98              # PRE: EXP_BASE + lane * 32
+V_LC, V_TC = 99, 100
+V_FLAG, V_TMP0, V_TMP1 = 182, 184, 185   # all roles; TMP pair 64-bit aligned (ds_read2 dst)
 # ---- fixed SGPRs
 S_PCHUNK, S_ROFF, S_NCH, S_PLTAB, S_PTTAB = 40, 42, 43, 44, 46
 S_OUT = 50
@@ -106,7 +109,7 @@ S_K = 56
 S_F0, S_F1 = 57, 58
 S_ROWS = 59                # POST: valid individuals (rows) of this item
 
-CLOBBER_V = sorted(set(list(range(V_ST, V_ST + 64)) + list(range(100, 252))))
+CLOBBER_V = list(range(64, 186))
 CLOBBER_S = list(range(40, 60))
 
 
