@@ -429,6 +429,10 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                            !getenv("GARLIC_WLOD_GENERIC");
     if (wlod_fast && (rc = ensure_score_rows(p, error, M, mu, W))) return rc;
 
+    // Host output: the device always computes into the padded layout the tuned kernels need; the
+    // rows are copied out into the caller's (possibly dense) layout by strided D2H copies.
+    const Layout Lhost = make_layout(p, pitch_align, ind_count);
+    if (where == GARLIC_HOST) pitch_align = std::max(pitch_align, 32);
     Layout L = make_layout(p, pitch_align, ind_count);
     for (int c = 0; c < p->nchr; c++)
         if (3 * L.pitch[c] * 8 + 512 >= (int64_t)1 << 32)
@@ -584,8 +588,10 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     HIP_TRY(hipEventRecord(ctx->ev_k1, ctx->stream));
     HIP_TRY(hipGetLastError());
     if (where == GARLIC_HOST)
-        HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)L.total, hipMemcpyDeviceToHost,
-                               ctx->stream));
+        for (int c = 0; c < p->nchr; c++)
+            HIP_TRY(hipMemcpy2DAsync(out + Lhost.base[c], sizeof(double) * Lhost.pitch[c], d_out + L.base[c],
+                                     sizeof(double) * L.pitch[c], sizeof(double) * p->chr_nloci[c],
+                                     (size_t)ind_count, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev_end, ctx->stream));
     // The work list lives in host vectors and per-panel device scratch: finish before returning.
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -50,6 +50,35 @@ def test_unweighted_parity(gpu_ctx, W, pitch_align):
     assert st["n_valid_windows"] + st["n_missing"] == sum(sizes)
 
 
+@pytest.mark.parametrize("pitch_align", [1, 2, 32])
+@pytest.mark.parametrize("W", [5, 100])
+def test_device_output_layouts(gpu_ctx, W, pitch_align):
+    """device-resident output in the caller's own layout: dense rows (pitch_align 1: the generic
+    kernel path, 8-byte stores), even pitch, 256-byte rows.  Host output always computes in the
+    padded layout and copies rows out, so only this test reaches the dense-layout kernel."""
+    import torch
+    rng = np.random.default_rng(40 + W)
+    sizes = [1500, W, 700]
+    max_gap = 200000
+    data = make_multichr(rng, sizes, 70, max_gap)
+    genos, freqs, poss, css, ces = data
+    with abi.Panel(gpu_ctx, sizes, 70) as panel:
+        panel.set_map(np.concatenate(poss), css, ces)
+        panel.set_freq(np.concatenate(freqs))
+        panel.set_genotypes(np.concatenate(genos, axis=0))
+        base, pitch, total = panel.out_layout(pitch_align, 70)
+        out = torch.full((total + 1,), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        # + 1 element offset for pitch_align 1: not even 16-byte aligned
+        off = 1 if pitch_align == 1 else 0
+        panel.lod_windows_device(out.data_ptr() + 8 * off, W, 0.001, max_gap, pitch_align=pitch_align)
+        host = out.cpu().numpy()[off:]
+    for c, n in enumerate(sizes):
+        got = host[base[c]: base[c] + 70 * pitch[c]].reshape(70, pitch[c])[:, :n]
+        want = ol.oracle_calc_lod(genos[c], freqs[c], poss[c], css[c], ces[c], W, 0.001, max_gap)
+        assert ol.count_mismatch(np.ascontiguousarray(got), want) == 0, (c, pitch_align)
+
+
 @pytest.mark.parametrize("nind", [1, 63, 64, 65, 130, 200])
 def test_individual_counts(gpu_ctx, nind):
     rng = np.random.default_rng(7 + nind)
