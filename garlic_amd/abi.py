@@ -24,7 +24,7 @@ SYMBOLS = [
     "garlic_panel_set_freq", "garlic_panel_set_genotypes", "garlic_panel_set_gl",
     "garlic_panel_set_ld", "garlic_lod_out_layout", "garlic_lod_windows",
     "garlic_wlod_windows", "garlic_lod_flatten", "garlic_last_call_stats",
-    "garlic_panel_compute_ld", "garlic_ld_counts", "garlic_ld_finish",
+    "garlic_panel_compute_ld", "garlic_ld_counts", "garlic_ld_finish", "garlic_roh_coverage",
 ]
 
 
@@ -78,6 +78,8 @@ def lib():
     L.garlic_panel_compute_ld.argtypes = [_vp, C.c_int32, _i32p, C.c_int32, _vp, C.c_int32]
     L.garlic_ld_counts.argtypes = [_vp, C.c_int32, _i32p, C.c_int32, _vp, _vp, C.c_int32]
     L.garlic_ld_finish.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, C.c_int32]
+    L.garlic_roh_coverage.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, _vp, C.c_int32,
+                                      C.c_int32]
     for name in SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int and name not in ("garlic_hip_abi_version",):
@@ -293,6 +295,17 @@ class Panel:
         check(lib().garlic_lod_flatten(self.handle, _vp(scores_ptr), pitch_align, nind_out, step,
                                        _vp(feed_ptr) if feed_ptr else None, feed_capacity, C.byref(n)))
         return n.value
+
+    def roh_coverage(self, scores_ptr, winsize, cutoff, pitch_align=32, nind_out=None):
+        """assembleROHWindows' coverage counts of device-resident scores: list of per-chromosome int16
+        [nind_out][nloci_c] host arrays."""
+        nind_out = self.nind if nind_out is None else nind_out
+        base, pitch, total = self.out_layout(1, nind_out)
+        out = np.empty(total, dtype=np.int16)
+        check(lib().garlic_roh_coverage(self.handle, _vp(scores_ptr), pitch_align, nind_out, winsize, cutoff,
+                                        _vp(out.ctypes.data), 1, HOST))
+        return [out[base[c]: base[c] + nind_out * pitch[c]].reshape(nind_out, pitch[c])
+                for c in range(self.nchr)]
 
     def stats(self):
         st = CallStats()

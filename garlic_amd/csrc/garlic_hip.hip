@@ -1134,6 +1134,55 @@ int garlic_lod_flatten(garlic_panel *p, const double *scores, int32_t pitch_alig
     return GARLIC_OK;
 }
 
+int garlic_roh_coverage(garlic_panel *p, const double *scores, int32_t pitch_align, int32_t nind_out,
+                        int32_t winsize, double cutoff, int16_t *inwin, int32_t inwin_pitch_align,
+                        int32_t where)
+{
+    if (!p || !scores || !inwin) return fail(GARLIC_ERR_INVALID, "panel, scores and inwin are required");
+    if (winsize <= 1 || pitch_align < 1 || inwin_pitch_align < 1 || nind_out < 1)
+        return fail(GARLIC_ERR_INVALID, "winsize must be > 1; pitch_align, inwin_pitch_align and nind_out >= 1");
+    if (winsize > 32767) return fail(GARLIC_ERR_INVALID, "coverage counts are 16-bit: winsize <= 32767");
+    if (nind_out > 65535) return fail(GARLIC_ERR_INVALID, "coverage: at most 65535 individuals per call");
+    int rc;
+    if ((rc = set_device(p->ctx))) return rc;
+    hipStream_t s = p->ctx->stream;
+    const Layout L = make_layout(p, pitch_align, nind_out), Lo = make_layout(p, inwin_pitch_align, nind_out);
+    std::vector<ChrDev> chrs(2 * (size_t)p->nchr);
+    std::vector<int32_t> seg_base(p->nchr + 1, 0);
+    for (int c = 0; c < p->nchr; c++) {
+        chrs[c] = ChrDev{p->chr_off[c], L.base[c], L.pitch[c], p->chr_nloci[c], 0};
+        chrs[p->nchr + c] = ChrDev{p->chr_off[c], Lo.base[c], Lo.pitch[c], p->chr_nloci[c], 0};
+        seg_base[c + 1] = seg_base[c] + (p->chr_nloci[c] + COV_SEG - 1) / COV_SEG;
+    }
+    DevBuf<ChrDev> d_chrs;
+    DevBuf<int32_t> d_seg;
+    DevBuf<int16_t> d_cov;
+    auto done = [&](int code) { d_chrs.release(); d_seg.release(); d_cov.release(); return code; };
+    if ((rc = d_chrs.reserve(chrs.size())) || (rc = d_seg.reserve(seg_base.size()))) return done(rc);
+    int16_t *dst = inwin;
+    if (where == GARLIC_HOST) {
+        if ((rc = d_cov.reserve((size_t)Lo.total))) return done(rc);
+        dst = d_cov.p;
+    }
+    hipError_t e = hipMemcpyAsync(d_chrs.p, chrs.data(), sizeof(ChrDev) * chrs.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(d_seg.p, seg_base.data(), sizeof(int32_t) * seg_base.size(), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+    const size_t lds = sizeof(int32_t) * ((size_t)winsize + COV_SEG + 1);
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(roh_coverage_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+    hipLaunchKernelGGL(roh_coverage_kernel, dim3((unsigned)seg_base[p->nchr], (unsigned)nind_out),
+                       dim3(COV_THREADS), lds, s, scores, d_chrs.p, d_chrs.p + p->nchr, d_seg.p, p->nchr, nind_out,
+                       winsize, cutoff, dst);
+    e = hipGetLastError();
+    if (e == hipSuccess && where == GARLIC_HOST)
+        e = hipMemcpyAsync(inwin, dst, sizeof(int16_t) * (size_t)Lo.total, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+    return done(GARLIC_OK);
+}
+
 int garlic_last_call_stats(garlic_panel *p, garlic_call_stats *stats)
 {
     if (!p || !stats) return fail(GARLIC_ERR_INVALID, "panel and stats are required");

@@ -355,4 +355,53 @@ feed_write_kernel(const double *scores, const ChrDev *chrs, int nchr, int nind, 
     }
 }
 
+// ---- ROH coverage counting: first half of assembleROHWindows (garlic-roh.cpp:446-454).
+//   inWin[l] = #{ windows w in (l - W, l] of this individual with score >= cutoff }
+// i.e. how many above-cutoff windows cover SNP l (MISSING = -9999 and NaN never qualify; windows
+// that would run past the chromosome end cover only the SNPs that exist).  Integer work: per
+// (row, 2048-SNP segment) one workgroup marks the windows of the segment and of the W-1 SNPs in
+// front of it, takes a prefix count and differences it.  Scores stay on the device; 2 bytes per
+// (individual, SNP) come back instead of 8.
+constexpr int COV_SEG = 2048, COV_THREADS = 256;
+__global__ void __launch_bounds__(COV_THREADS)
+roh_coverage_kernel(const double *__restrict__ scores, const ChrDev *__restrict__ chrs,
+                    const ChrDev *__restrict__ ochrs, const int32_t *__restrict__ seg_base, int nchr,
+                    int nind, int W, double cutoff, int16_t *__restrict__ inwin)
+{
+    extern __shared__ int32_t pre[];                    // [halo + COV_SEG + 1] inclusive prefix counts
+    __shared__ int32_t part[COV_THREADS];
+    int chr = 0;
+    while (chr + 1 < nchr && (int)blockIdx.x >= seg_base[chr + 1]) chr++;
+    const ChrDev c = chrs[chr], oc = ochrs[chr];
+    const int seg0 = ((int)blockIdx.x - seg_base[chr]) * COV_SEG;
+    const int ind = blockIdx.y;
+    const double *row = scores + c.out_base + (int64_t)ind * c.out_pitch;
+    const int halo = W - 1;
+    const int first = seg0 - halo;                      // window index of pre[1]
+    const int n = halo + min(COV_SEG, c.nloci - seg0);  // windows looked at
+    // each thread marks a contiguous chunk, then the chunks are chained
+    const int per = (n + COV_THREADS - 1) / COV_THREADS;
+    const int lo = threadIdx.x * per, hi = min(n, lo + per);
+    int cnt = 0;
+    for (int k = lo; k < hi; k++) {
+        const int w = first + k;
+        const bool q = (w >= 0) && (row[w] >= cutoff);  // NaN >= x is false
+        cnt += q ? 1 : 0;
+        pre[k + 1] = cnt;
+    }
+    part[threadIdx.x] = cnt;
+    if (threadIdx.x == 0) pre[0] = 0;
+    __syncthreads();
+    int offset = 0;
+    for (int t = 0; t < (int)threadIdx.x; t++) offset += part[t];
+    __syncthreads();
+    for (int k = lo; k < hi; k++) pre[k + 1] += offset;
+    __syncthreads();
+    int16_t *orow = inwin + oc.out_base + (int64_t)ind * oc.out_pitch;
+    for (int k = halo + (int)threadIdx.x; k < n; k += COV_THREADS) {
+        // SNP l = first + k is covered by windows l-W+1 .. l = positions k-halo .. k
+        orow[first + k] = (int16_t)(pre[k + 1] - pre[k - halo]);
+    }
+}
+
 } // namespace garlic

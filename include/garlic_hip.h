@@ -156,6 +156,20 @@ int garlic_wlod_windows(garlic_panel *panel, int32_t winsize, double error, int3
 int garlic_lod_flatten(garlic_panel *panel, const double *scores, int32_t pitch_align, int32_t nind_out,
                        int32_t step, double *feed, int64_t feed_capacity, int64_t *count);
 
+/* First half of assembleROHWindows (src/garlic-roh.cpp:446-454) on the device: for every individual
+ * and SNP the number of windows with score >= cutoff that cover the SNP,
+ *     inWin[l] = #{ w in (l - winsize, l] : scores[w] >= cutoff }
+ * (MISSING and NaN never qualify; the reference indexes past the array for a qualifying window in
+ * the last winsize-1 positions, which only a cutoff <= -9999 can produce: here such windows cover
+ * the SNPs that exist).  scores: device memory laid out as garlic_lod_out_layout(pitch_align,
+ * nind_out); inwin: int16 elements addressed the same way with inwin_pitch_align (1 = dense rows of
+ * nloci_c), host or device per `where`.  The caller compares inWin with
+ * OVERLAP_FRAC * winsize clamped to [1, winsize] (:422-424) -- 2 bytes per (individual, SNP) cross
+ * PCIe instead of 8. */
+int garlic_roh_coverage(garlic_panel *panel, const double *scores, int32_t pitch_align, int32_t nind_out,
+                        int32_t winsize, double cutoff, int16_t *inwin, int32_t inwin_pitch_align,
+                        int32_t where);
+
 /* Introspection used by tests and the bench (device work of the last garlic_*_windows call). */
 typedef struct garlic_call_stats {
     int64_t n_segments;      /* gap/centromere-free SNP segments over all chromosomes */

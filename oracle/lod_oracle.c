@@ -311,3 +311,20 @@ void oracle_mask(int nloci, const int32_t *pos, int cStart, int cEnd, int winsiz
         valid[s] = (uint8_t)ok;
     }
 }
+
+/* garlic-roh.cpp:446-454: coverage of every SNP by above-cutoff windows of one individual row.
+ * (The reference increments inWin[w + i] without a bound; a qualifying window needs a real score,
+ * and real scores end at nloci - winsize, so the bound below only matters for cutoff <= MISSING.) */
+void oracle_roh_coverage(int nloci, int nind, const double *win, int winsize, double cutoff,
+                         int16_t *inwin)
+{
+    for (int ind = 0; ind < nind; ind++) {
+        int16_t *in = inwin + (size_t)ind * nloci;
+        const double *row = win + (size_t)ind * nloci;
+        for (int w = 0; w < nloci; w++) in[w] = 0;
+        for (int w = 0; w < nloci; w++)
+            if (row[w] >= cutoff)
+                for (int i = 0; i < winsize && w + i < nloci; i++) in[w + i]++;
+    }
+}
+

@@ -67,6 +67,8 @@ void oracle_hr2_ld(int nloci, int nind, const int16_t *genotypes, const double *
 
 /* garlic-data.cpp:2026-2069, one chromosome; returns number of values written. */
 int64_t oracle_flatten(int nloci, int nind, const double *win, int step, double *out);
+void oracle_roh_coverage(int nloci, int nind, const double *win, int winsize, double cutoff,
+                         int16_t *inwin);
 
 /* Window validity mask implied by garlic-roh.cpp:50-125 (SURVEY.md 8(a') item 1);
  * valid[s]=1 iff window s holds a LOD score for every individual. */

@@ -65,6 +65,8 @@ def oracle():
         lib.oracle_hr2_ld.argtypes = [C.c_int, C.c_int, _sp, _dp, C.c_int, _ip, C.c_int, _dp]
         lib.oracle_flatten.restype = C.c_int64
         lib.oracle_flatten.argtypes = [C.c_int, C.c_int, _dp, C.c_int, _dp]
+        lib.oracle_roh_coverage.restype = None
+        lib.oracle_roh_coverage.argtypes = [C.c_int, C.c_int, _dp, C.c_int, C.c_double, _sp]
         lib.oracle_mask.restype = None
         lib.oracle_mask.argtypes = [C.c_int, _ip, C.c_int, C.c_int, C.c_int, C.c_int, _bp]
         _oracle = lib
@@ -177,6 +179,14 @@ def oracle_flatten(win, step):
     out = np.empty(win.size, dtype=np.float64)
     n = oracle().oracle_flatten(nloci, nind, _p(win, _dp), step, _p(out, _dp))
     return out[:n].copy()
+
+
+def oracle_roh_coverage(win, W, cutoff):
+    win = np.ascontiguousarray(win, dtype=np.float64)
+    nind, nloci = win.shape
+    out = np.empty((nind, nloci), dtype=np.int16)
+    oracle().oracle_roh_coverage(nloci, nind, _p(win, _dp), W, cutoff, _p(out, _sp))
+    return out
 
 
 def ref_calc_lod(geno, freq, pos, cS, cE, W, error, max_gap, gl=None, centro_known=True):

@@ -157,3 +157,36 @@ def test_kde_feed_flatten_on_device(gpu_ctx):
             assert ol.bits_equal(feed.cpu().numpy(), want), step
     d = np.load(os.path.join(G, "flatten.npz"))
     assert ol.bits_equal(ol.oracle_flatten(d["win"], 30), d["flat_step30"])
+
+
+@pytest.mark.parametrize("W", [2, 30, 250])
+def test_roh_coverage_counts_on_device(gpu_ctx, W):
+    """garlic_roh_coverage = the inWin[] loop of assembleROHWindows (garlic-roh.cpp:446-454) over
+    device-resident scores: several cutoffs incl. one below MISSING, NaN scores, segment borders
+    (2048-SNP segments), chromosomes shorter than the window"""
+    import torch
+    rng = np.random.default_rng(70 + W)
+    mg, nind = 200000, 37
+    sizes = [5000, 1, max(1, W - 1), W + 3, 2048, 2049]
+    chroms = [ol.random_panel(rng, n, nind, max_gap=mg, gaps=2 if n > 1000 else 0) for n in sizes]
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms])
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        base, pitch, total = panel.out_layout(32, nind)
+        dev = torch.empty(total, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        panel.lod_windows_device(dev.data_ptr(), W, 0.001, mg, pitch_align=32)
+        host = dev.cpu().numpy().copy()
+        # plant a few NaNs (never >= cutoff) inside chromosome 0
+        for i, l in ((0, 10), (3, 2047), (3, 2048), (36, 4000)):
+            host[base[0] + i * pitch[0] + l] = np.nan
+        dev.copy_(torch.from_numpy(host))
+        torch.cuda.synchronize()
+        rows = [host[base[c]: base[c] + nind * pitch[c]].reshape(nind, pitch[c])[:, :n] for c, n in enumerate(sizes)]
+        for cutoff in (0.0, -2.5, 3.0, -10000.0):
+            got = panel.roh_coverage(dev.data_ptr(), W, cutoff, pitch_align=32)
+            for c in range(len(sizes)):
+                want = ol.oracle_roh_coverage(rows[c], W, cutoff)
+                assert np.array_equal(got[c], want), (W, cutoff, c)
+
