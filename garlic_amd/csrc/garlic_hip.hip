@@ -146,6 +146,8 @@ struct garlic_panel {
     DevBuf<uint8_t> d_codes;                       // [GOFF+nloci+pad][nind_pad]
     DevBuf<double> d_tabgl;
     bool tabgl_valid = false;
+    DevBuf<double> d_glterms;                      // TGLS term matrix [blk][GOFF+nloci+pad][64]
+    bool glterms_valid = false;
     int tabgl_ncodes = 0;
     // wLOD
     bool have_ld = false, wlod_use_gl = false;
@@ -338,6 +340,32 @@ int ensure_gl_table(garlic_panel *p)
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     p->tabgl_valid = true;
     p->tabgl_ncodes = ncodes;
+    p->glterms_valid = false;
+    return GARLIC_OK;
+}
+
+// ---- TGLS pass 1: every (SNP, individual) term, once per panel (window-size independent).
+// Returns GARLIC_OK with glterms_valid unset when the matrix does not fit: the caller then keeps
+// the look-up-in-the-chain kernel.
+int ensure_gl_terms(garlic_panel *p)
+{
+    if (p->glterms_valid) return GARLIC_OK;
+    if (getenv("GARLIC_GL_NO_TERMS")) return GARLIC_OK;
+    const int64_t rows = GOFF + p->nloci + GPAD_BACK;
+    const size_t n = (size_t)rows * p->nind_pad;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GARLIC_OK;
+    if (p->d_glterms.cap < n && n * sizeof(double) + ((size_t)8 << 30) > free_b) return GARLIC_OK;
+    int rc;
+    if ((rc = p->d_glterms.reserve(n))) return rc;
+    hipStream_t s = p->ctx->stream;
+    HIP_TRY(hipMemsetAsync(p->d_glterms.p, 0, sizeof(double) * n, s));
+    VariantArgs a{p->d_packed.p, nullptr, p->d_tabgl.p, p->d_codes.p, nullptr, nullptr, nullptr, nullptr, nullptr,
+                  p->nind_pad, p->nwordrows, 0, 0, 0, (int32_t)p->gl_values.size(), 1};
+    hipLaunchKernelGGL(gl_terms_kernel, dim3((unsigned)((p->nloci + 63) / 64), (unsigned)(p->nind_pad / WAVE)),
+                       dim3(256), 0, s, a, p->nloci, rows, p->d_glterms.p);
+    HIP_TRY(hipGetLastError());
+    p->glterms_valid = true;
     return GARLIC_OK;
 }
 
@@ -416,6 +444,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     if (use_gl) {
         if (!p->have_gl) return fail(GARLIC_ERR_STATE, "use_gl set but no genotype likelihoods were given");
         if ((rc = ensure_gl_table(p))) return rc;
+        if (mode == MODE_LOD_GL && (rc = ensure_gl_terms(p))) return rc;
     } else if ((rc = ensure_term_table(p, error))) return rc;
     if (mode == MODE_WLOD) {
         if (!p->have_ld || p->ld_winsize != W)
@@ -571,7 +600,10 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         VariantArgs a{p->d_packed.p, p->d_tab.p,  p->d_tabgl.p, p->d_codes.p, p->d_decay.p, p->d_rld.p,
                       p->d_items.p,  p->d_chrs.p, d_out,        p->nind_pad,  p->nwordrows, ind_begin,    ind_count,
                       W,             (int32_t)p->gl_values.size(), use_gl ? 1 : 0};
-        if (mode == MODE_LOD_GL) {
+        if (mode == MODE_LOD_GL && p->glterms_valid) {
+            hipLaunchKernelGGL(lod_chain_terms_kernel, dim3((unsigned)n_items), dim3(WAVE), 0, ctx->stream, a,
+                               (int)n_items, (int64_t)(GOFF + p->nloci + GPAD_BACK), p->d_glterms.p);
+        } else if (mode == MODE_LOD_GL) {
             hipLaunchKernelGGL(lod_chain_gl_kernel, dim3((unsigned)((n_items + GL_WAVES - 1) / GL_WAVES)),
                                dim3(GL_WAVES * WAVE), 0, ctx->stream, a, (int)n_items);
         } else {
@@ -749,7 +781,7 @@ int garlic_panel_destroy(garlic_panel *p)
     p->d_blk_offsets.release(); p->d_total.release(); p->d_boundaries.release();
     p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release(); p->d_row_counts.release(); p->d_codes.release(); p->d_tabgl.release();
     p->d_rld.release(); p->d_decay.release(); p->d_stage64.release();
-    p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release();
+    p->d_glterms.release(); p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release();
     p->d_out.release();
     delete p;
     return GARLIC_OK;
@@ -789,6 +821,7 @@ int garlic_panel_set_freq(garlic_panel *p, const double *freq)
     p->have_freq = true;
     p->tab_valid = false;
     p->tabgl_valid = false;
+    p->glterms_valid = false;
     return GARLIC_OK;
 }
 
@@ -831,6 +864,7 @@ int garlic_panel_set_genotypes(garlic_panel *p, const int16_t *geno, int64_t ld,
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     p->have_geno = true;
+    p->glterms_valid = false;
     return GARLIC_OK;
 }
 
@@ -882,6 +916,7 @@ int garlic_panel_set_gl(garlic_panel *p, const double *gl, int64_t ld, int64_t l
                            hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     p->have_gl = true;
+    p->glterms_valid = false;
     return GARLIC_OK;
 }
 

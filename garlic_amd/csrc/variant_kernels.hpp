@@ -124,6 +124,77 @@ lod_chain_gl_kernel(VariantArgs p, int n_items)
     }
 }
 
+// ---- TGLS in two passes.  The term of (SNP, individual) does not depend on the window size, and
+// looking it up costs two dependent loads plus a gather that drags in 15 cache lines of the
+// ncodes x 32 B term row for 64 values.  Inside the sequential chain that latency is exposed three
+// times per tile; as a pass of its own it is a fully parallel streaming kernel, done once per panel
+// and reused by every window size.  terms: [64-individual block][GOFF + nloci + pad][64] doubles,
+// pad rows 0.0 (= the term of a missing genotype).
+__global__ void __launch_bounds__(256)
+gl_terms_kernel(VariantArgs p, int64_t nloci, int64_t rows, double *__restrict__ terms)
+{
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    const int64_t blk = blockIdx.y, col = blk * WAVE + lane;
+    const int64_t l0 = (int64_t)blockIdx.x * 64;
+    for (int64_t l = l0 + wave; l < min(nloci, l0 + 64); l += 4) {
+        const int64_t G = GOFF + l;
+        const uint32_t word = p.packed[packed_index(G >> 4, col, p.nwordrows)];
+        const uint32_t g = (word >> (2 * (int)(G & 15))) & 3u;
+        const uint32_t code = p.codes[G * p.nind_pad + col];
+        terms[(blk * rows + G) * WAVE + lane] = p.tabgl[((G * p.ncodes) + code) * 4 + g];
+    }
+}
+
+// the chain of lod_chain_gl_kernel with its 64 terms per tile read straight from the term matrix
+// (one round of coalesced 512-B loads per tile)
+__global__ void __launch_bounds__(WAVE)
+lod_chain_terms_kernel(VariantArgs p, int n_items, int64_t rows, const double *__restrict__ terms)
+{
+    __shared__ double tile[WAVE * TPITCH];
+    const int item = blockIdx.x;
+    if (item >= n_items) return;
+    const ChainItem it = p.items[item];
+    if (it.chr < 0) return;
+    const ChrDev c = p.chrs[it.chr];
+    const int lane = threadIdx.x, W = p.winsize, a = it.a, b = it.b;
+    const int rows_valid = min(WAVE, p.ind_count - it.ind0);
+    const int64_t col = (int64_t)p.ind_begin + it.ind0 + lane;
+    const double *tcol = terms + ((col >> 6) * rows) * WAVE + (col & 63);   // term of SNP G at tcol[G * 64]
+    const int64_t Gbase = c.loc_base + GOFF;
+    double acc = 0.0;
+    for (int l0 = a; l0 < a + W - 1; l0 += 32) {         // first window, W-1 terms, 32 loads in flight
+        double t[32];
+#pragma unroll
+        for (int q = 0; q < 32; q++) t[q] = tcol[(Gbase + min(l0 + q, a + W - 2)) * WAVE];
+#pragma unroll
+        for (int q = 0; q < 32; q++) acc += (l0 + q < a + W - 1) ? t[q] : 0.0;
+    }
+    double *out_row0 = p.out + c.out_base + (int64_t)it.ind0 * c.out_pitch;
+    for (int s0 = a & ~(TILE - 1); s0 <= b; s0 += TILE) {
+        const int64_t Gin = Gbase + s0 + W - 1, Gout = Gbase + s0 - 1;
+        double t_in[TILE], t_out[TILE];
+#pragma unroll
+        for (int j = 0; j < TILE; j++) {
+            t_in[j] = tcol[(Gin + j) * WAVE];
+            t_out[j] = tcol[(Gout + j) * WAVE];
+        }
+#pragma unroll
+        for (int j = 0; j < TILE; j++) {
+            const int s = s0 + j;
+            const bool in = (s >= a && s <= b);
+            const double ti = in ? t_in[j] : 0.0;
+            const double to = (in && s > a) ? t_out[j] : 0.0;
+            acc = (acc - to) + ti;
+            tile[lane * TPITCH + j] = acc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        variant_store(tile, s0, a, b, lane, rows_valid, out_row0 + s0, c.out_pitch);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- 1.0 / LD, IEEE division (garlic-roh.cpp:270 does it per use; the quotient is the same double)
 __global__ void reciprocal_kernel(const double *__restrict__ ld, double *__restrict__ rld, int64_t n)
 {
