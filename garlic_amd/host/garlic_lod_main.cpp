@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -27,6 +28,7 @@ struct Args {
     std::vector<int> winsize_multi;
     bool auto_winsize = false, weighted = false, raw_lod = false, kde_thinning = true, phased = false;
     int auto_winsize_step = 10, max_gap = 200000, M = 7, threads = 1, kde_subsample = 20, gpus = 1;
+    std::vector<int> devices;      // --devices; empty = 0 .. gpus-1
     int ld_subsample = 0;          // src/garlic-cli.cpp:137
     unsigned long long ld_seed = 0; // extension: 0 = time-seeded like the reference
     double mu = 1e-9, overlap_frac = 0.25;
@@ -39,7 +41,8 @@ struct Args {
                  "         (--error E | --tgls F --gl-type GQ|GL|PL) (--winsize W | --winsize-multi W1 W2 ...)\n"
                  "         [--auto-winsize] [--auto-winsize-step N] [--max-gap N] [--overlap-frac X]\n"
                  "         [--freq-file F] [--tped-missing C] [--raw-lod] [--kde-subsample N] [--no-kde-thinning]\n"
-                 "         [--weighted --map F --M N --mu X --ld-subsample N --ld-seed S --threads N] [--gpus N]\n";
+                 "         [--weighted --map F --M N --mu X --ld-subsample N --ld-seed S --threads N]\n"
+                 "         [--gpus N | --devices 0,1,...]\n";
     exit(1);
 }
 
@@ -79,6 +82,11 @@ Args parse(int argc, char **argv)
         else if (f == "--kde-subsample") a.kde_subsample = atoi(val().c_str());
         else if (f == "--no-kde-thinning") a.kde_thinning = !a.kde_thinning;
         else if (f == "--gpus") a.gpus = atoi(val().c_str());
+        else if (f == "--devices") {   // explicit HIP ordinals, e.g. 0,1,2,3 (an ordinal may repeat: shards share that GPU)
+            std::stringstream ss(val());
+            std::string tok;
+            while (std::getline(ss, tok, ',')) a.devices.push_back(atoi(tok.c_str()));
+        }
         else usage(("unknown flag " + f).c_str());
     }
     // validators of src/garlic-cli.cpp:240-462 that concern Phase I
@@ -142,8 +150,9 @@ int main(int argc, char **argv)
         }
         std::cerr << "Filtered monomorphic" << (a.weighted ? " or out of bounds" : "") << " sites: " << kept << " loci kept\n";
 
-        std::vector<int> devices;
-        for (int d = 0; d < a.gpus; d++) devices.push_back(d);
+        std::vector<int> devices = a.devices;
+        if (devices.empty())
+            for (int d = 0; d < a.gpus; d++) devices.push_back(d);
         if (a.weighted && a.phased) { std::cerr << "ERROR: --phased needs haplotype phase, which this engine does not hold\n"; return 1; }
 
         std::vector<int> sizes = a.winsize_multi.empty() ? std::vector<int>{a.winsize} : a.winsize_multi;

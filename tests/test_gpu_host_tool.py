@@ -109,3 +109,23 @@ def test_kde_feed_matches_oracle(tmp_path):
             for g, f, p, (cs, ce) in per_chr])
         got = np.fromfile(f"{out}.{W}SNPs.lod.f64", dtype=np.float64)
         assert ol.bits_equal(got, want), W
+
+
+def test_sharded_run_equals_single_device(tmp_path):
+    """individuals sharded over several contexts (here: all on GPU 0) -- rows gathered in TFAM order,
+    LD pair counts summed over shards -- give byte-identical files, unweighted and weighted"""
+    import filecmp
+    common = ["--winsize", "30", "--raw-lod"]
+    weighted = ["--weighted", "--map", os.path.join(E2E, "tiny.map"), "--ld-subsample", "11", "--ld-seed", "5"]
+    for extra in ([], weighted):
+        outs = []
+        for k, devs in enumerate(("0", "0,0", "0,0,0,0,0")):
+            d = tmp_path / f"run{len(extra)}_{k}"
+            d.mkdir()
+            outs.append(run_tool(d, *common, *extra, "--devices", devs))
+        names = sorted(os.path.basename(p)[len("mine"):] for p in glob.glob(outs[0] + "*"))
+        assert any("raw.lod" in n for n in names) and any(n.endswith(".lod.f64") for n in names)
+        for other in outs[1:]:
+            for n in names:
+                assert filecmp.cmp(outs[0] + n, other + n, shallow=False), (n, other)
+
