@@ -396,7 +396,7 @@ lod_chain_kernel(ChainArgs p)
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Persistent workgroup: pulls (run, 64-individual block) items, longest runs
-    // first, from one device-wide counter.  Wave 2 owns the accumulator: it sums the run's first
+    // first, from one device-wide counter.  Wave 0 owns the accumulator: it sums the run's first
     // window and runs the first / last (partial) tiles through the compiler-generated path; all
     // full tiles go through the 3-role hand-scheduled loop.
     for (;;) {
@@ -510,8 +510,8 @@ lod_chain_kernel(ChainArgs p)
             const uint32_t wmask = GARLIC_CHAIN_WROWS - 1;
             if (p.trace && threadIdx.x == 0) p.trace[4 * item_idx + 2] = wall_clock64();
             // all waves enter together; the block starts by draining each wave's own memory
-            // operations, its stage barriers order the LDS hand-offs (TILE buffer 0 above
-            // included: the loop first writes it two barriers in)
+            // operations, one barrier after CHAIN has reset the LDS counters, counters from
+            // then on (TILE buffer 0 used by the head tile above is this wave's own)
             asm volatile(GARLIC_CHAIN_LOOP_ASM
                          : [acc] "+v"(acc)
                          : [wave] "s"(wave), [lane] "v"(lane), [lc] "v"(lc), [tc] "v"(tc),

@@ -3,35 +3,39 @@
 chain kernel -- ONE inline-asm block executed by the 3 wavefronts of a workgroup, each in its own
 role (gfx950, wave64; one workgroup = one (SNP run, 64 individuals) item at a time).
 
-Why hand-scheduled, why two roles: a single wavefront issues about one instruction every 4 cycles,
+Why hand-scheduled, why three roles: a single wavefront issues about one instruction every 4 cycles,
 and a ds_write_b128 / global_store_dwordx4 blocks it for ~28 / ~38 cycles (tools/ubench/
-issue_rates.hip).  A C2-sized panel has only ~4 items per CU, so the job is bound by the
-instruction stream of the longest SNP run, not by HBM.  hipcc serialises ds_read -> s_waitcnt ->
-v_add_f64 per step; here every LDS read is issued an 8-step batch ahead and all waits are counted.
-Splitting further (separate look-up waves handing terms over through LDS) was measured SLOWER:
-the extra LDS traffic saturates the CU's LDS pipeline.
+issue_rates.hip), so one wave doing everything needs ~77 cycles per window start.  hipcc
+serialises ds_read -> s_waitcnt -> v_add_f64 per step; here every LDS read is issued an 8-step
+batch ahead and all waits are counted.  Splitting the chain wave further (separate look-up waves
+handing terms over through LDS) was measured SLOWER: the extra LDS traffic saturates the CU's LDS
+pipeline.
 
   wave 0  CHAIN  one VALU per term (byte extract of a pre-expanded LDS offset), term look-up
-                 (ds_read_b64), the dependent FP64
-                 chain acc = (acc - t_out) + t_in (two roundings, reference
-                 src/garlic-roh.cpp:98-100), acc -> transpose tile (ds_write_b128 per 2 steps)
-                 -- no vector-memory instruction at all: a request of its own would queue behind
-                 POST's stores in the CU's memory pipeline and stall the chain (measured: +30 %)
-  wave 1  POST   LDS-DMA prefetch of genotype words / term rows (8-slot ring); funnel shift of the
-                 words and expansion of the 2-bit genotypes into one byte each (= genotype*8, the
-                 LDS offset inside a term row: 3 VALU per 4 genotypes via a 24-bit multiply);
-                 transposed write-out of finished tiles: 16 x (ds_read_b128 ->
-                 global_store_dwordx4), 4 rows x 256 B per store.  POST is HBM-bound and has issue
-                 slots to spare; CHAIN is the long pole, so work moves this way.
+                 (ds_read_b64), the dependent FP64 chain acc = (acc - t_out) + t_in (two
+                 roundings, reference src/garlic-roh.cpp:98-100), acc -> transpose tile
+                 (ds_write_b128 per 2 steps).  No vector-memory instruction at all: a request of
+                 its own would queue behind POST's stores in the CU's memory pipeline and stall
+                 the chain (measured: +30 %).  This wave sets the pace.
+  wave 1  POST   transposed write-out of finished tiles: 16 x (ds_read_b128 ->
+                 global_store_dwordx4 nt), 4 rows x 256 B per store, row groups past the shard's
+                 last individual skipped.  Nothing else: when HBM pushes back this wave blocks at
+                 the store issue, and anything else in it adds to the stage time one to one.
+  wave 2  PRE    LDS-DMA prefetch: per tile the 2 x 32 term rows into an NSLOT-deep ring, and every
+                 CHPERIOD tiles one chunk (CHROWS word rows, 1 KB requests) of the item's
+                 block-major genotype stream into the WROWS-row genotype ring that BOTH SNP
+                 streams read (the leaving stream is the entering one W-1 SNPs later); funnel
+                 shift of the words and expansion of the 2-bit genotypes into one byte each
+                 (= genotype*8, the LDS offset inside a term row: 8 VALU per 4 genotypes).
 
-The two waves are decoupled: 4 transpose-tile buffers and three LDS counters instead of a barrier
-per tile (a barrier makes every POST stall -- HBM back-pressure comes in bursts -- a CHAIN stall):
-    tiles_done     CHAIN -> POST   tile k is complete in LDS, input slot k is released
-    tiles_stored   POST -> CHAIN   tile buffer k has been read back (may be overwritten)
-    inputs_landed  POST -> CHAIN   highest tile whose inputs are confirmed in the ring
-POST's vector-memory operations retire in issue order: vmcnt(60) before requesting tile k+8 proves
-everything older than the last 3 tiles' 48 stores + 12 requests has completed, i.e. the inputs of
-tile k+5.
+The waves are decoupled by counters in LDS instead of a barrier per tile (a barrier makes every
+POST stall -- HBM back-pressure comes in bursts -- a CHAIN stall):
+    tiles_done     CHAIN -> POST, PRE   tile k is complete in LDS, input slot k is released
+    tiles_stored   POST -> CHAIN        tile buffer k has been read back (may be overwritten)
+    inputs_ready   PRE -> CHAIN         highest tile whose expanded inputs are in the rings
+PRE's only vector-memory operations are its own requests and they retire in issue order, so its
+wait is an exact vmcnt(n): the requests of the NFLY youngest tiles may stay in flight
+(loads_in_flight()).
 
 CHAIN per tile (32 window starts x 64 individuals), software pipeline over 8-step batches g:
     A(g)  byte offsets of the batch's entering / leaving terms: 1 VALU each (v_and / v_bfe / v_lshr)
@@ -39,12 +43,18 @@ CHAIN per tile (32 window starts x 64 individuals), software pipeline over 8-ste
     C(g)  the chain + tile writes, with A(g+2) woven in
   iteration g:  wait R(g) | issue R(g+1) | C(g) (+) A(g+2)
 
-LDS map (bytes; must match lod_kernels.hpp):
-      0  generic-path slot (3072), item word (3072), flags (3584)   (flags used here)
-   4096  ring: 8 slots x 7168 {lead term rows 1024, trail term rows 1024, genotype words
-                               lead w+1, lead w+2, trail w+1, trail w+2 (256 each),
-                               expanded lead offsets 2048 (32 B per lane), expanded trail 2048}
-  61440  TILE[4][64 rows x 272 B]
+LDS map (bytes; lod_kernels.hpp takes GARLIC_CHAIN_LDS_* from the generated file):
+      0  generic-path slot (3072), item word (3072), flags (3584)
+   4096  TAB ring   NSLOT x 2048   {lead term rows 1024, trail term rows 1024}      (LDS-DMA target)
+      +  WORD ring  WROWS x 256    genotype word row w at (w % WROWS)               (LDS-DMA target)
+      +  EXP ring   NSLOT x 4096   {expanded lead offsets 2048 (32 B per lane), expanded trail 2048}
+      +  TILE[NTILE][64 rows x 272 B]
+The two DMA-target rings stay below 64 KB (16-bit DS offsets / M0).  All fixed VGPRs live in
+v64..v185, reused by the three roles (separate register files).
+
+Environment hooks for experiments: GARLIC_NSLOT, GARLIC_NFLY, GARLIC_NTILE, GARLIC_WROWS,
+GARLIC_CHUNK, GARLIC_STORE_FLAGS, GARLIC_LOAD_FLAGS, GARLIC_ABLATE (nodp, chainwrite, nosync,
+nodma, nochunk, notab, nopost, poststore, noexpand).
 """
 import os
 
