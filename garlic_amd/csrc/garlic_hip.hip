@@ -518,7 +518,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         if ((rc = p->d_valid.reserve(valid.size()))) return rc;
         if ((rc = p->d_tiles.reserve(tiles.size()))) return rc;
     }
-    // Persistent workgroups (3 waves each: CHAIN, POST, PRE), one per CU; items are pulled longest
+    // Persistent workgroups (4 waves each: CHAIN, POST, PRE, COMB), one per CU; items are pulled longest
     // first, so the short runs pack behind the long ones instead of competing with them for HBM
     // bandwidth.
     int workers = 256;

@@ -253,7 +253,7 @@ struct ChainArgs {
     int64_t *trace;           // optional (GARLIC_TRACE): per item {worker, t_begin, t_asm, t_end} in 100 MHz ticks
 };
 
-// LDS map (bytes).  One workgroup = 3 waves (CHAIN, POST, PRE roles) working on one item; the hand-scheduled loop
+// LDS map (bytes).  One workgroup = 4 waves (CHAIN, POST, PRE, COMB roles) working on one item; the hand-scheduled loop
 // (chain_loop_gfx950.inc, see tools/gen_chain_asm.py for the full map) owns everything from 4096
 // on; the compiler-generated "generic" tile path used for a run's first and last tiles keeps its
 // inputs in the slot at 0 and transposes through TILE buffer 0.
@@ -266,7 +266,7 @@ constexpr uint32_t SL_LTAB = 1024, SL_TTAB = 2048;
 constexpr uint32_t LDS_ITEM = 3072;                              // broadcast word for the item index
 constexpr uint32_t LDS_TILE = GARLIC_CHAIN_LDS_TILE0;                             // TILE buffer 0 of the asm loop
 constexpr uint32_t LDS_BYTES = GARLIC_CHAIN_LDS_TOTAL;
-constexpr int CHAIN_THREADS = 192;
+constexpr int CHAIN_THREADS = 256;   // 4 waves: CHAIN, POST, PRE, COMB
 
 // Wave-uniform stream state (lives in SGPRs).
 struct Streams {
@@ -398,7 +398,7 @@ lod_chain_kernel(ChainArgs p)
     // Persistent workgroup: pulls (run, 64-individual block) items, longest runs
     // first, from one device-wide counter.  Wave 0 owns the accumulator: it sums the run's first
     // window and runs the first / last (partial) tiles through the compiler-generated path; all
-    // full tiles go through the 3-role hand-scheduled loop.
+    // full tiles go through the 4-role hand-scheduled loop.
     for (;;) {
     if (threadIdx.x == 0)
         *reinterpret_cast<volatile int *>(smem + LDS_ITEM) = atomicAdd(p.next_item, 1);

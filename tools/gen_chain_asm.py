@@ -1,56 +1,63 @@
 #!/usr/bin/env python3
 """Generates garlic_amd/csrc/chain_loop_gfx950.inc: the hand-scheduled steady-state loop of the LOD
-chain kernel -- ONE inline-asm block executed by the 3 wavefronts of a workgroup, each in its own
-role (gfx950, wave64; one workgroup = one (SNP run, 64 individuals) item at a time).
+chain kernel -- ONE inline-asm block executed by the 4 wavefronts of a workgroup, each in its own
+role on its own SIMD (gfx950, wave64; one workgroup = one (SNP run, 64 individuals) item at a
+time).
 
-Why hand-scheduled, why three roles: a single wavefront issues about one instruction every 4 cycles,
-and a ds_write_b128 / global_store_dwordx4 blocks it for ~28 / ~38 cycles (tools/ubench/
+Why hand-scheduled, why roles: a single wavefront issues about one instruction every 4 cycles, and
+a ds_write_b128 / global_store_dwordx4 blocks it for ~28 / ~38 cycles (tools/ubench/
 issue_rates.hip), so one wave doing everything needs ~77 cycles per window start.  hipcc
 serialises ds_read -> s_waitcnt -> v_add_f64 per step; here every LDS read is issued an 8-step
-batch ahead and all waits are counted.  Splitting the chain wave further (separate look-up waves
-handing terms over through LDS) was measured SLOWER: the extra LDS traffic saturates the CU's LDS
-pipeline.
+batch ahead and all waits are counted.  The wave that carries the sequential FP64 chain sets the
+pace of the whole kernel, so everything that is not the chain lives in the other three.
 
-  wave 0  CHAIN  one VALU per term (byte extract of a pre-expanded LDS offset), term look-up
-                 (ds_read_b64), the dependent FP64 chain acc = (acc - t_out) + t_in (two
-                 roundings, reference src/garlic-roh.cpp:98-100), acc -> transpose tile
-                 (ds_write_b128 per 2 steps).  No vector-memory instruction at all: a request of
-                 its own would queue behind POST's stores in the CU's memory pipeline and stall
-                 the chain (measured: +30 %).  This wave sets the pace.
+  wave 0  CHAIN  per window ONE address op (byte extract), ONE look-up (ds_read_b128 =
+                 {t_out, t_in} of the lane's genotype pair) and the dependent chain
+                 acc = (acc - t_out) + t_in (two roundings, reference src/garlic-roh.cpp:98-100);
+                 acc -> transpose tile (ds_write_b128 per 2 steps).  No vector-memory instruction
+                 at all: a request of its own would queue behind POST's stores in the CU's memory
+                 pipeline and stall the chain (measured: +30 %).
   wave 1  POST   transposed write-out of finished tiles: 16 x (ds_read_b128 ->
                  global_store_dwordx4 nt), 4 rows x 256 B per store, row groups past the shard's
                  last individual skipped.  Nothing else: when HBM pushes back this wave blocks at
                  the store issue, and anything else in it adds to the stage time one to one.
-  wave 2  PRE    LDS-DMA prefetch: per tile the 2 x 32 term rows into an NSLOT-deep ring, and every
-                 CHPERIOD tiles one chunk (CHROWS word rows, 1 KB requests) of the item's
+  wave 2  PRE    LDS-DMA prefetch: per tile the 2 x 32 raw term rows into the NSLOT-deep TAB ring,
+                 and every CHPERIOD tiles one chunk (CHROWS word rows, 1 KB requests) of the item's
                  block-major genotype stream into the WROWS-row genotype ring that BOTH SNP
                  streams read (the leaving stream is the entering one W-1 SNPs later); funnel
-                 shift of the words and expansion of the 2-bit genotypes into one byte each
-                 (= genotype*8, the LDS offset inside a term row: 8 VALU per 4 genotypes).
+                 shift of the words; per step the byte 16 * (4 * g_out + g_in) -> EXP ring.
+  wave 3  COMB   per tile the 32 step tables {t_out[g_out], t_in[g_in]} for the 16 genotype pairs
+                 (16 ds_read_b64 + 8 ds_write_b128 per lane) -> COMB ring.  This is what lets
+                 CHAIN do one look-up per window instead of two (and one address op instead of
+                 two); in PRE it made PRE the bottleneck (measured), hence its own wave.
 
-The waves are decoupled by counters in LDS instead of a barrier per tile (a barrier makes every
+The waves are decoupled by counters in LDS instead of barriers (a barrier per tile makes every
 POST stall -- HBM back-pressure comes in bursts -- a CHAIN stall):
-    tiles_done     CHAIN -> POST, PRE   tile k is complete in LDS, input slot k is released
-    tiles_stored   POST -> CHAIN        tile buffer k has been read back (may be overwritten)
-    inputs_ready   PRE -> CHAIN         highest tile whose expanded inputs are in the rings
+    tiles_done    CHAIN -> all        tile k is complete in LDS; its input slots are released
+    tiles_stored  POST -> CHAIN       tile buffer k has been read back (may be overwritten)
+    exp_ready     PRE -> CHAIN        highest tile whose expanded offsets are in the EXP ring
+    comb_ready    COMB -> CHAIN       highest tile whose step tables are in the COMB ring
+    tabs_landed   PRE -> COMB         number of tiles whose raw term rows have landed
 PRE's only vector-memory operations are its own requests and they retire in issue order, so its
 wait is an exact vmcnt(n): the requests of the NFLY youngest tiles may stay in flight
-(loads_in_flight()).
+(loads_in_flight()).  PRE expands and COMB combines tile k+ELEAD once CHAIN has finished tile k
+(rings of NEXP slots); the raw rows were requested NSLOT tiles ahead.
 
 CHAIN per tile (32 window starts x 64 individuals), software pipeline over 8-step batches g:
-    A(g)  byte offsets of the batch's entering / leaving terms: 1 VALU each (v_and / v_bfe / v_lshr)
-    R(g)  16 ds_read_b64 into one of two 32-VGPR buffers
+    A(g)  byte offsets of the batch's entries: 1 VALU per step (v_and / v_bfe / v_lshr)
+    R(g)  8 ds_read_b128 into one of two 32-VGPR buffers
     C(g)  the chain + tile writes, with A(g+2) woven in
   iteration g:  wait R(g) | issue R(g+1) | C(g) (+) A(g+2)
 
 LDS map (bytes; lod_kernels.hpp takes GARLIC_CHAIN_LDS_* from the generated file):
-      0  generic-path slot (3072), item word (3072), flags (3584)
-   4096  TAB ring   NSLOT x 2048   {lead term rows 1024, trail term rows 1024}      (LDS-DMA target)
-      +  WORD ring  WROWS x 256    genotype word row w at (w % WROWS)               (LDS-DMA target)
-      +  EXP ring   NSLOT x 4096   {expanded lead offsets 2048 (32 B per lane), expanded trail 2048}
+      0  generic-path slot (3072), item word (3072), flags (3584 .. 3603)
+   4096  COMB ring  NEXP x 8192    per step 16 entries x {t_out, t_in}    (CHAIN: immediate offsets)
+      +  EXP ring   NEXP x 2048    32 bytes per lane
+      +  TAB ring   NSLOT x 2048   {lead term rows 1024, trail term rows 1024}        (LDS-DMA target)
+      +  WORD ring  WROWS x 256    genotype word row w at (w % WROWS)                 (LDS-DMA target)
       +  TILE[NTILE][64 rows x 272 B]
-The two DMA-target rings stay below 64 KB (16-bit DS offsets / M0).  All fixed VGPRs live in
-v64..v185, reused by the three roles (separate register files).
+Everything addressed with 16-bit DS immediates stays below 64 KB; LDS-DMA targets may lie above
+(measured).  All fixed VGPRs live in v64..v187, reused by the four roles (separate register files).
 
 Environment hooks for experiments: GARLIC_NSLOT, GARLIC_NFLY, GARLIC_NTILE, GARLIC_WROWS,
 GARLIC_CHUNK, GARLIC_STORE_FLAGS, GARLIC_LOAD_FLAGS, GARLIC_ABLATE (nodp, chainwrite, nosync,
@@ -64,7 +71,7 @@ STORE_FLAGS = os.environ.get("GARLIC_STORE_FLAGS", "nt")  # non-temporal: the sc
 
 LOAD_FLAGS = os.environ.get("GARLIC_LOAD_FLAGS", "")
 NSLOT = int(os.environ.get("GARLIC_NSLOT", "8"))
-NTILE = int(os.environ.get("GARLIC_NTILE", "4"))
+NTILE = int(os.environ.get("GARLIC_NTILE", "2"))
 NFLY = int(os.environ.get("GARLIC_NFLY", "3"))   # tiles of LDS-DMA requests PRE leaves in flight
 assert 3 * NFLY <= 63 and NSLOT - NFLY >= 3 and NSLOT % 2 == 0
 WROWS = int(os.environ.get("GARLIC_WROWS", "128"))   # genotype ring: word rows (256 B each), power of 2
@@ -72,18 +79,23 @@ WMASK = WROWS * 256 - 1
 CH = int(os.environ.get("GARLIC_CHUNK", "4"))        # 1 KB requests per genotype chunk (4 word rows each)
 CHROWS, CHPERIOD = 4 * CH, 2 * CH                    # rows per chunk; one chunk every CHPERIOD tiles
 assert NSLOT % CHPERIOD == 0
-FLAGS = 3584          # +0 tiles_done, +4 tiles_stored, +8 inputs_landed
-# three rings indexed by the same slot number (tile k -> slot k % NSLOT).  The two rings that are
-# LDS-DMA targets / read with immediate offsets stay below 64 KB (16-bit DS offset field).
-TAB_BASE, TAB_SLOT = 4096, 2048         # term rows: lead 1024, trail 1024
+NEXP = 4              # depth of the rings CHAIN reads (combined term table, expanded offsets)
+ELEAD = 3             # PRE prepares tile k+ELEAD once CHAIN has finished tile k
+assert NSLOT % NEXP == 0 and ELEAD < NEXP and ELEAD <= NSLOT - NFLY and NSLOT % NTILE == 0
+FLAGS = 3584          # +0 tiles_done, +4 tiles_stored, +8 exp_ready, +12 comb_ready, +16 tabs_landed
+# Rings.  What CHAIN reads with immediate offsets (16-bit DS offset field) comes first:
+#   COMB  tile t -> slot t % NEXP: per window step one 256-B table of the 16 (leaving genotype,
+#         entering genotype) combinations, entry = {t_out, t_in}: ONE look-up per window
+#   EXP   tile t -> slot t % NEXP: per lane 32 bytes, byte j = 16 * (4 * g_out + g_in) of step j
+#   TAB   tile t -> slot t % NSLOT: raw term rows as fetched (lead 1024 B, trail 1024 B; LDS-DMA)
+#   WORD  genotype word row w at (w % WROWS) * 256 (LDS-DMA; targets above 64 KB are fine)
+COMB_BASE, COMB_SLOT = 4096, 8192
+EXP_BASE, EXP_SLOT = COMB_BASE + NEXP * COMB_SLOT, 2048
+TAB_BASE, TAB_SLOT = EXP_BASE + NEXP * EXP_SLOT, 2048
 T_LTAB, T_TTAB = 0, 1024
-# genotype ring: word row w of the item's stream lives at WORD_BASE + (w % WROWS) * 256, filled by
-# 1 KB (4-row) LDS-DMA chunks; both SNP streams (entering / leaving) read it at their own row
 WORD_BASE = TAB_BASE + NSLOT * TAB_SLOT
-EXP_BASE, EXP_SLOT = WORD_BASE + WROWS * 256, 4096         # expanded offsets: lead 2048, trail 2048
-E_EXPL, E_EXPT = 0, 2048
-TILE_BASE = EXP_BASE + NSLOT * EXP_SLOT
-assert EXP_BASE <= 65536
+TILE_BASE = WORD_BASE + WROWS * 256
+assert WORD_BASE <= 65535
 TILE_BUF = 64 * 34 * 8
 TPITCH_B = 34 * 8
 LDS_TOTAL = TILE_BASE + NTILE * TILE_BUF
@@ -91,16 +103,18 @@ LDS_TOTAL = TILE_BASE + NTILE * TILE_BUF
 # ---- fixed VGPRs (clobbered by the block; each wave has its own register file)
 # Every role is a different wave with its own register file, so the three roles reuse one compact
 # range v64..v185: the kernel's register count decides how many workgroups fit a CU.
-V_BUF = [64, 96]            # CHAIN: two term buffers, 16 x 64-bit each
-V_ADDR = 128                # CHAIN: 16 LDS byte offsets
+V_BUF = [64, 96]            # CHAIN: two term buffers, 8 x {t_out, t_in} each
+V_ADDR = 128                # CHAIN: 8 LDS byte offsets
 V_ACC = 144                 # CHAIN: P0 = [144:145], P1 = [146:147]
-V_E = [148, 164]            # CHAIN: two sets of 16 expanded-offset dwords (lead 8, trail 8)
+V_E = [148, 156]            # CHAIN: two sets of 8 expanded-offset dwords
 V_LANE32 = 180              # CHAIN: EXP_BASE + lane * 32
 V_TWR = 181                 # CHAIN: tile write address
 V_ST = 64                   # POST: 64 VGPRs of store data
 V_STOFF = 128               # POST: 16 store offsets
 V_TRD, V_TRD2 = 144, 145    # POST: tile-read bases
-V_X = 64                    # PRE: 16 expanded dwords being built + 4 scratch
+V_X = 64                    # PRE: 8 expanded dwords being built (+ 8 scratch from V_X + 8)
+V_CT, V_CL, V_CW = 101, 102, 103   # PRE: per-lane offsets of the combine step (trail row, lead row, entry)
+V_CB = 104                  # PRE: 8 x {t_out, t_in} being combined (32 VGPRs)
 V_LL, V_LH, V_TL, V_TH = 84, 85, 86, 87   # PRE: funnel-shifted genotype bits
 V_WL1, V_WL2, V_WT1, V_WT2 = 88, 89, 90, 91
 V_LANE4, V_LANE16 = 92, 93
@@ -108,7 +122,7 @@ V_LADDR, V_TADDR = 94, 95   # PRE: ring byte offset (+ lane*4) of word +0 of the
 V_A1L, V_A1T = 96, 97       # PRE: ring offsets of word +1
 V_LANE32P = 98              # PRE: EXP_BASE + lane * 32
 V_LC, V_TC = 99, 100
-V_FLAG, V_TMP0, V_TMP1 = 182, 184, 185   # all roles; TMP pair 64-bit aligned (ds_read2 dst)
+V_FLAG, V_TMP0, V_TMP1 = 182, 184, 185   # all roles; v[184:187] = destination of the flag reads
 # ---- fixed SGPRs
 S_PCHUNK, S_ROFF, S_NCH, S_PLTAB, S_PTTAB = 40, 42, 43, 44, 46
 S_OUT = 50
@@ -119,7 +133,7 @@ S_K = 56
 S_F0, S_F1 = 57, 58
 S_ROWS = 59                # POST: valid individuals (rows) of this item
 
-CLOBBER_V = list(range(64, 186))
+CLOBBER_V = list(range(64, 188))
 CLOBBER_S = list(range(40, 60))
 
 
@@ -159,20 +173,14 @@ def quad(r):
 
 # ------------------------------------------------------------------ CHAIN
 def addr_ops(j, eset):
-    """the 2 VALU ops producing the LDS byte offsets of step j's leaving/entering terms: byte j%4 of
-    dword j//4 of the tile's expanded offsets (set `eset`: lead dwords 0-7, trail dwords 8-15)"""
-    i = j % 8
-    at, al = V_ADDR + 2 * i, V_ADDR + 2 * i + 1
-    ops = []
-    for dst, src in ((at, V_E[eset] + 8 + j // 4), (al, V_E[eset] + j // 4)):
-        b = j % 4
-        if b == 0:
-            ops.append(f"v_and_b32_e32 v{dst}, 0xff, v{src}")
-        elif b == 3:
-            ops.append(f"v_lshrrev_b32_e32 v{dst}, 24, v{src}")
-        else:
-            ops.append(f"v_bfe_u32 v{dst}, v{src}, {8 * b}, 8")
-    return ops
+    """the VALU op producing the LDS byte offset of step j's {t_out, t_in} entry inside the step's
+    256-B table: byte j%4 of dword j//4 of the tile's expanded offsets (register set `eset`)"""
+    dst, src, b = V_ADDR + j % 8, V_E[eset] + j // 4, j % 4
+    if b == 0:
+        return [f"v_and_b32_e32 v{dst}, 0xff, v{src}"]
+    if b == 3:
+        return [f"v_lshrrev_b32_e32 v{dst}, 24, v{src}"]
+    return [f"v_bfe_u32 v{dst}, v{src}, {8 * b}, 8"]
 
 
 def all_addr_ops(n, eset):
@@ -183,18 +191,18 @@ def all_addr_ops(n, eset):
 
 
 def gen_R(g, slot, n):
-    """issue the 16 term reads of batch n of the tile living in ring slot `slot`"""
+    """issue the 8 look-ups of batch n of the tile living in COMB/EXP slot `slot`: one ds_read_b128
+    per window step = {t_out, t_in} of this lane's genotype pair"""
     buf = V_BUF[n % 2]
     last = 0
     for i in range(8):
         j = 8 * n + i
-        g.lds(f"ds_read_b64 {pair(buf + 4 * i)}, v{V_ADDR + 2 * i} offset:{TAB_BASE + slot * TAB_SLOT + T_TTAB + 32 * j}")
-        last = g.lds(f"ds_read_b64 {pair(buf + 4 * i + 2)}, v{V_ADDR + 2 * i + 1} offset:{TAB_BASE + slot * TAB_SLOT + T_LTAB + 32 * j}")
+        last = g.lds(f"ds_read_b128 {quad(buf + 4 * i)}, v{V_ADDR + i} offset:{COMB_BASE + slot * COMB_SLOT + 256 * j}")
     return last
 
 
 def gen_C(g, n, a_ops, tbuf):
-    """chain of batch n, the next-but-one batch's address ops woven in (2 after every add)"""
+    """chain of batch n, the next-but-one batch's address ops woven in (1 per step)"""
     buf = V_BUF[n % 2]
     a_ops = list(a_ops)
     P0, P1 = V_ACC, V_ACC + 2
@@ -215,32 +223,35 @@ def gen_C(g, n, a_ops, tbuf):
 
 
 def gen_exp_reads(g, slot, eset):
-    """CHAIN: the tile's 16 expanded-offset dwords (this lane's 32 B per stream)"""
+    """CHAIN: the tile's 8 expanded-offset dwords (this lane's 32 bytes)"""
     base = slot * EXP_SLOT       # V_LANE32 holds EXP_BASE + lane*32
     last = 0
     for h in range(2):
-        g.lds(f"ds_read_b128 {quad(V_E[eset] + 4 * h)}, v{V_LANE32} offset:{base + E_EXPL + 16 * h}")
-        last = g.lds(f"ds_read_b128 {quad(V_E[eset] + 8 + 4 * h)}, v{V_LANE32} offset:{base + E_EXPT + 16 * h}")
+        last = g.lds(f"ds_read_b128 {quad(V_E[eset] + 4 * h)}, v{V_LANE32} offset:{base + 16 * h}")
     return last
 
 
 def chain_tile(g, slot, uid):
-    """CHAIN, one tile k: ring slot = k % NSLOT, tile buffer = k % NTILE"""
-    nxt = (slot + 1) % NSLOT
+    """CHAIN, one tile k (unrolled position slot = k % NSLOT): COMB/EXP slot k % NEXP, tile buffer
+    k % NTILE"""
     tbuf = slot % NTILE
+    nxt = (slot + 1) % NEXP
+    slot = slot % NEXP
     e = g.emit
     if "nosync" not in ABL:
         # wait until POST has (a) read back the tile that last used this tile buffer and (b) confirmed
         # the inputs of the NEXT tile (its words are read in batch 1, its terms from batch 3 on)
         e(f"CHAIN_POLL_{uid}_%=:")
-        e(f"ds_read2_b32 v[{V_TMP0}:{V_TMP1}], v{V_FLAG} offset0:1 offset1:2")
+        e(f"ds_read_b128 v[{V_TMP0}:{V_TMP0 + 3}], v{V_FLAG}")   # done, stored, exp_ready, comb_ready
         e("s_waitcnt lgkmcnt(0)")
-        e(f"v_readfirstlane_b32 s{S_F0}, v{V_TMP0}")
-        e(f"v_readfirstlane_b32 s{S_F1}, v{V_TMP1}")
+        e(f"v_readfirstlane_b32 s{S_F0}, v{V_TMP0 + 1}")
+        e(f"v_readfirstlane_b32 s{S_F1}, v{V_TMP0 + 2}")
+        e(f"v_readfirstlane_b32 s{S_TMP}, v{V_TMP0 + 3}")
         e(f"s_add_u32 s{S_F0}, s{S_F0}, {NTILE - 1}")
         e(f"s_cmp_ge_u32 s{S_F0}, s{S_K}")           # tiles_stored >= k - (NTILE-1)
         e(f"s_cbranch_scc0 CHAIN_SLEEP_{uid}_%=")
-        e(f"s_cmp_gt_u32 s{S_F1}, s{S_K}")           # inputs_landed >= k + 1
+        e(f"s_min_u32 s{S_F1}, s{S_F1}, s{S_TMP}")   # both the offsets and the tables of tile k+1
+        e(f"s_cmp_gt_u32 s{S_F1}, s{S_K}")           # ready >= k + 1
         e(f"s_cbranch_scc1 CHAIN_GO_{uid}_%=")
         e(f"CHAIN_SLEEP_{uid}_%=:")
         e("s_sleep 1")
@@ -289,13 +300,16 @@ def gen_chain(g):
     e(f"v_mov_b32_e32 v{V_TMP0}, 0")
     e(f"v_mov_b32_e32 v{V_TMP1}, 0")
     e(f"ds_write_b32 v{V_FLAG}, v{V_TMP0}")                                  # tiles_done = 0
-    e(f"ds_write2_b32 v{V_FLAG}, v{V_TMP0}, v{V_TMP1} offset0:1 offset1:2")  # stored = landed = 0
+    e(f"ds_write2_b32 v{V_FLAG}, v{V_TMP0}, v{V_TMP1} offset0:1 offset1:2")  # stored = exp_ready = 0
+    e(f"ds_write2_b32 v{V_FLAG}, v{V_TMP0}, v{V_TMP1} offset0:3 offset1:4")  # comb_ready = tabs_landed = 0
     e("s_waitcnt lgkmcnt(0)")
     e("s_barrier")  # the previous item's counters are gone; POST may start
-    e("CHAIN_FIRST_%=:")  # wait for the ring's initial fill
-    e(f"ds_read_b32 v{V_TMP1}, v{V_FLAG} offset:8")
+    e("CHAIN_FIRST_%=:")  # wait for the rings' initial fill
+    e(f"ds_read2_b32 v[{V_TMP0}:{V_TMP1}], v{V_FLAG} offset0:2 offset1:3")
     e("s_waitcnt lgkmcnt(0)")
+    e(f"v_readfirstlane_b32 s{S_F0}, v{V_TMP0}")
     e(f"v_readfirstlane_b32 s{S_F1}, v{V_TMP1}")
+    e(f"s_min_u32 s{S_F1}, s{S_F1}, s{S_F0}")
     e(f"s_cmp_gt_u32 s{S_F1}, 0")
     e("s_cbranch_scc1 CHAIN_START_%=")
     e("s_sleep 2")
@@ -367,12 +381,18 @@ def loads_in_flight(slot):
 
 
 def post_expand(g, slot):
-    """PRE: read the tile's genotype words (+1, +2; word +0 is carried) of both streams from the
-    genotype ring, funnel-shift them and expand each 2-bit genotype into one byte = genotype*8;
-    this lane's 32 bytes per stream go to the slot's EXP areas."""
+    """PRE: prepare the tile living in TAB slot `slot` (unrolled position = tile % NSLOT) for CHAIN.
+    (1) Genotype words (+1, +2; word +0 is carried) of both SNP streams from the genotype ring,
+        funnel-shifted to the tile's first step; per step the pair (leaving genotype g_out,
+        entering genotype g_in) becomes one byte 16 * (4 * g_out + g_in) = the offset of the
+        pair's entry in the step's table; this lane's 32 bytes go to the EXP slot.
+    (2) The tile's 32 step tables: entry (g_out, g_in) = {t_out[g_out], t_in[g_in]} from the raw
+        term rows, 16 entries x 16 B per step, 8 entries per lane -> COMB slot.  CHAIN then needs
+        ONE address op and ONE ds_read_b128 per window instead of two and two."""
     if "noexpand" in ABL:
         return
     e = g.emit
+    s4 = slot % NEXP
     for a1, a0 in ((V_A1L, V_LADDR), (V_A1T, V_TADDR)):
         e(f"v_add_u32_e32 v{a1}, 0x100, v{a0}")
         e(f"v_and_b32_e32 v{a1}, {WMASK}, v{a1}")
@@ -389,22 +409,37 @@ def post_expand(g, slot):
     e(f"v_alignbit_b32 v{V_TH}, v{V_WT2}, v{V_WT1}, s{S_SHT}")
     e(f"v_mov_b32_e32 v{V_LC}, v{V_WL2}")
     e(f"v_mov_b32_e32 v{V_TC}, v{V_WT2}")
-    t = [V_X + 16, V_X + 17, V_X + 18, V_X + 19]
-    for stream, (lo, hi) in enumerate(((V_LL, V_LH), (V_TL, V_TH))):
-        for d in range(8):            # dword d holds steps 4d..4d+3, one byte (= genotype*8) each
-            src = lo if d < 4 else hi
-            o = 8 * (d % 4)
-            dst = V_X + 8 * stream + d
-            for i in range(4):
-                e(f"v_bfe_u32 v{t[i]}, v{src}, {o + 2 * i}, 2")
-            e(f"v_lshl_or_b32 v{t[0]}, v{t[1]}, 8, v{t[0]}")
-            e(f"v_lshl_or_b32 v{t[2]}, v{t[3]}, 8, v{t[2]}")
-            e(f"v_lshl_or_b32 v{dst}, v{t[2]}, 16, v{t[0]}")
-            e(f"v_lshlrev_b32_e32 v{dst}, 3, v{dst}")
-    base = slot * EXP_SLOT             # V_LANE32P holds EXP_BASE + lane*32
-    for stream, area in enumerate((E_EXPL, E_EXPT)):
-        for h in range(2):
-            g.lds(f"ds_write_b128 v{V_LANE32P}, {quad(V_X + 8 * stream + 4 * h)} offset:{base + area + 16 * h}")
+    t = [V_X + 8 + i for i in range(8)]          # scratch: g_in 0-3, g_out 4-7
+    for d in range(8):                            # dword d holds steps 4d..4d+3
+        lsrc, tsrc = (V_LL, V_TL) if d < 4 else (V_LH, V_TH)
+        o = 8 * (d % 4)
+        dst = V_X + d
+        for i in range(4):
+            e(f"v_bfe_u32 v{t[i]}, v{lsrc}, {o + 2 * i}, 2")
+            e(f"v_bfe_u32 v{t[4 + i]}, v{tsrc}, {o + 2 * i}, 2")
+        for i in range(4):
+            e(f"v_lshl_or_b32 v{t[i]}, v{t[4 + i]}, 2, v{t[i]}")      # 4 * g_out + g_in
+        e(f"v_lshl_or_b32 v{t[0]}, v{t[1]}, 8, v{t[0]}")
+        e(f"v_lshl_or_b32 v{t[2]}, v{t[3]}, 8, v{t[2]}")
+        e(f"v_lshl_or_b32 v{dst}, v{t[2]}, 16, v{t[0]}")
+        e(f"v_lshlrev_b32_e32 v{dst}, 4, v{dst}")
+    for h in range(2):                            # V_LANE32P holds EXP_BASE + lane*32
+        g.lds(f"ds_write_b128 v{V_LANE32P}, {quad(V_X + 4 * h)} offset:{s4 * EXP_SLOT + 16 * h}")
+
+
+def comb_build(g, slot):
+    """COMB wave: the 32 step tables of the tile whose raw term rows live in TAB slot `slot`:
+    entry (g_out, g_in) = {t_out[g_out], t_in[g_in]}, 16 entries x 16 B per step, 8 entries per
+    lane (lane -> step (lane >> 4) + 4*kk, entry lane & 15)."""
+    s4 = slot % NEXP
+    tb = TAB_BASE + slot * TAB_SLOT
+    rd = []
+    for kk in range(8):
+        g.lds(f"ds_read_b64 {pair(V_CB + 4 * kk)}, v{V_CT} offset:{tb + T_TTAB + 128 * kk}")
+        rd.append(g.lds(f"ds_read_b64 {pair(V_CB + 4 * kk + 2)}, v{V_CL} offset:{tb + T_LTAB + 128 * kk}"))
+    for kk in range(8):                           # V_CW holds lane*16: entry e = lane + 64*kk
+        g.wait_lds(rd[kk])
+        g.lds(f"ds_write_b128 v{V_CW}, {quad(V_CB + 4 * kk)} offset:{COMB_BASE + s4 * COMB_SLOT + 1024 * kk}")
 
 
 # ------------------------------------------------------------------ POST
@@ -484,9 +519,9 @@ def gen_post(g):
 
 # ------------------------------------------------------------------ PRE
 def pre_tile(g, slot, uid):
-    """PRE, iteration k: once CHAIN has finished tile k its ring slot is free -> request tile
-    k+NSLOT into it; the inputs requested NFLY iterations ago (tile k+NSLOT-NFLY) have landed ->
-    expand them."""
+    """PRE, iteration k: once CHAIN has finished tile k its TAB slot is free -> request tile
+    k+NSLOT into it; the rows requested NFLY iterations ago (tile k+NSLOT-NFLY) have landed ->
+    tell COMB; expand tile k+ELEAD."""
     e = g.emit
     e(f"PRE_POLL_{uid}_%=:")
     e(f"ds_read_b32 v{V_TMP0}, v{V_FLAG}")
@@ -500,13 +535,17 @@ def pre_tile(g, slot, uid):
     g.drained()
     gen_prefetch(g, slot, slot % CHPERIOD == 0)
     e(f"s_waitcnt vmcnt({loads_in_flight(slot)})")
-    post_expand(g, (slot + NSLOT - NFLY) % NSLOT)
+    e(f"s_add_u32 s{S_F1}, s{S_K}, {NSLOT - NFLY + 1}")
+    e(f"s_max_u32 s{S_F1}, s{S_F1}, {NSLOT}")
+    e(f"v_mov_b32_e32 v{V_TMP1}, s{S_F1}")
+    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP1} offset:16")  # tabs_landed = tiles 0 .. k+NSLOT-NFLY (a count)
+    post_expand(g, (slot + ELEAD) % NSLOT)
     e(f"s_add_u32 s{S_K}, s{S_K}, 1")
-    e(f"s_add_u32 s{S_F1}, s{S_K}, {NSLOT - NFLY - 1}")
+    e(f"s_add_u32 s{S_F1}, s{S_K}, {ELEAD - 1}")
     e(f"v_mov_b32_e32 v{V_TMP1}, s{S_F1}")
     e("s_waitcnt lgkmcnt(0)")
     g.drained()
-    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP1} offset:8")   # inputs_ready = k + NSLOT - NFLY
+    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP1} offset:8")   # inputs_ready = k + ELEAD
 
 
 def gen_pre(g):
@@ -541,11 +580,13 @@ def gen_pre(g):
         gen_prefetch(g, slot, False)
     e("s_waitcnt vmcnt(0)")
     g.drained()
-    for slot in range(NSLOT - NFLY):  # tiles 0..NSLOT-NFLY-1 expanded up front; the loop stays ahead
+    e(f"v_mov_b32_e32 v{V_TMP1}, {NSLOT}")
+    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP1} offset:16")      # tabs_landed: NSLOT tiles (0 = none yet)
+    for slot in range(ELEAD):  # tiles 0..ELEAD-1 prepared up front; the loop stays ELEAD ahead
         post_expand(g, slot)
     e("s_waitcnt lgkmcnt(0)")
     g.drained()
-    e(f"v_mov_b32_e32 v{V_TMP0}, {NSLOT - NFLY - 1}")
+    e(f"v_mov_b32_e32 v{V_TMP0}, {ELEAD - 1}")
     e(f"ds_write_b32 v{V_FLAG}, v{V_TMP0} offset:8")
     e("PRE_LOOP_%=:")
     for idx in range(NSLOT):
@@ -560,6 +601,62 @@ def gen_pre(g):
     e("s_branch DONE_%=")
 
 
+# ------------------------------------------------------------------ COMB
+def comb_tile(g, slot, uid):
+    """COMB, tile t (unrolled position t % NSLOT): wait for its raw term rows (PRE's tabs_landed)
+    and for the COMB slot (tile t - NEXP consumed by CHAIN), build, publish comb_ready = t"""
+    e = g.emit
+    e(f"COMB_POLL_{uid}_%=:")
+    e(f"ds_read2_b32 v[{V_TMP0}:{V_TMP1}], v{V_FLAG} offset0:0 offset1:4")   # tiles_done, tabs_landed
+    e("s_waitcnt lgkmcnt(0)")
+    e(f"v_readfirstlane_b32 s{S_F0}, v{V_TMP0}")
+    e(f"v_readfirstlane_b32 s{S_F1}, v{V_TMP1}")
+    e(f"s_add_u32 s{S_F0}, s{S_F0}, {NEXP - 1}")
+    e(f"s_cmp_ge_u32 s{S_F0}, s{S_K}")               # tiles_done >= t - (NEXP - 1)
+    e(f"s_cbranch_scc0 COMB_SLEEP_{uid}_%=")
+    e(f"s_cmp_gt_u32 s{S_F1}, s{S_K}")               # tabs_landed (a count) > t
+    e(f"s_cbranch_scc1 COMB_GO_{uid}_%=")
+    e(f"COMB_SLEEP_{uid}_%=:")
+    e("s_sleep 1")
+    e(f"s_branch COMB_POLL_{uid}_%=")
+    e(f"COMB_GO_{uid}_%=:")
+    g.drained()
+    comb_build(g, slot)
+    e(f"v_mov_b32_e32 v{V_TMP1}, s{S_K}")
+    e("s_waitcnt lgkmcnt(0)")
+    g.drained()
+    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP1} offset:12")  # comb_ready = t
+    e(f"s_add_u32 s{S_K}, s{S_K}, 1")
+
+
+def gen_comb(g):
+    e = g.emit
+    e("ROLE_COMB_%=:")
+    e(f"s_mov_b32 s{S_CNT}, %[ntiles]")
+    e(f"s_mov_b32 s{S_K}, 0")
+    e(f"v_mov_b32_e32 v{V_FLAG}, {FLAGS}")
+    # lane -> step (lane >> 4) + 4*kk, entry lane & 15 = 4 * g_out + g_in
+    e(f"v_lshrrev_b32_e32 v{V_CW}, 4, %[lane]")
+    e(f"v_lshlrev_b32_e32 v{V_CW}, 5, v{V_CW}")                 # (lane >> 4) * 32: the step's term row
+    e(f"v_bfe_u32 v{V_CT}, %[lane], 2, 2")
+    e(f"v_lshl_add_u32 v{V_CT}, v{V_CT}, 3, v{V_CW}")           # + g_out * 8
+    e(f"v_and_b32_e32 v{V_CL}, 3, %[lane]")
+    e(f"v_lshl_add_u32 v{V_CL}, v{V_CL}, 3, v{V_CW}")           # + g_in * 8
+    e(f"v_lshlrev_b32_e32 v{V_CW}, 4, %[lane]")                 # entry address lane * 16
+    e("s_barrier")  # CHAIN has reset the counters
+    e("COMB_LOOP_%=:")   # tiles 0 .. ntiles (CHAIN wants tile k+1 ready before it starts tile k)
+    for idx in range(NSLOT):
+        comb_tile(g, idx, idx)
+        e(f"s_cmp_gt_u32 s{S_K}, s{S_CNT}")
+        if idx < NSLOT - 1:
+            e("s_cbranch_scc1 COMB_DONE_%=")
+        else:
+            e("s_cbranch_scc0 COMB_LOOP_%=")
+    e("COMB_DONE_%=:")
+    e("s_waitcnt lgkmcnt(0)")
+    e("s_branch DONE_%=")
+
+
 def gen_all():
     g = Gen()
     e = g.emit
@@ -568,9 +665,12 @@ def gen_all():
     e("s_cbranch_scc1 ROLE_POST_%=")
     e("s_cmp_eq_u32 %[wave], 2")
     e("s_cbranch_scc1 ROLE_PRE_%=")
+    e("s_cmp_eq_u32 %[wave], 3")
+    e("s_cbranch_scc1 ROLE_COMB_%=")
     gen_chain(g)
     gen_post(g)
     gen_pre(g)
+    gen_comb(g)
     e("DONE_%=:")
     e("s_waitcnt lgkmcnt(0)")
     return g.out
@@ -582,7 +682,7 @@ def main():
     path = os.path.join(here, "..", "garlic_amd", "csrc", "chain_loop_gfx950.inc")
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_chain_asm.py -- do not edit; see that file for roles and schedule.\n")
-        f.write("// One inline-asm block: steady-state loop of lod_chain_kernel, 3 waves in 3 roles (gfx950).\n")
+        f.write("// One inline-asm block: steady-state loop of lod_chain_kernel, 4 waves in 4 roles (gfx950).\n")
         f.write(f"#define GARLIC_CHAIN_LDS_TOTAL {LDS_TOTAL}\n")
         f.write(f"#define GARLIC_CHAIN_LDS_TILE0 {TILE_BASE}\n")
         f.write(f"#define GARLIC_CHAIN_NSLOT {NSLOT}\n")

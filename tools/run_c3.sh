@@ -1,0 +1,8 @@
+#!/bin/bash
+cp garlic_amd/libgarlic_hip.so /tmp/orig.so
+for f in build/var/*.so; do
+  cp $f garlic_amd/libgarlic_hip.so
+  r=$(python bench.py --workload c3w100 --steps 3 --warmup 1 --no-cpu 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['roofline']['kernel_ms'], d['roofline']['frac'])")
+  echo "$(basename $f) c3w100 $r"
+done
+cp /tmp/orig.so garlic_amd/libgarlic_hip.so
