@@ -66,3 +66,65 @@ def test_c2_properties_and_sampled_parity(c2_panel, W):
         got = blk[sample].cpu().numpy()
         assert ol.bits_equal(got, want), (W, c)
     assert n_missing == st["n_missing"] and st["n_valid_windows"] + st["n_missing"] == spec.nloci
+
+
+def test_variants_200k_by_1000_sampled_parity(gpu_ctx):
+    """wLOD (LD weights computed on the device from a 100-individual subsample) and TGLS at a size
+    where every kernel runs many workgroups per CU: sampled individuals bit for bit, mask and
+    idempotence over the whole output"""
+    import torch
+    nloci, nind, W, mg = 200_000, 1000, 100, 200000
+    spec = synth.PanelSpec(nloci, seed=20260105, max_gap=mg)
+    dev = torch.device("cuda", 0)
+    sample = [0, 63, 64, 517, 960, 999]
+    geno_s = np.empty((nloci, len(sample)), dtype=np.int16)
+    gl_s = np.empty((nloci, len(sample)), dtype=np.float64)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(11)
+    with abi.Panel(gpu_ctx, spec.chr_nloci, nind) as panel:
+        panel.set_map(spec.pos, spec.centro_start, spec.centro_end, gpos=spec.gpos)
+        panel.set_freq(spec.freq)
+        for l0, g in synth.genotype_chunks(spec, nind, dev):
+            gq = torch.randint(3, 61, g.shape, generator=gen, device=dev).to(torch.float64)
+            gl = torch.pow(torch.tensor(10.0, dtype=torch.float64, device=dev), -gq / 10.0)
+            torch.cuda.synchronize()
+            panel.set_genotypes_device(g.data_ptr(), g.shape[1], l0, g.shape[0])
+            panel.set_gl_device(gl.data_ptr(), gl.shape[1], l0, gl.shape[0])
+            geno_s[l0:l0 + g.shape[0]] = g[:, sample].cpu().numpy()
+            gl_s[l0:l0 + g.shape[0]] = gl[:, sample].cpu().numpy()
+        sub = np.arange(0, nind, 10, dtype=np.int32)
+        ld = panel.compute_ld(W, sub_idx=sub)
+        assert np.isfinite(ld).all() and (ld[: int(spec.chr_nloci[0]) - W + 1] >= 1.0).all()
+        base, pitch, total = panel.out_layout(32, nind)
+        out = torch.empty(total, dtype=torch.float64, device=dev)
+        runs = {
+            "wlod": lambda: panel.wlod_windows_device(out.data_ptr(), W, 0.001, mg, 7, 1e-9),
+            "tgls": lambda: panel.lod_windows_device(out.data_ptr(), W, 0.001, mg, use_gl=True),
+        }
+        for name, call in runs.items():
+            out.fill_(float("nan"))
+            torch.cuda.synchronize()
+            call()
+            torch.cuda.synchronize()
+            first = out.clone()
+            out.fill_(float("nan"))
+            torch.cuda.synchronize()
+            call()
+            torch.cuda.synchronize()
+            for c in range(spec.nchr):
+                n = int(spec.chr_nloci[c])
+                lo, hi = int(spec.chr_off[c]), int(spec.chr_off[c + 1])
+                blk = out[base[c]: base[c] + nind * pitch[c]].view(nind, pitch[c])[:, :n]
+                ref = first[base[c]: base[c] + nind * pitch[c]].view(nind, pitch[c])[:, :n]
+                assert torch.equal(blk.contiguous().view(torch.int64), ref.contiguous().view(torch.int64)), (name, c)
+                valid = ol.oracle_mask(spec.pos[lo:hi], int(spec.centro_start[c]), int(spec.centro_end[c]), W, mg)
+                miss = blk == ol.MISSING
+                assert bool((miss == miss[0:1]).all()) and np.array_equal(~miss[0].cpu().numpy(), valid.astype(bool))
+                g = np.ascontiguousarray(geno_s[lo:hi])
+                args = (spec.freq[lo:hi], spec.pos[lo:hi])
+                cen = (int(spec.centro_start[c]), int(spec.centro_end[c]))
+                if name == "wlod":
+                    want = ol.oracle_calc_wlod(g, *args, spec.gpos[lo:hi], ld[lo:hi], *cen, W, 0.001, mg, 1e-9, 7)
+                else:
+                    want = ol.oracle_calc_lod(g, *args, *cen, W, 0.001, mg, gl=np.ascontiguousarray(gl_s[lo:hi]))
+                assert ol.bits_equal(blk[sample].cpu().numpy(), want), (name, c)
