@@ -632,6 +632,110 @@ int interpolateGeneticmap(std::vector<MapData *> *maps, std::vector<GenMapScaffo
     return interpolated;
 }
 
+// ------------------------------------------------------------------------- genotype cache
+namespace {
+const char CACHE_MAGIC[8] = {'G', 'A', 'R', 'L', 'I', 'C', '2', 'B'};
+const uint32_t CACHE_VERSION = 1;
+
+struct CacheOut {
+    FILE *f;
+    explicit CacheOut(const std::string &p) : f(fopen(p.c_str(), "wb")) { if (!f) fail("cannot write " + p); }
+    ~CacheOut() { if (f) fclose(f); }
+    void put(const void *p, size_t n) { if (n && fwrite(p, 1, n, f) != n) fail("short write to genotype cache"); }
+    template <class T> void val(T v) { put(&v, sizeof v); }
+    void str(const std::string &s) { val<uint32_t>((uint32_t)s.size()); put(s.data(), s.size()); }
+};
+struct CacheIn {
+    FILE *f;
+    explicit CacheIn(const std::string &p) : f(fopen(p.c_str(), "rb")) { if (!f) fail("cannot read " + p); }
+    ~CacheIn() { if (f) fclose(f); }
+    void get(void *p, size_t n) { if (n && fread(p, 1, n, f) != n) fail("genotype cache is truncated"); }
+    template <class T> T val() { T v; get(&v, sizeof v); return v; }
+    std::string str()
+    {
+        const uint32_t n = val<uint32_t>();
+        if (n > (1u << 20)) fail("genotype cache is corrupt (string length)");
+        std::string s(n, '\0');
+        get(&s[0], n);
+        return s;
+    }
+};
+} // namespace
+
+void writeGenotypeCache(const std::string &path, std::vector<HapData *> *haps, std::vector<MapData *> *maps,
+                        std::vector<FreqData *> *freqs)
+{
+    CacheOut o(path);
+    const int nind = haps->at(0)->nind;
+    o.put(CACHE_MAGIC, 8);
+    o.val<uint32_t>(CACHE_VERSION);
+    o.val<uint32_t>((uint32_t)nind);
+    o.val<uint32_t>((uint32_t)maps->size());
+    const size_t row = ((size_t)nind + 3) / 4;
+    std::vector<uint8_t> bits(row);
+    for (size_t c = 0; c < maps->size(); c++) {
+        const MapData *m = maps->at(c);
+        const HapData *h = haps->at(c);
+        o.str(m->chr);
+        o.val<uint32_t>((uint32_t)m->nloci);
+        o.put(m->physicalPos, sizeof(int) * m->nloci);
+        o.put(m->geneticPos, sizeof(double) * m->nloci);
+        o.put(m->allele, (size_t)m->nloci);
+        o.put(freqs->at(c)->freq, sizeof(double) * m->nloci);
+        for (int l = 0; l < m->nloci; l++) o.str(m->locusName[l]);
+        for (int l = 0; l < m->nloci; l++) {
+            std::fill(bits.begin(), bits.end(), 0);
+            for (int i = 0; i < nind; i++) {
+                const short g = h->data[l][i];
+                const unsigned code = (g == 0 || g == 1 || g == 2) ? (unsigned)g : 3u;   // -9 = missing
+                bits[i >> 2] |= (uint8_t)(code << (2 * (i & 3)));
+            }
+            o.put(bits.data(), row);
+        }
+    }
+}
+
+void loadGenotypeCache(const std::string &path, int &numLoci, int &numInd, std::vector<HapData *> **haps,
+                       std::vector<MapData *> **maps, std::vector<FreqData *> **freqs)
+{
+    CacheIn in(path);
+    char magic[8];
+    in.get(magic, 8);
+    if (memcmp(magic, CACHE_MAGIC, 8) != 0) fail(path + " is not a GARLIC genotype cache");
+    if (in.val<uint32_t>() != CACHE_VERSION) fail(path + ": unsupported genotype cache version");
+    const int nind = (int)in.val<uint32_t>();
+    const uint32_t nchr = in.val<uint32_t>();
+    if (nind < 1 || nchr < 1 || nchr > 100000) fail(path + ": corrupt genotype cache header");
+    *haps = new std::vector<HapData *>;
+    *maps = new std::vector<MapData *>;
+    *freqs = new std::vector<FreqData *>;
+    const size_t row = ((size_t)nind + 3) / 4;
+    std::vector<uint8_t> bits(row);
+    static const short DECODE[4] = {0, 1, 2, -9};
+    numLoci = 0;
+    for (uint32_t c = 0; c < nchr; c++) {
+        const std::string chr = in.str();
+        const int n = (int)in.val<uint32_t>();
+        MapData *m = initMapData(n);
+        m->chr = chr;
+        in.get(m->physicalPos, sizeof(int) * n);
+        in.get(m->geneticPos, sizeof(double) * n);
+        in.get(m->allele, (size_t)n);
+        FreqData *f = initFreqData(n);
+        in.get(f->freq, sizeof(double) * n);
+        for (int l = 0; l < n; l++) m->locusName[l] = in.str();
+        HapData *h = new HapData{new short *[n], nind, n};
+        for (int l = 0; l < n; l++) {
+            in.get(bits.data(), row);
+            short *d = h->data[l] = new short[nind];
+            for (int i = 0; i < nind; i++) d[i] = DECODE[(bits[i >> 2] >> (2 * (i & 3))) & 3];
+        }
+        (*maps)->push_back(m); (*haps)->push_back(h); (*freqs)->push_back(f);
+        numLoci += n;
+    }
+    numInd = nind;
+}
+
 // ------------------------------------------------------------------------- the path
 void setLodOptions(const LodOptions &o) { g_options = o; }
 

@@ -139,6 +139,17 @@ int filterMonomorphicAndOOBSites(std::vector<MapData *> **mapDataByChr, std::vec
                                  std::vector<GenMapScaffold *> *scaffoldMapByChr, bool USE_GL);
 int interpolateGeneticmap(std::vector<MapData *> *mapDataByChr, std::vector<GenMapScaffold *> *scaffoldMapByChr);
 
+// Binary sidecar of what loadTPEDData produces: parsing a 10M x 10k TPED is ~400 GB
+// of text and dwarfs the GPU time; the cache holds the same genotypes at 2 bits each (4 per byte,
+// SNP-major; 3 = missing), positions, genetic positions, locus names, counted alleles and
+// frequencies, and loads at memory speed.  Same (hap, map, freq) triple as the TPED path, so
+// everything downstream is unchanged.  `throw 0` on I/O or format errors.
+void writeGenotypeCache(const std::string &path, std::vector<HapData *> *hapDataByChr,
+                        std::vector<MapData *> *mapDataByChr, std::vector<FreqData *> *freqDataByChr);
+void loadGenotypeCache(const std::string &path, int &numLoci, int &numInd,
+                       std::vector<HapData *> **hapDataByChr, std::vector<MapData *> **mapDataByChr,
+                       std::vector<FreqData *> **freqDataByChr);
+
 // ---- the path (drop-in signatures)
 struct LodOptions {
     std::vector<int> devices;   // HIP device ordinals; empty = {0}.  Individuals shard contiguously.

@@ -21,7 +21,7 @@ using namespace garlic_host;
 namespace {
 struct Args {
     std::string tped, tfam, out = "outfile", build = "none", centromere = "none", tgls = "none",
-                gl_type = "none", freq_file = "none", map = "none";
+                gl_type = "none", freq_file = "none", map = "none", cache = "none";
     char tped_missing = '0';       // src/garlic-cli.cpp:114
     double error = -1;             // :34 (must be in (0,1) unless TGLS)
     int winsize = 0;               // :38
@@ -42,7 +42,7 @@ struct Args {
                  "         [--auto-winsize] [--auto-winsize-step N] [--max-gap N] [--overlap-frac X]\n"
                  "         [--freq-file F] [--tped-missing C] [--raw-lod] [--kde-subsample N] [--no-kde-thinning]\n"
                  "         [--weighted --map F --M N --mu X --ld-subsample N --ld-seed S --threads N]\n"
-                 "         [--gpus N | --devices 0,1,...]\n";
+                 "         [--gpus N | --devices 0,1,...] [--genotype-cache F]\n";
     exit(1);
 }
 
@@ -61,6 +61,7 @@ Args parse(int argc, char **argv)
         else if (f == "--gl-type") a.gl_type = val();
         else if (f == "--freq-file") a.freq_file = val();
         else if (f == "--map") a.map = val();
+        else if (f == "--genotype-cache") a.cache = val();   // extension: binary sidecar of the parsed TPED
         else if (f == "--tped-missing") a.tped_missing = val()[0];
         else if (f == "--error") a.error = atof(val().c_str());
         else if (f == "--winsize") a.winsize = atoi(val().c_str());
@@ -121,7 +122,18 @@ int main(int argc, char **argv)
         centromere centro(a.build, a.centromere, "none");
         int numLoci = 0, numInd = 0;
         std::vector<HapData *> *haps; std::vector<MapData *> *maps; std::vector<FreqData *> *freqs;
-        loadTPEDData(a.tped, numLoci, numInd, &haps, &maps, &freqs, a.tped_missing);
+        FILE *probe = a.cache == "none" ? nullptr : fopen(a.cache.c_str(), "rb");
+        if (probe) {   // parsed before: load the 2-bit sidecar instead of the text
+            fclose(probe);
+            loadGenotypeCache(a.cache, numLoci, numInd, &haps, &maps, &freqs);
+            std::cerr << "Loaded genotype cache " << a.cache << "\n";
+        } else {
+            loadTPEDData(a.tped, numLoci, numInd, &haps, &maps, &freqs, a.tped_missing);
+            if (a.cache != "none") {
+                writeGenotypeCache(a.cache, haps, maps, freqs);
+                std::cerr << "Wrote genotype cache " << a.cache << "\n";
+            }
+        }
         std::string pop;
         int nindFam = 0;
         scanIndData3(a.tfam, nindFam, pop);

@@ -129,3 +129,18 @@ def test_sharded_run_equals_single_device(tmp_path):
             for n in names:
                 assert filecmp.cmp(outs[0] + n, other + n, shallow=False), (n, other)
 
+
+def test_genotype_cache_gives_identical_outputs(tmp_path):
+    """second run from the 2-bit sidecar (no TPED parse) writes byte-identical freq, raw-LOD and feed files"""
+    import filecmp
+    cache = str(tmp_path / "tiny.g2b")
+    outs = []
+    for k in range(2):
+        d = tmp_path / f"c{k}"
+        d.mkdir()
+        outs.append(run_tool(d, "--winsize", "30", "--raw-lod", "--genotype-cache", cache))
+    names = sorted(os.path.basename(p)[len("mine"):] for p in glob.glob(outs[0] + "*"))
+    assert len(names) >= 5
+    for n in names:
+        assert filecmp.cmp(outs[0] + n, outs[1] + n, shallow=False), n
+

@@ -37,3 +37,21 @@ def test_no_gpu_is_a_loud_failure(tmp_path):
     assert r.returncode != 0
     assert "Loaded 6000 loci x 24 individuals (3 chromosomes)" in r.stderr   # ingest ran
     assert "no HIP device" in r.stderr or "garlic_ctx_create" in r.stderr
+
+
+def test_genotype_cache_round_trip_without_gpu(tmp_path):
+    """--genotype-cache: the first run parses the TPED and writes the 2-bit sidecar, the second loads it
+    (same loci x individuals x chromosomes); ingest is host code, so this runs without a GPU too"""
+    cache = str(tmp_path / "tiny.g2b")
+    args = [*BASE, "--centromere", os.path.join(E2E, "tiny.centromeres.txt"), "--error", "0.001",
+            "--winsize", "30", "--out", str(tmp_path / "x"), "--genotype-cache", cache]
+    r1 = run(*args)
+    assert "Wrote genotype cache" in r1.stderr and os.path.getsize(cache) > 6000 * 6
+    r2 = run(*args)
+    assert "Loaded genotype cache" in r2.stderr and "Wrote genotype cache" not in r2.stderr
+    assert "Loaded 6000 loci x 24 individuals (3 chromosomes)" in r2.stderr
+    # a truncated cache is refused, not half-read
+    with open(cache, "r+b") as f:
+        f.truncate(os.path.getsize(cache) // 2)
+    r3 = run(*args)
+    assert r3.returncode != 0 and "truncated" in r3.stderr
