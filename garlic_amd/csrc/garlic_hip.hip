@@ -453,7 +453,11 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     }
     // tuned wLOD kernel: one LDS score row per SNP (needs the plain --error table) and R = 16
     // window accumulators per lane; TGLS-weighted and very narrow windows keep the generic kernel
-    const size_t wlod_lds = sizeof(double) * (size_t)(W + TILE) * 4;
+    // transposed write-out patch only while rows + patch keep 8 workgroups (32 waves) on a CU
+    const size_t wlod_rows = sizeof(double) * (size_t)(W + TILE) * 4;
+    const size_t wlod_patch = sizeof(double) * (size_t)WAVE * WT_PITCH;
+    const bool wlod_use_patch = wlod_rows + 16 + wlod_patch <= 160 * 1024 / 8;
+    const size_t wlod_lds = wlod_rows + 16 + (wlod_use_patch ? wlod_patch : 0);   // 16: the patch lock
     const bool wlod_fast = mode == MODE_WLOD && !use_gl && W >= WLOD_R && W + 64 <= GPAD_BACK &&
                            !getenv("GARLIC_WLOD_GENERIC");
     if (wlod_fast && (rc = ensure_score_rows(p, error, M, mu, W))) return rc;
@@ -559,7 +563,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     if (wlod_fast) {
         const int nquad = (nblk + WLOD_WAVES - 1) / WLOD_WAVES;
         WlodArgs a{p->d_valid.p, p->d_chrs.p, p->d_tiles.p, p->nwordrows, p->nchr, ind_begin, ind_count, W, nquad,
-                   (uint32_t)((int64_t)p->plan.n_tiles * nquad)};
+                   (uint32_t)((int64_t)p->plan.n_tiles * nquad), wlod_use_patch ? 1 : 0};
         const uint32_t *a_packed = p->d_packed.p;
         const double *a_wtab = p->d_wtab.p, *a_skew = p->d_skew.p + SKEW_FRONT;
         const unsigned wl_grid = (a.n_work + 7u) / 8u * 8u;

@@ -262,7 +262,8 @@ wlod_kernel(VariantArgs p, int ring)
 //   transposed through LDS so that every store covers whole row segments, and windows that hold
 //   no score (mask byte 0) are written as MISSING by the same store: no separate fill pass.
 constexpr int WLOD_R = 16;   // window accumulators per lane (weights of one step: 32 SGPRs)
-constexpr int WLOD_WAVES = 4;  // waves (64-individual blocks) per workgroup
+constexpr int WLOD_WAVES = 4;  // waves (64-individual blocks) per workgroup (8 was measured slower)
+constexpr int WT_PITCH = 18;   // doubles per row of the write-out patch (16 + pad, 16-B aligned rows)
 constexpr int SKEW_FRONT = 16; // doubles of padding in front of the skewed weight table
 
 struct WlodArgs {
@@ -272,6 +273,7 @@ struct WlodArgs {
     int64_t nwordrows;
     int32_t nchr, ind_begin, ind_count, winsize, nquad;   // nquad = workgroups per tile
     uint32_t n_work;           // tiles x nquad
+    int32_t use_patch;         // transposed write-out through the LDS patch (allocated then)
 };
 
 // Ordered sums of windows s .. s+15 for this lane's individual: acc[r] = sum_j sc[s+r+j] * D[s+r+j][j],
@@ -320,6 +322,9 @@ wlod_tile_kernel(const uint32_t *__restrict__ packed,
     const int lane = threadIdx.x & (WAVE - 1), W = p.winsize;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *rows = dyn;                                   // [W + TILE][4]
+    int *patch_lock = reinterpret_cast<int *>(dyn + (size_t)((W + TILE) * 4));
+    double *patch = dyn + (size_t)((W + TILE) * 4) + 2;   // [64][WT_PITCH] write-out patch (shared; optional)
+    if (threadIdx.x == 0) *patch_lock = 0;                // ordered by the barrier below / first use
     // Workgroups go round-robin over the 8 XCDs (one L2 each): give every XCD one contiguous
     // range of the work, so that the 64-individual blocks of a tile -- same weights, same score
     // rows -- meet in one L2.
@@ -341,13 +346,9 @@ wlod_tile_kernel(const uint32_t *__restrict__ packed,
         const double2 *src = reinterpret_cast<const double2 *>(wtab + G0 * 4);
         double2 *dst = reinterpret_cast<double2 *>(rows);
         for (int k = threadIdx.x; k < (W + TILE - 1) * 2; k += WLOD_WAVES * WAVE) dst[k] = src[k];
-        __syncthreads();
     }
+    __syncthreads();
     if (!active) return;
-    // Each lane writes its own row, 16 contiguous bytes per store; the 8 stores of a group land
-    // in the same 128-B line of that row and merge in L2.  (Measured alternatives, none faster:
-    // transposing through LDS to 64-B row pieces, non-temporal stores -- 3x slower, they defeat the
-    // L2 merge --, deferring the stores behind the next group's first loads.)
     const bool row_ok = ind0 + lane < p.ind_count;
     double *out_row = out + c.out_base + (int64_t)(ind0 + lane) * c.out_pitch + s0;
 #pragma unroll 1
@@ -360,15 +361,51 @@ wlod_tile_kernel(const uint32_t *__restrict__ packed,
         // windows without a score are MISSING (garlic-roh.cpp:232)
 #pragma unroll
         for (int r = 0; r < R; r++) acc[r] = (gm != 0 && ((gm >> r) & 1u)) ? acc[r] : MISSING_D;
-        if (!row_ok) continue;
         const int sg = s0 + grp * R;
+        if (ALIGNED16 && p.use_patch) {
+            // Write-out: 128 contiguous bytes per row and instruction, non-temporal, transposed
+            // through ONE LDS patch [64][WT_PITCH] per workgroup that its waves take turns on
+            // (a patch per wave would cost the occupancy the scalar weight loads need; 16 B per
+            // lane and row straight from registers left 0.45 ms of L2 write-back work per 1.6 GB).
+            // The host enables it while score rows + patch still allow 8 waves per SIMD.
+            if (lane == 0)
+                while (atomicCAS(patch_lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < R; r += 2) {
-            if (ALIGNED16 && sg + r + 1 < c.nloci) {
-                *reinterpret_cast<double2 *>(out_row + grp * R + r) = make_double2(acc[r], acc[r + 1]);
-            } else {
-                if (sg + r < c.nloci) out_row[grp * R + r] = acc[r];
-                if (sg + r + 1 < c.nloci) out_row[grp * R + r + 1] = acc[r + 1];
+            for (int r = 0; r < R; r += 2)
+                *reinterpret_cast<double2 *>(patch + lane * WT_PITCH + r) = make_double2(acc[r], acc[r + 1]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int cc = 2 * (lane & 7);
+            double *out_blk = out + c.out_base + (int64_t)ind0 * c.out_pitch + s0 + grp * R + cc;
+            const double *prow = patch + (lane >> 3) * WT_PITCH + cc;
+            double *dst = out_blk + (int64_t)(lane >> 3) * c.out_pitch;
+#pragma unroll 1
+            for (int q = 0; q < 8; q++, prow += 8 * WT_PITCH, dst += 8 * c.out_pitch) {
+                // (one row piece at a time, rolled: registers are what buys occupancy here)
+                const int rrow = 8 * q + (lane >> 3);
+                const double2 v = *reinterpret_cast<const double2 *>(prow);
+                if (ind0 + rrow >= p.ind_count) continue;
+                if (sg + cc + 1 < c.nloci) {
+                    __builtin_nontemporal_store(v.x, dst);
+                    __builtin_nontemporal_store(v.y, dst + 1);
+                } else if (sg + cc < c.nloci) {
+                    dst[0] = v.x;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) atomicExch(patch_lock, 0);
+        } else if (row_ok) {   // wide windows, dense / unaligned layouts: each lane writes its own row
+#pragma unroll
+            for (int r = 0; r < R; r += 2) {
+                if (ALIGNED16 && sg + r + 1 < c.nloci) {
+                    *reinterpret_cast<double2 *>(out_row + grp * R + r) = make_double2(acc[r], acc[r + 1]);
+                } else {
+                    if (sg + r < c.nloci) out_row[grp * R + r] = acc[r];
+                    if (sg + r + 1 < c.nloci) out_row[grp * R + r + 1] = acc[r + 1];
+                }
             }
         }
     }
