@@ -45,19 +45,30 @@ __device__ __forceinline__ double variant_term(const VariantArgs &p, int64_t G, 
     return p.tab[G * 4 + g];
 }
 
-// masked transposed store of one 32-step tile held in LDS (64 rows x TPITCH doubles)
+// masked transposed store of one 32-step tile held in LDS (64 rows x TPITCH doubles): 4 rows x 256
+// contiguous bytes per instruction; one non-temporal 16-B store per lane where the layout allows
+// (8-B-per-lane stores block the issuing wave ~100 cycles each -- and one wave works through a
+// run's tiles one after the other, so that is on the kernel's critical path)
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void variant_store(const double *tile, int s0, int a, int b, int lane,
                                               int rows_valid, double *out_tile, int64_t pitch)
 {
     const int rsub = lane >> 4, csub = lane & 15;
+    const int s = s0 + 2 * csub;
+    const bool in0 = (s >= a && s <= b), in1 = (s + 1 >= a && s + 1 <= b);
+    const bool al16 = ((reinterpret_cast<uintptr_t>(out_tile) & 15) == 0) && ((pitch & 1) == 0);
     for (int q = 0; q < WAVE / 4; q++) {
         const int r = 4 * q + rsub;
         if (r >= rows_valid) continue;
         const double v0 = tile[r * TPITCH + 2 * csub], v1 = tile[r * TPITCH + 2 * csub + 1];
         double *dst = out_tile + (int64_t)r * pitch + 2 * csub;
-        const int s = s0 + 2 * csub;
-        if (s >= a && s <= b) dst[0] = v0;
-        if (s + 1 >= a && s + 1 <= b) dst[1] = v1;
+        if (al16 && in0 && in1) {
+            f64x2 v = {v0, v1};
+            __builtin_nontemporal_store(v, reinterpret_cast<f64x2 *>(dst));
+        } else {
+            if (in0) dst[0] = v0;
+            if (in1) dst[1] = v1;
+        }
     }
 }
 
@@ -170,13 +181,29 @@ lod_chain_terms_kernel(VariantArgs p, int n_items, int64_t rows, const double *_
         for (int q = 0; q < 32; q++) acc += (l0 + q < a + W - 1) ? t[q] : 0.0;
     }
     double *out_row0 = p.out + c.out_base + (int64_t)it.ind0 * c.out_pitch;
+    // the kernel's time is the longest run's, whose tiles come one after the other: the next tile's
+    // terms are requested before this tile's chain and write-out (pad rows keep it in bounds)
+    double n_in[TILE], n_out[TILE];
+    {
+        const int64_t Gin = Gbase + (a & ~(TILE - 1)) + W - 1, Gout = Gbase + (a & ~(TILE - 1)) - 1;
+#pragma unroll
+        for (int j = 0; j < TILE; j++) {
+            n_in[j] = tcol[(Gin + j) * WAVE];
+            n_out[j] = tcol[(Gout + j) * WAVE];
+        }
+    }
     for (int s0 = a & ~(TILE - 1); s0 <= b; s0 += TILE) {
         const int64_t Gin = Gbase + s0 + W - 1, Gout = Gbase + s0 - 1;
         double t_in[TILE], t_out[TILE];
 #pragma unroll
         for (int j = 0; j < TILE; j++) {
-            t_in[j] = tcol[(Gin + j) * WAVE];
-            t_out[j] = tcol[(Gout + j) * WAVE];
+            t_in[j] = n_in[j];
+            t_out[j] = n_out[j];
+        }
+#pragma unroll
+        for (int j = 0; j < TILE; j++) {
+            n_in[j] = tcol[(Gin + TILE + j) * WAVE];
+            n_out[j] = tcol[(Gout + TILE + j) * WAVE];
         }
 #pragma unroll
         for (int j = 0; j < TILE; j++) {
