@@ -605,7 +605,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                       p->d_items.p,  p->d_chrs.p, d_out,        p->nind_pad,  p->nwordrows, ind_begin,    ind_count,
                       W,             (int32_t)p->gl_values.size(), use_gl ? 1 : 0};
         if (mode == MODE_LOD_GL && p->glterms_valid) {
-            hipLaunchKernelGGL(lod_chain_terms_kernel, dim3((unsigned)n_items), dim3(WAVE), 0, ctx->stream, a,
+            hipLaunchKernelGGL(lod_chain_terms_kernel, dim3((unsigned)n_items), dim3(2 * WAVE), 0, ctx->stream, a,
                                (int)n_items, (int64_t)(GOFF + p->nloci + GPAD_BACK), p->d_glterms.p);
         } else if (mode == MODE_LOD_GL) {
             hipLaunchKernelGGL(lod_chain_gl_kernel, dim3((unsigned)((n_items + GL_WAVES - 1) / GL_WAVES)),

@@ -156,19 +156,44 @@ gl_terms_kernel(VariantArgs p, int64_t nloci, int64_t rows, double *__restrict__
     }
 }
 
-// the chain of lod_chain_gl_kernel with its 64 terms per tile read straight from the term matrix
-// (one round of coalesced 512-B loads per tile)
-__global__ void __launch_bounds__(WAVE)
+// The chain of lod_chain_gl_kernel with its 64 terms per tile read straight from the term matrix
+// (one round of coalesced 512-B loads per tile).  All work items are resident at once, so the
+// kernel lasts as long as the longest run needs for its tiles one after the other; that path is
+// split over two waves: wave 0 loads (one tile ahead) and runs the chain into one of two LDS
+// tiles, wave 1 writes finished tiles out (transposed, 16-B non-temporal stores).  Two counters in
+// LDS (tiles written / tiles stored) instead of barriers, as in the unweighted kernel.
+__global__ void __launch_bounds__(2 * WAVE)
 lod_chain_terms_kernel(VariantArgs p, int n_items, int64_t rows, const double *__restrict__ terms)
 {
-    __shared__ double tile[WAVE * TPITCH];
+    __shared__ double tiles[2][WAVE * TPITCH];
+    __shared__ int flags[2];                               // [0] tiles written, [1] tiles stored
+    volatile int *vflags = flags;
     const int item = blockIdx.x;
     if (item >= n_items) return;
     const ChainItem it = p.items[item];
     if (it.chr < 0) return;
     const ChrDev c = p.chrs[it.chr];
-    const int lane = threadIdx.x, W = p.winsize, a = it.a, b = it.b;
+    const int lane = threadIdx.x & (WAVE - 1), W = p.winsize, a = it.a, b = it.b;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rows_valid = min(WAVE, p.ind_count - it.ind0);
+    double *out_row0 = p.out + c.out_base + (int64_t)it.ind0 * c.out_pitch;
+    if (threadIdx.x == 0) { flags[0] = 0; flags[1] = 0; }
+    __syncthreads();
+    const int first = a & ~(TILE - 1);
+
+    if (wave == 1) {   // ---- write-out
+        int k = 0;
+        for (int s0 = first; s0 <= b; s0 += TILE, k++) {
+            while (vflags[0] <= k) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            variant_store(tiles[k & 1], s0, a, b, lane, rows_valid, out_row0 + s0, c.out_pitch);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) vflags[1] = k + 1;
+        }
+        return;
+    }
+
+    // ---- loads + chain
     const int64_t col = (int64_t)p.ind_begin + it.ind0 + lane;
     const double *tcol = terms + ((col >> 6) * rows) * WAVE + (col & 63);   // term of SNP G at tcol[G * 64]
     const int64_t Gbase = c.loc_base + GOFF;
@@ -180,19 +205,17 @@ lod_chain_terms_kernel(VariantArgs p, int n_items, int64_t rows, const double *_
 #pragma unroll
         for (int q = 0; q < 32; q++) acc += (l0 + q < a + W - 1) ? t[q] : 0.0;
     }
-    double *out_row0 = p.out + c.out_base + (int64_t)it.ind0 * c.out_pitch;
-    // the kernel's time is the longest run's, whose tiles come one after the other: the next tile's
-    // terms are requested before this tile's chain and write-out (pad rows keep it in bounds)
-    double n_in[TILE], n_out[TILE];
+    double n_in[TILE], n_out[TILE];                       // the next tile's terms (pad rows keep it in bounds)
     {
-        const int64_t Gin = Gbase + (a & ~(TILE - 1)) + W - 1, Gout = Gbase + (a & ~(TILE - 1)) - 1;
+        const int64_t Gin = Gbase + first + W - 1, Gout = Gbase + first - 1;
 #pragma unroll
         for (int j = 0; j < TILE; j++) {
             n_in[j] = tcol[(Gin + j) * WAVE];
             n_out[j] = tcol[(Gout + j) * WAVE];
         }
     }
-    for (int s0 = a & ~(TILE - 1); s0 <= b; s0 += TILE) {
+    int k = 0;
+    for (int s0 = first; s0 <= b; s0 += TILE, k++) {
         const int64_t Gin = Gbase + s0 + W - 1, Gout = Gbase + s0 - 1;
         double t_in[TILE], t_out[TILE];
 #pragma unroll
@@ -205,6 +228,9 @@ lod_chain_terms_kernel(VariantArgs p, int n_items, int64_t rows, const double *_
             n_in[j] = tcol[(Gin + TILE + j) * WAVE];
             n_out[j] = tcol[(Gout + TILE + j) * WAVE];
         }
+        while (vflags[1] + 2 <= k) __builtin_amdgcn_s_sleep(1);   // tile buffer k & 1 has been written out
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        double *tile = tiles[k & 1];
 #pragma unroll
         for (int j = 0; j < TILE; j++) {
             const int s = s0 + j;
@@ -214,11 +240,8 @@ lod_chain_terms_kernel(VariantArgs p, int n_items, int64_t rows, const double *_
             acc = (acc - to) + ti;
             tile[lane * TPITCH + j] = acc;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        variant_store(tile, s0, a, b, lane, rows_valid, out_row0 + s0, c.out_pitch);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) vflags[0] = k + 1;
     }
 }
 
