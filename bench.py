@@ -115,10 +115,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    # Rehearsal of the multi-rank path on a one-GPU box (not a measurement): GARLIC_BENCH_REHEARSE=1
+    # puts every rank on cuda:0 and uses gloo for the barrier / max-over-ranks (RCCL refuses two
+    # ranks on one device).
+    rehearse = os.environ.get("GARLIC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     nloci, nind, W, desc = WORKLOADS[args.workload]
@@ -163,7 +172,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
