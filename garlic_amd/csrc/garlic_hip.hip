@@ -148,6 +148,10 @@ struct garlic_panel {
     bool tabgl_valid = false;
     DevBuf<double> d_glterms;                      // TGLS term matrix [blk][GOFF+nloci+pad][64]
     bool glterms_valid = false;
+    DevBuf<double> d_glscores;                     // (term * nomut) * norec, same shape (wLOD with GL)
+    bool glscores_valid = false;
+    int32_t glscores_M = 0;
+    double glscores_mu = 0;
     int tabgl_ncodes = 0;
     // wLOD
     bool have_ld = false, wlod_use_gl = false;
@@ -366,6 +370,30 @@ int ensure_gl_terms(garlic_panel *p)
                        dim3(256), 0, s, a, p->nloci, rows, p->d_glterms.p);
     HIP_TRY(hipGetLastError());
     p->glterms_valid = true;
+    p->glscores_valid = false;
+    return GARLIC_OK;
+}
+
+// ---- wLOD with GL: score matrix (term * nomut) * norec; leaves glscores_valid unset when the term
+// matrix or this one does not fit (the generic kernel runs then)
+int ensure_gl_scores(garlic_panel *p, int32_t M, double mu)
+{
+    int rc;
+    if ((rc = ensure_gl_terms(p))) return rc;
+    if (!p->glterms_valid) return GARLIC_OK;
+    if (p->glscores_valid && p->glscores_M == M && memcmp(&p->glscores_mu, &mu, sizeof mu) == 0) return GARLIC_OK;
+    const int64_t rows = GOFF + p->nloci + GPAD_BACK;
+    const size_t n = (size_t)rows * p->nind_pad;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GARLIC_OK;
+    if (p->d_glscores.cap < n && n * sizeof(double) + ((size_t)8 << 30) > free_b) return GARLIC_OK;
+    if ((rc = p->d_glscores.reserve(n))) return rc;
+    hipLaunchKernelGGL(gl_scores_kernel, dim3(4096), dim3(256), 0, p->ctx->stream, p->d_glterms.p, p->d_decay.p,
+                       rows, (int64_t)n, p->d_glscores.p);
+    HIP_TRY(hipGetLastError());
+    p->glscores_valid = true;
+    p->glscores_M = M;
+    p->glscores_mu = mu;
     return GARLIC_OK;
 }
 
@@ -451,16 +479,20 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
             return fail(GARLIC_ERR_STATE, "wLOD needs LD weights for winsize %d (garlic_panel_set_ld)", W);
         if ((rc = ensure_decay_table(p, M, mu))) return rc;
     }
-    // tuned wLOD kernel: one LDS score row per SNP (needs the plain --error table) and R = 16
-    // window accumulators per lane; TGLS-weighted and very narrow windows keep the generic kernel
+    // tuned wLOD kernels: 16 window accumulators per lane; scores from one LDS row per SNP (plain
+    // --error) or from the TGLS score matrix (use_gl); very narrow / very wide windows keep the
+    // generic kernel
+    const bool wlod_shape_ok = mode == MODE_WLOD && W >= WLOD_R && W + 64 <= GPAD_BACK &&
+                               !getenv("GARLIC_WLOD_GENERIC");
+    if (wlod_shape_ok && use_gl && (rc = ensure_gl_scores(p, M, mu))) return rc;
+    const bool wlod_gl = wlod_shape_ok && use_gl && p->glscores_valid;      // scores from the term matrix
+    const bool wlod_fast = (wlod_shape_ok && !use_gl) || wlod_gl;           // tile kernel, either variant
+    if (wlod_fast && !wlod_gl && (rc = ensure_score_rows(p, error, M, mu, W))) return rc;
     // transposed write-out patch only while rows + patch keep 8 workgroups (32 waves) on a CU
-    const size_t wlod_rows = sizeof(double) * (size_t)(W + TILE) * 4;
+    const size_t wlod_rows = wlod_gl ? 0 : sizeof(double) * (size_t)(W + TILE) * 4;
     const size_t wlod_patch = sizeof(double) * (size_t)WAVE * WT_PITCH;
     const bool wlod_use_patch = wlod_rows + 16 + wlod_patch <= 160 * 1024 / 8;
     const size_t wlod_lds = wlod_rows + 16 + (wlod_use_patch ? wlod_patch : 0);   // 16: the patch lock
-    const bool wlod_fast = mode == MODE_WLOD && !use_gl && W >= WLOD_R && W + 64 <= GPAD_BACK &&
-                           !getenv("GARLIC_WLOD_GENERIC");
-    if (wlod_fast && (rc = ensure_score_rows(p, error, M, mu, W))) return rc;
 
     // Host output: the device always computes into the padded layout the tuned kernels need; the
     // rows are copied out into the caller's (possibly dense) layout by strided D2H copies.
@@ -563,15 +595,23 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     if (wlod_fast) {
         const int nquad = (nblk + WLOD_WAVES - 1) / WLOD_WAVES;
         WlodArgs a{p->d_valid.p, p->d_chrs.p, p->d_tiles.p, p->nwordrows, p->nchr, ind_begin, ind_count, W, nquad,
-                   (uint32_t)((int64_t)p->plan.n_tiles * nquad), wlod_use_patch ? 1 : 0};
+                   (uint32_t)((int64_t)p->plan.n_tiles * nquad), wlod_use_patch ? 1 : 0,
+                   (int64_t)(GOFF + p->nloci + GPAD_BACK)};
         const uint32_t *a_packed = p->d_packed.p;
-        const double *a_wtab = p->d_wtab.p, *a_skew = p->d_skew.p + SKEW_FRONT;
+        const double *a_wtab = wlod_gl ? p->d_glscores.p : p->d_wtab.p, *a_skew = p->d_skew.p + SKEW_FRONT;
         const unsigned wl_grid = (a.n_work + 7u) / 8u * 8u;
-        if (aligned16)
-            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, true>), dim3(wl_grid), dim3(WLOD_WAVES * WAVE), wlod_lds, ctx->stream,
+        const dim3 wl_block(WLOD_WAVES * WAVE);
+        if (wlod_gl && aligned16)
+            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, true, true>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
+                               a_packed, a_wtab, a_skew, d_out, a);
+        else if (wlod_gl)
+            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, false, true>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
+                               a_packed, a_wtab, a_skew, d_out, a);
+        else if (aligned16)
+            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, true, false>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
                                a_packed, a_wtab, a_skew, d_out, a);
         else
-            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, false>), dim3(wl_grid), dim3(WLOD_WAVES * WAVE), wlod_lds, ctx->stream,
+            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, false, false>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
                                a_packed, a_wtab, a_skew, d_out, a);
     } else if (n_items && mode == MODE_LOD) {
         ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p,     p->d_chrs.p,     d_out, p->nind_pad, p->nwordrows,
@@ -785,7 +825,7 @@ int garlic_panel_destroy(garlic_panel *p)
     p->d_blk_offsets.release(); p->d_total.release(); p->d_boundaries.release();
     p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release(); p->d_row_counts.release(); p->d_codes.release(); p->d_tabgl.release();
     p->d_rld.release(); p->d_decay.release(); p->d_stage64.release();
-    p->d_glterms.release(); p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release();
+    p->d_glterms.release(); p->d_glscores.release(); p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release();
     p->d_out.release();
     delete p;
     return GARLIC_OK;

@@ -324,6 +324,7 @@ struct WlodArgs {
     int32_t nchr, ind_begin, ind_count, winsize, nquad;   // nquad = workgroups per tile
     uint32_t n_work;           // tiles x nquad
     int32_t use_patch;         // transposed write-out through the LDS patch (allocated then)
+    int64_t score_rows;        // FROM_SCORES: SNP rows per 64-individual block of the score matrix
 };
 
 // Ordered sums of windows s .. s+15 for this lane's individual: acc[r] = sum_j sc[s+r+j] * D[s+r+j][j],
@@ -357,10 +358,76 @@ __device__ __forceinline__ void wlod_group(const double *rows, const uint32_t *g
                  : GARLIC_WLOD_LOOP_CLOBBERS);
 }
 
-template <int R, bool ALIGNED16>
+// wLOD with per-genotype likelihoods (garlic-roh.cpp:245, USE_GL): the score of (SNP, individual)
+// comes from the TGLS term matrix, scores[blk][G][64] = (term * nomut) * norec (gl_scores_kernel),
+// not from a 4-entry row -- one coalesced 512-B load per step instead of an LDS look-up.  This
+// variant is compiler-scheduled (scores are fetched 8 steps at a time, the weights by the scalar
+// loads hipcc places); the hand-scheduled loop above assumes the LDS look-up.
+typedef const __attribute__((address_space(4))) double *const_f64_ptr;
+
+template <int R>
+__device__ __forceinline__ void wlod_group_scores(const double *scol, int64_t G, const double *Ds, int W,
+                                                  double (&acc)[R])
+{
+    // weights through the constant address space: they never change during the kernel, and only
+    // then does the compiler keep their wave-uniform loads on the scalar path next to the stores
+    const const_f64_ptr Dg = (const_f64_ptr)(uintptr_t)Ds;
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.0;
+    const double *sp = scol + G * WAVE;
+    double up[R - 1];
+#pragma unroll
+    for (int i = 0; i < R - 1; i++) up[i] = sp[i * WAVE];
+#pragma unroll
+    for (int i = 0; i < R - 1; i++) {                      // windows enter one by one
+        const const_f64_ptr Dr = Dg + (int64_t)i * W;
+#pragma unroll
+        for (int r = 0; r <= i; r++) acc[r] += up[i] * Dr[i - r];
+    }
+    int i = R - 1;
+    for (; i + 8 <= W; i += 8) {                           // all R windows take every SNP
+        double sc[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) sc[q] = sp[(i + q) * WAVE];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const const_f64_ptr Dr = Dg + (int64_t)(i + q) * W + (i + q - (R - 1));
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] += sc[q] * Dr[(R - 1) - r];
+        }
+    }
+    for (; i < W; i++) {
+        const double sc = sp[i * WAVE];
+        const const_f64_ptr Dr = Dg + (int64_t)i * W + (i - (R - 1));
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] += sc * Dr[(R - 1) - r];
+    }
+    double dn[R - 1];
+#pragma unroll
+    for (int d = 0; d < R - 1; d++) dn[d] = sp[(W + d) * WAVE];
+#pragma unroll
+    for (int d = 0; d < R - 1; d++) {                      // and leave one by one
+        const const_f64_ptr Dr = Dg + (int64_t)(W + d) * W;
+#pragma unroll
+        for (int r = d + 1; r < R; r++) acc[r] += dn[d] * Dr[W + d - r];
+    }
+}
+
+// scores[i] = (terms[i] * nomut[G]) * norec[G] over the whole term matrix (garlic-roh.cpp:249)
+__global__ void gl_scores_kernel(const double *__restrict__ terms, const double *__restrict__ decay,
+                                 int64_t rows, int64_t n, double *__restrict__ scores)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t G = (i >> 6) % rows;
+        scores[i] = (terms[i] * decay[2 * G]) * decay[2 * G + 1];
+    }
+}
+
+template <int R, bool ALIGNED16, bool FROM_SCORES>
 __global__ void __launch_bounds__(WLOD_WAVES * WAVE) __attribute__((amdgpu_num_vgpr(64)))   // 8 waves per SIMD
 wlod_tile_kernel(const uint32_t *__restrict__ packed,
-                 const double *__restrict__ wtab,   // [GOFF + nloci + pad][4]
+                 const double *__restrict__ wtab,   // [GOFF + nloci + pad][4]; FROM_SCORES: [blk][rows][64]
                  const double *__restrict__ D,      // [nloci + pad][W], D[l][j] = 1.0 / LD[l - j][j]
                  double *__restrict__ out, WlodArgs p)
 {   // the read-only tables are separate __restrict__ arguments: only then are the wave-uniform
@@ -371,9 +438,10 @@ wlod_tile_kernel(const uint32_t *__restrict__ packed,
     // walk the same weights at the same time (scalar-cache hits for all but the first)
     const int lane = threadIdx.x & (WAVE - 1), W = p.winsize;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *rows = dyn;                                   // [W + TILE][4]
-    int *patch_lock = reinterpret_cast<int *>(dyn + (size_t)((W + TILE) * 4));
-    double *patch = dyn + (size_t)((W + TILE) * 4) + 2;   // [64][WT_PITCH] write-out patch (shared; optional)
+    double *rows = dyn;                                   // [W + TILE][4]   (not with FROM_SCORES)
+    const size_t rows_doubles = FROM_SCORES ? 0 : (size_t)((W + TILE) * 4);
+    int *patch_lock = reinterpret_cast<int *>(dyn + rows_doubles);
+    double *patch = dyn + rows_doubles + 2;               // [64][WT_PITCH] write-out patch (shared; optional)
     if (threadIdx.x == 0) *patch_lock = 0;                // ordered by the barrier below / first use
     // Workgroups go round-robin over the 8 XCDs (one L2 each): give every XCD one contiguous
     // range of the work, so that the 64-individual blocks of a tile -- same weights, same score
@@ -392,7 +460,7 @@ wlod_tile_kernel(const uint32_t *__restrict__ packed,
     const int64_t G0 = c.loc_base + GOFF + s0;
     const bool has = lane < TILE && s0 + lane < c.nloci && p.valid[c.loc_base + s0 + lane] != 0;
     const uint32_t vm = (uint32_t)__ballot(has);
-    if (vm != 0) {   // same for every wave of the workgroup
+    if (!FROM_SCORES && vm != 0) {   // same for every wave of the workgroup
         const double2 *src = reinterpret_cast<const double2 *>(wtab + G0 * 4);
         double2 *dst = reinterpret_cast<double2 *>(rows);
         for (int k = threadIdx.x; k < (W + TILE - 1) * 2; k += WLOD_WAVES * WAVE) dst[k] = src[k];
@@ -405,9 +473,14 @@ wlod_tile_kernel(const uint32_t *__restrict__ packed,
     for (int grp = 0; grp < TILE / R; grp++) {
         double acc[R];
         const uint32_t gm = (vm >> (grp * R)) & ((1u << R) - 1u);
-        if (gm != 0)
-            wlod_group<R>(rows + grp * R * 4, gcol, G0 + grp * R,
-                          D + (c.loc_base + s0 + grp * R) * (int64_t)W, W, acc);
+        if (gm != 0) {
+            if (FROM_SCORES)
+                wlod_group_scores<R>(wtab + ((col >> 6) * p.score_rows) * WAVE + (col & 63), G0 + grp * R,
+                                     D + (c.loc_base + s0 + grp * R) * (int64_t)W, W, acc);
+            else
+                wlod_group<R>(rows + grp * R * 4, gcol, G0 + grp * R,
+                              D + (c.loc_base + s0 + grp * R) * (int64_t)W, W, acc);
+        }
         // windows without a score are MISSING (garlic-roh.cpp:232)
 #pragma unroll
         for (int r = 0; r < R; r++) acc[r] = (gm != 0 && ((gm >> r) & 1u)) ? acc[r] : MISSING_D;

@@ -125,6 +125,15 @@ def test_wlod_tile_kernel_shapes(gpu_ctx, W):
             out = panel.wlod_windows(W, 0.001, mg, 7, 1e-9, pitch_align=pa, ind_begin=i0, ind_count=cnt)
             for c in range(len(sizes)):
                 assert ol.bits_equal(np.ascontiguousarray(out[c]), want[c][i0:i0 + cnt]), (pa, i0, c)
+        # the same with per-genotype likelihoods (scores from the TGLS term matrix)
+        err = [rng.choice([1e-16, 1e-3, 0.01, 0.2, 1.0], size=c[0].shape) for c in chroms]
+        panel.set_gl(np.concatenate(err, axis=0))
+        want = [ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, 0.001, mg, 1e-9, 7, gl=err[c])
+                for c, (g, f, p, cs, ce) in enumerate(chroms)]
+        for pa, i0, cnt in ((32, 0, nind), (1, 37, 70)):
+            out = panel.wlod_windows(W, 0.001, mg, 7, 1e-9, pitch_align=pa, ind_begin=i0, ind_count=cnt, use_gl=True)
+            for c in range(len(sizes)):
+                assert ol.bits_equal(np.ascontiguousarray(out[c]), want[c][i0:i0 + cnt]), ("gl", pa, i0, c)
 
 
 def test_kde_feed_flatten_on_device(gpu_ctx):

@@ -41,7 +41,7 @@ def main():
     for l0, g in synth.genotype_chunks(spec, nind, dev):
         torch.cuda.synchronize()
         panel.set_genotypes_device(g.data_ptr(), g.shape[1], l0, g.shape[0])
-        if "tgls" in args.modes:
+        if "tgls" in args.modes or "wlodgl" in args.modes:
             # GQ ~ integer U{3..60}; error = 10^max(-10, -GQ/10)   (garlic-data.cpp:1557)
             gq = torch.randint(3, 61, g.shape, generator=gen, device=dev).to(torch.float64)
             gl = torch.pow(torch.tensor(10.0, dtype=torch.float64, device=dev), -gq / 10.0)
@@ -62,6 +62,8 @@ def main():
             panel.lod_windows_device(out.data_ptr(), W, error, max_gap)
         elif mode == "tgls":
             panel.lod_windows_device(out.data_ptr(), W, error, max_gap, use_gl=True)
+        elif mode == "wlodgl":
+            panel.wlod_windows_device(out.data_ptr(), W, error, max_gap, 7, 1e-9, use_gl=True)
         else:
             panel.wlod_windows_device(out.data_ptr(), W, error, max_gap, 7, 1e-9)
 
