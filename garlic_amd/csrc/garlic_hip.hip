@@ -486,7 +486,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                                !getenv("GARLIC_WLOD_GENERIC");
     if (wlod_shape_ok && use_gl && (rc = ensure_gl_scores(p, M, mu))) return rc;
     const bool wlod_gl = wlod_shape_ok && use_gl && p->glscores_valid;      // scores from the term matrix
-    const bool wlod_fast = (wlod_shape_ok && !use_gl) || wlod_gl;           // tile kernel, either variant
+    bool wlod_fast = (wlod_shape_ok && !use_gl) || wlod_gl;                 // tile kernel, either variant
+    if (wlod_fast && !wlod_gl && sizeof(double) * (size_t)(W + TILE) * 4 + 16 > 150 * 1024) wlod_fast = false;
     if (wlod_fast && !wlod_gl && (rc = ensure_score_rows(p, error, M, mu, W))) return rc;
     // transposed write-out patch only while rows + patch keep 8 workgroups (32 waves) on a CU
     const size_t wlod_rows = wlod_gl ? 0 : sizeof(double) * (size_t)(W + TILE) * 4;
@@ -601,6 +602,13 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         const double *a_wtab = wlod_gl ? p->d_glscores.p : p->d_wtab.p, *a_skew = p->d_skew.p + SKEW_FRONT;
         const unsigned wl_grid = (a.n_work + 7u) / 8u * 8u;
         const dim3 wl_block(WLOD_WAVES * WAVE);
+        if (wlod_lds > 48 * 1024) {
+            const void *fn = wlod_gl ? (aligned16 ? (const void *)wlod_tile_kernel<WLOD_R, true, true>
+                                                  : (const void *)wlod_tile_kernel<WLOD_R, false, true>)
+                                     : (aligned16 ? (const void *)wlod_tile_kernel<WLOD_R, true, false>
+                                                  : (const void *)wlod_tile_kernel<WLOD_R, false, false>);
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlod_lds));
+        }
         if (wlod_gl && aligned16)
             hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, true, true>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
                                a_packed, a_wtab, a_skew, d_out, a);
@@ -654,7 +662,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
             const int ring = W + TILE;
             const size_t lds = sizeof(double) * ((size_t)ring * WAVE + ((W + 1) & ~1) + (size_t)WAVE * TPITCH);
             if (lds > 160 * 1024)
-                return fail(GARLIC_ERR_INVALID, "wLOD kernel of this build supports winsize <= %d", 240);
+                return fail(GARLIC_ERR_INVALID, "wLOD with winsize %d: this build supports 2..240 and 16..4096", W);
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wlod_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(wlod_kernel, dim3((unsigned)n_items), dim3(WAVE), lds, ctx->stream, a,

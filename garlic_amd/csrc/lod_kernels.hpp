@@ -35,7 +35,8 @@ constexpr int WAVE = 64;
 constexpr int TILE = 32;          // window starts per tile (= 256 B of one output row)
 constexpr int TPITCH = 34;        // doubles per LDS tile row: 272 B keeps ds_read_b128 16-B aligned
 constexpr int GOFF = 32;          // pad SNP rows in front of the packed genotypes / term table
-constexpr int GPAD_BACK = 32 * GARLIC_CHAIN_NSLOT + 48 * GARLIC_CHAIN_CHROWS + 64; // pad SNP rows behind: the input rings run NSLOT tiles (+ one genotype chunk) ahead
+constexpr int GPAD_CHAIN = 32 * GARLIC_CHAIN_NSLOT + 48 * GARLIC_CHAIN_CHROWS + 64;
+constexpr int GPAD_BACK = GPAD_CHAIN > 4160 ? GPAD_CHAIN : 4160;   // also: wLOD tiles read W + 63 SNPs past a chromosome end (W <= 4096) // pad SNP rows behind: the input rings run NSLOT tiles (+ one genotype chunk) ahead
 constexpr double MISSING_D = -9999.0;
 
 struct ChrDev {

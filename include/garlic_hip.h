@@ -141,7 +141,9 @@ int garlic_lod_windows(garlic_panel *panel, int32_t winsize, double error, int32
                        int32_t use_gl, int32_t ind_begin, int32_t ind_count, int32_t pitch_align,
                        double *out, int32_t where);
 
-/* calcwLODWindows (src/garlic-roh.cpp:311): gap-weighted wLOD; needs gpos and LD for winsize. */
+/* calcwLODWindows (src/garlic-roh.cpp:311): gap-weighted wLOD; needs gpos and LD for winsize
+ * (garlic_panel_set_ld or garlic_panel_compute_ld).  winsize up to 4096 (above that:
+ * GARLIC_ERR_INVALID; the reference has no limit but no use for such windows either). */
 int garlic_wlod_windows(garlic_panel *panel, int32_t winsize, double error, int32_t max_gap,
                         int32_t use_gl, int32_t M, double mu, int32_t ind_begin, int32_t ind_count,
                         int32_t pitch_align, double *out, int32_t where);

@@ -101,6 +101,30 @@ def test_wlod_random_multichr_with_gl(gpu_ctx):
                 assert ol.bits_equal(np.ascontiguousarray(out[c]), want), (use_gl, c)
 
 
+def test_wlod_wide_window(gpu_ctx):
+    """W = 1500: score rows need > 48 KB of LDS and the reads run 1500 SNPs past chromosome ends"""
+    rng = np.random.default_rng(5)
+    W, nind, mg = 1500, 70, 10 ** 9
+    sizes = [4000, 1600]
+    chroms = [ol.random_panel(rng, n, nind, max_gap=mg, gaps=0) for n in sizes]
+    gpos = [c[2] * 1e-6 for c in chroms]
+    lds = [rng.uniform(1.0, 50.0, size=(n, W)) for n in sizes]
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms],
+                      gpos=np.concatenate(gpos))
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        panel.set_ld(W, np.concatenate(lds, axis=0))
+        out = panel.wlod_windows(W, 0.001, mg, 7, 1e-9, pitch_align=32)
+        for c, (g, f, p, cs, ce) in enumerate(chroms):
+            want = ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, 0.001, mg, 1e-9, 7)
+            assert ol.bits_equal(np.ascontiguousarray(out[c]), want), c
+        # wider than 4096 with windows to compute: refused (chromosome 0 has 4000 SNPs: W = 3990 still runs)
+        panel.set_ld(4200, np.ones((sum(sizes), 4200)))
+        out = panel.wlod_windows(4200, 0.001, mg, 7, 1e-9)     # no chromosome holds a window: all MISSING
+        assert all((o == ol.MISSING).all() for o in out)
+
+
 @pytest.mark.parametrize("W", [15, 16, 17, 31, 100, 250])
 def test_wlod_tile_kernel_shapes(gpu_ctx, W):
     """tuned wLOD kernel (W >= 16; 15 takes the generic one): chromosomes shorter than / equal to /
