@@ -103,3 +103,32 @@ def test_ld_bad_subsample_is_refused(gpu_ctx):
             with pytest.raises(abi.GarlicError) as e:
                 panel.compute_ld(5, sub_idx=np.array(bad, dtype=np.int32))
             assert e.value.code == abi.ERR_INVALID
+
+
+def test_ld_sharded_counts_on_device(gpu_ctx):
+    """the device-resident form of the sharded LD step: int32 count tensors stay on the GPU, are summed
+    there (what an RCCL all-reduce does across GPUs) and finished in place"""
+    import torch
+    rng = np.random.default_rng(12)
+    W, nind = 12, 100
+    chroms = [ol.random_panel(rng, n, nind, max_gap=10 ** 9, gaps=0, miss=0.02) for n in (150, 90)]
+    nloci = sum(c[0].shape[0] for c in chroms)
+    want = oracle_ld(chroms, W)
+    shards = []
+    for lo, hi in ((0, 37), (37, 100)):
+        shard = [(g[:, lo:hi].copy(), f, p, cs, ce) for g, f, p, cs, ce in chroms]
+        panel = make_panel(gpu_ctx, shard, hi - lo)
+        loc = torch.zeros((nloci, 2), dtype=torch.int32, device="cuda")
+        pair = torch.zeros((nloci, W, 2), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        panel.ld_counts_device(W, loc.data_ptr(), pair.data_ptr())
+        shards.append((panel, loc, pair))
+    loc = shards[0][1] + shards[1][1]
+    pair = shards[0][2] + shards[1][2]
+    torch.cuda.synchronize()
+    for panel, _, _ in shards:
+        ld = torch.empty((nloci, W), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        panel.ld_finish_device(W, loc.data_ptr(), pair.data_ptr(), ld.data_ptr())
+        assert same(ld.cpu().numpy(), want)
+        panel.close()
