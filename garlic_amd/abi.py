@@ -25,6 +25,7 @@ SYMBOLS = [
     "garlic_panel_set_ld", "garlic_lod_out_layout", "garlic_lod_windows",
     "garlic_wlod_windows", "garlic_lod_flatten", "garlic_last_call_stats",
     "garlic_panel_compute_ld", "garlic_ld_counts", "garlic_ld_finish", "garlic_roh_coverage",
+    "garlic_lod_feed",
 ]
 
 
@@ -78,6 +79,8 @@ def lib():
     L.garlic_panel_compute_ld.argtypes = [_vp, C.c_int32, _i32p, C.c_int32, _vp, C.c_int32]
     L.garlic_ld_counts.argtypes = [_vp, C.c_int32, _i32p, C.c_int32, _vp, _vp, C.c_int32]
     L.garlic_ld_finish.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, C.c_int32]
+    L.garlic_lod_feed.argtypes = [_vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_double, C.c_int32, _vp, C.c_int64, _i64p, _i64p]
     L.garlic_roh_coverage.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, _vp, C.c_int32,
                                       C.c_int32]
     for name in SYMBOLS:
@@ -295,6 +298,16 @@ class Panel:
         check(lib().garlic_lod_flatten(self.handle, _vp(scores_ptr), pitch_align, nind_out, step,
                                        _vp(feed_ptr) if feed_ptr else None, feed_capacity, C.byref(n)))
         return n.value
+
+    def lod_feed(self, winsize, error, max_gap, step, use_gl=False, weighted=False, M=7, mu=1e-9):
+        """scores + thinning on the device: returns (feed float64 [count], per-chromosome counts)"""
+        cap = int(sum((int(n) + step - 1) // step for n in self.chr_nloci)) * self.nind
+        feed = np.empty(max(cap, 1), dtype=np.float64)
+        n = C.c_int64()
+        per_chr = np.zeros(self.nchr, dtype=np.int64)
+        check(lib().garlic_lod_feed(self.handle, winsize, error, max_gap, int(use_gl), int(weighted), M, mu,
+                                    step, _vp(feed.ctypes.data), cap, C.byref(n), _ptr(per_chr, _i64p)))
+        return feed[: n.value].copy(), per_chr
 
     def roh_coverage(self, scores_ptr, winsize, cutoff, pitch_align=32, nind_out=None):
         """assembleROHWindows' coverage counts of device-resident scores: list of per-chromosome int16

@@ -1186,8 +1186,8 @@ int garlic_wlod_windows(garlic_panel *p, int32_t winsize, double error, int32_t 
                       out, where);
 }
 
-int garlic_lod_flatten(garlic_panel *p, const double *scores, int32_t pitch_align, int32_t nind_out,
-                       int32_t step, double *feed, int64_t feed_capacity, int64_t *count)
+static int flatten_impl(garlic_panel *p, const double *scores, int32_t pitch_align, int32_t nind_out,
+                        int32_t step, double *feed, int64_t feed_capacity, int64_t *count, int64_t *chr_counts)
 {
     if (!p || !scores || !count) return fail(GARLIC_ERR_INVALID, "panel, scores and count are required");
     if (step < 1 || pitch_align < 1 || nind_out < 1)
@@ -1209,6 +1209,11 @@ int garlic_lod_flatten(garlic_panel *p, const double *scores, int32_t pitch_alig
     HIP_TRY(hipMemcpyAsync(counts.data(), p->d_row_counts.p, sizeof(int64_t) * nrows, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     int64_t total = 0; // exclusive scan over (chromosome, individual) rows: tiny, done on the host
+    if (chr_counts)
+        for (int c = 0; c < p->nchr; c++) {
+            chr_counts[c] = 0;
+            for (int i = 0; i < nind_out; i++) chr_counts[c] += counts[(size_t)c * nind_out + i];
+        }
     for (auto &c : counts) { const int64_t n = c; c = total; total += n; }
     *count = total;
     if (total > feed_capacity || total == 0) return GARLIC_OK;
@@ -1219,6 +1224,41 @@ int garlic_lod_flatten(garlic_panel *p, const double *scores, int32_t pitch_alig
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     return GARLIC_OK;
+}
+
+int garlic_lod_flatten(garlic_panel *p, const double *scores, int32_t pitch_align, int32_t nind_out,
+                       int32_t step, double *feed, int64_t feed_capacity, int64_t *count)
+{
+    return flatten_impl(p, scores, pitch_align, nind_out, step, feed, feed_capacity, count, nullptr);
+}
+
+// LOD / wLOD scores and their thinned KDE feed in one call: the scores never leave the device
+int garlic_lod_feed(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
+                    int32_t weighted, int32_t M, double mu, int32_t step, double *feed,
+                    int64_t feed_capacity, int64_t *count, int64_t *chr_counts)
+{
+    if (!p || !count) return fail(GARLIC_ERR_INVALID, "panel and count are required");
+    if (step < 1) return fail(GARLIC_ERR_INVALID, "step must be >= 1");
+    int rc;
+    if ((rc = set_device(p->ctx))) return rc;
+    const Layout L = make_layout(p, 32, p->nind);
+    DevBuf<double> scores, d_feed;   // call-local: a resident 8 B per window would defeat the purpose
+    auto done = [&](int code) { scores.release(); d_feed.release(); return code; };
+    if ((rc = scores.reserve((size_t)L.total))) return done(rc);
+    if (weighted) p->wlod_use_gl = use_gl != 0;
+    rc = launch_lod(p, weighted ? MODE_WLOD : (use_gl ? MODE_LOD_GL : MODE_LOD), winsize, error, max_gap, M, mu, 0,
+                    p->nind, 32, scores.p, GARLIC_DEVICE);
+    if (rc) return done(rc);
+    // at most ceil(nloci_c / step) values per (chromosome, individual)
+    int64_t cap = 0;
+    for (int c = 0; c < p->nchr; c++) cap += ((int64_t)p->chr_nloci[c] + step - 1) / step * p->nind;
+    if ((rc = d_feed.reserve((size_t)std::max<int64_t>(cap, 1)))) return done(rc);
+    if ((rc = flatten_impl(p, scores.p, 32, p->nind, step, d_feed.p, cap, count, chr_counts))) return done(rc);
+    if (*count > feed_capacity || *count == 0) return done(GARLIC_OK);
+    if (!feed) return done(fail(GARLIC_ERR_INVALID, "feed is NULL"));
+    hipError_t e = hipMemcpy(feed, d_feed.p, sizeof(double) * (size_t)*count, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "feed copy-out: %s", hipGetErrorString(e)));
+    return done(GARLIC_OK);
 }
 
 int garlic_roh_coverage(garlic_panel *p, const double *scores, int32_t pitch_align, int32_t nind_out,

@@ -854,6 +854,48 @@ std::vector<WinData *> *LodEngine::wlodWindowsResident(int winsize, double error
     return run(true, winsize, error, MAX_GAP, M, mu);
 }
 
+DoubleData *LodEngine::lodFeed(int winsize, double error, int MAX_GAP, int step, bool weighted, int M, double mu)
+{
+    std::cerr << "Calculating LOD scores with winsize " << winsize << " (thinned on the device, step " << step << ").\n";
+    const int nchr = (int)impl->chr_nloci.size();
+    const size_t ns = impl->shards.size();
+    std::vector<std::vector<double>> feeds(ns);
+    std::vector<std::vector<int64_t>> per_chr(ns, std::vector<int64_t>(nchr, 0));
+    std::vector<std::string> errors(ns);
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < ns; k++)
+        th.emplace_back([&, k] {
+            auto &s = impl->shards[k];
+            int64_t cap = 0, n = 0;
+            for (int c = 0; c < nchr; c++) cap += ((int64_t)impl->chr_nloci[c] + step - 1) / step * s.nind;
+            feeds[k].resize((size_t)std::max<int64_t>(cap, 1));
+            if (garlic_lod_feed(s.panel, winsize, error, MAX_GAP, impl->use_gl, weighted, M, mu, step, feeds[k].data(),
+                                cap, &n, per_chr[k].data()) != GARLIC_OK)
+                errors[k] = garlic_hip_last_error();
+            else
+                feeds[k].resize((size_t)n);
+        });
+    for (auto &t : th) t.join();
+    for (auto &e : errors)
+        if (!e.empty()) fail("garlic_lod_feed: " + e);
+    // merge in the reference's order: chromosome -> individual (= shard order) -> locus
+    int64_t total = 0;
+    for (auto &f : feeds) total += (int64_t)f.size();
+    if (total > 0x7fffffff) fail("KDE feed has more than 2^31 values: DoubleData::size is an int");
+    DoubleData *d = new DoubleData;
+    d->size = (int)total;
+    d->data = new double[total > 0 ? total : 1];
+    std::vector<int64_t> off(ns, 0);
+    int64_t o = 0;
+    for (int c = 0; c < nchr; c++)
+        for (size_t k = 0; k < ns; k++) {
+            memcpy(d->data + o, feeds[k].data() + off[k], sizeof(double) * (size_t)per_chr[k][c]);
+            o += per_chr[k][c];
+            off[k] += per_chr[k][c];
+        }
+    return d;
+}
+
 std::vector<LDData *> *LodEngine::ldWeights(int winsize, const std::vector<int> &subsample, bool want_host)
 {
     std::cerr << "Calculating LD weights with winsize " << winsize << ".\n";

@@ -200,6 +200,11 @@ public:
     // reference-shaped host copy when want_host is set, else NULL.
     std::vector<LDData *> *ldWeights(int winsize, const std::vector<int> &subsample, bool want_host = true);
     std::vector<WinData *> *wlodWindowsResident(int winsize, double error, int MAX_GAP, int M, double mu);
+    // What exploreWinsizes / selectWinsize keep of a window size (garlic-roh.cpp:741-745, 816-823):
+    // convertWinData2DoubleData(calcLODWindows(...), step), with the scores thinned on the device(s)
+    // -- 8/step bytes per window come back instead of 8.  weighted: wLOD from the resident LD weights.
+    DoubleData *lodFeed(int winsize, double error, int MAX_GAP, int step, bool weighted = false, int M = 0,
+                        double mu = 0.0);
     LodEngine(const LodEngine &) = delete;
     LodEngine &operator=(const LodEngine &) = delete;
 

@@ -171,16 +171,19 @@ int main(int argc, char **argv)
         LodEngine engine(haps, freqs, maps, gls, &centro, USE_GL, devices); // one upload, many window sizes
         const std::vector<int> ldsub = a.weighted ? drawLdSubsample(numInd, a.ld_subsample, a.ld_seed) : std::vector<int>();
         for (int W : sizes) {
-            std::vector<WinData *> *win;
-            if (a.weighted) {   // garlic-main.cpp:346-357: LD weights per window size, then wLOD
-                engine.ldWeights(W, ldsub, false);
-                win = engine.wlodWindowsResident(W, a.error, a.max_gap, a.M, a.mu);
-            } else {
-                win = engine.lodWindows(W, a.error, a.max_gap);
+            if (a.weighted) engine.ldWeights(W, ldsub, false);   // garlic-main.cpp:346-357: LD weights per window size
+            const std::string feed_path = a.out + "." + std::to_string(W) + "SNPs.lod.f64";
+            if (!a.raw_lod) {   // only the KDE feed is wanted: thin on the device, no full-score download
+                DoubleData *feed = engine.lodFeed(W, a.error, a.max_gap, a.kde_thinning ? W : 1, a.weighted, a.M, a.mu);
+                writeFeed(feed_path, feed);
+                releaseDoubleData(feed);
+                continue;
             }
-            if (a.raw_lod) writeWinData(win, ind, maps, sizes.size() == 1 ? a.out : a.out + "." + std::to_string(W) + "SNPs");
+            std::vector<WinData *> *win = a.weighted ? engine.wlodWindowsResident(W, a.error, a.max_gap, a.M, a.mu)
+                                                     : engine.lodWindows(W, a.error, a.max_gap);
+            writeWinData(win, ind, maps, sizes.size() == 1 ? a.out : a.out + "." + std::to_string(W) + "SNPs");
             DoubleData *feed = convertWinData2DoubleData(win, a.kde_thinning ? W : 1);
-            writeFeed(a.out + "." + std::to_string(W) + "SNPs.lod.f64", feed);
+            writeFeed(feed_path, feed);
             releaseDoubleData(feed);
             releaseWinData(win);
         }

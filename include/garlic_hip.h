@@ -158,6 +158,19 @@ int garlic_wlod_windows(garlic_panel *panel, int32_t winsize, double error, int3
 int garlic_lod_flatten(garlic_panel *panel, const double *scores, int32_t pitch_align, int32_t nind_out,
                        int32_t step, double *feed, int64_t feed_capacity, int64_t *count);
 
+/* The explore / auto-winsize flows (src/garlic-roh.cpp:726-751, 798-837, 881-920) compute the
+ * scores of a window size only to thin them into the KDE feed and throw them away.  This is both
+ * steps in one call with the scores kept on the device: garlic_lod_windows or garlic_wlod_windows
+ * (weighted != 0; needs LD for winsize) over every individual of the panel, then
+ * convertWinData2DoubleData with `step` (garlic_lod_flatten).  feed: HOST buffer of feed_capacity
+ * doubles; *count = values produced (nothing is copied if it exceeds the capacity: an upper bound is
+ * sum_c ceil(nloci_c / step) * nind); chr_counts (may be NULL): values per chromosome, so that
+ * feeds of individual shards can be merged in the reference's chromosome -> individual order.
+ * 8 / step bytes per window cross PCIe instead of 8. */
+int garlic_lod_feed(garlic_panel *panel, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
+                    int32_t weighted, int32_t M, double mu, int32_t step, double *feed,
+                    int64_t feed_capacity, int64_t *count, int64_t *chr_counts);
+
 /* First half of assembleROHWindows (src/garlic-roh.cpp:446-454) on the device: for every individual
  * and SNP the number of windows with score >= cutoff that cover the SNP,
  *     inWin[l] = #{ w in (l - winsize, l] : scores[w] >= cutoff }

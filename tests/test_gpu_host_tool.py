@@ -115,16 +115,18 @@ def test_sharded_run_equals_single_device(tmp_path):
     """individuals sharded over several contexts (here: all on GPU 0) -- rows gathered in TFAM order,
     LD pair counts summed over shards -- give byte-identical files, unweighted and weighted"""
     import filecmp
-    common = ["--winsize", "30", "--raw-lod"]
     weighted = ["--weighted", "--map", os.path.join(E2E, "tiny.map"), "--ld-subsample", "11", "--ld-seed", "5"]
-    for extra in ([], weighted):
+    # with --raw-lod the full scores come back; without, only the feed thinned on the devices
+    cases = ((["--winsize", "30", "--raw-lod"], []), (["--winsize", "30", "--raw-lod"], weighted),
+             (["--winsize-multi", "20", "45"], []), (["--winsize", "30", "--no-kde-thinning"], weighted))
+    for case, (common, extra) in enumerate(cases):
         outs = []
         for k, devs in enumerate(("0", "0,0", "0,0,0,0,0")):
-            d = tmp_path / f"run{len(extra)}_{k}"
+            d = tmp_path / f"case{case}_{k}"
             d.mkdir()
             outs.append(run_tool(d, *common, *extra, "--devices", devs))
         names = sorted(os.path.basename(p)[len("mine"):] for p in glob.glob(outs[0] + "*"))
-        assert any("raw.lod" in n for n in names) and any(n.endswith(".lod.f64") for n in names)
+        assert any(n.endswith(".lod.f64") for n in names)
         for other in outs[1:]:
             for n in names:
                 assert filecmp.cmp(outs[0] + n, other + n, shallow=False), (n, other)

@@ -223,3 +223,33 @@ def test_roh_coverage_counts_on_device(gpu_ctx, W):
                 want = ol.oracle_roh_coverage(rows[c], W, cutoff)
                 assert np.array_equal(got[c], want), (W, cutoff, c)
 
+
+def test_lod_feed_one_call(gpu_ctx):
+    """garlic_lod_feed = scores + convertWinData2DoubleData on the device, unweighted / TGLS / wLOD"""
+    rng = np.random.default_rng(21)
+    mg, W, nind = 200000, 30, 70
+    sizes = [900, 400]
+    chroms = [ol.random_panel(rng, n, nind, max_gap=mg) for n in sizes]
+    gpos = [c[2] * 1e-6 for c in chroms]
+    lds = [rng.uniform(1.0, 8.0, size=(n, W)) for n in sizes]
+    err = [rng.choice([1e-3, 0.01, 0.2], size=c[0].shape) for c in chroms]
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms],
+                      gpos=np.concatenate(gpos))
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        panel.set_gl(np.concatenate(err, axis=0))
+        panel.set_ld(W, np.concatenate(lds, axis=0))
+        for step in (1, W, 7):
+            for mode in ("lod", "tgls", "wlod"):
+                feed, per_chr = panel.lod_feed(W, 0.001, mg, step, use_gl=(mode == "tgls"), weighted=(mode == "wlod"))
+                want = []
+                for c, (g, f, p, cs, ce) in enumerate(chroms):
+                    if mode == "wlod":
+                        win = ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, 0.001, mg, 1e-9, 7)
+                    else:
+                        win = ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg, gl=err[c] if mode == "tgls" else None)
+                    want.append(ol.oracle_flatten(win, step))
+                assert [len(w) for w in want] == list(per_chr), (mode, step)
+                assert ol.bits_equal(feed, np.concatenate(want)), (mode, step)
+
