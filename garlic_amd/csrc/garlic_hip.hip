@@ -1242,8 +1242,11 @@ int garlic_lod_feed(garlic_panel *p, int32_t winsize, double error, int32_t max_
     int rc;
     if ((rc = set_device(p->ctx))) return rc;
     const Layout L = make_layout(p, 32, p->nind);
-    DevBuf<double> scores, d_feed;   // call-local: a resident 8 B per window would defeat the purpose
-    auto done = [&](int code) { scores.release(); d_feed.release(); return code; };
+    // scores go to the panel's device scratch (the one host-output calls use; it stays allocated,
+    // hipMalloc of 8 GB per call would cost more than the kernels)
+    DevBuf<double> &scores = p->d_out;
+    DevBuf<double> d_feed;
+    auto done = [&](int code) { d_feed.release(); return code; };
     if ((rc = scores.reserve((size_t)L.total))) return done(rc);
     if (weighted) p->wlod_use_gl = use_gl != 0;
     rc = launch_lod(p, weighted ? MODE_WLOD : (use_gl ? MODE_LOD_GL : MODE_LOD), winsize, error, max_gap, M, mu, 0,

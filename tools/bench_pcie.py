@@ -47,13 +47,20 @@ def main():
                                                abi._vp(out.ctypes.data), abi.HOST))
         times.append(time.perf_counter() - t0)
     st = panel.stats()
+    # the explore / auto-winsize form: only the thinned KDE feed comes back
+    panel.lod_feed(args.winsize, 0.001, 200000, args.winsize)
+    t0 = time.perf_counter()
+    feed, _ = panel.lod_feed(args.winsize, 0.001, 200000, args.winsize)
+    t_feed = time.perf_counter() - t0
     win = args.snps * args.inds
     print(json.dumps({"snps": args.snps, "inds": args.inds, "winsize": args.winsize,
                       "upload_s (int16 genotypes, pack on device)": t_up,
                       "lod_windows_host_output_s": min(times),
                       "of_which_device_ms": st["total_ms"], "chain_kernel_ms": st["chain_kernel_ms"],
                       "d2h_GBps": win * 8 / 1e9 / max(1e-9, min(times) - st["chain_kernel_ms"] * 1e-3),
-                      "lod_windows_per_s_pcie_inclusive": win / args.winsize / min(times)}))
+                      "lod_windows_per_s_pcie_inclusive": win / args.winsize / min(times),
+                      "lod_feed_call_s (scores + thinning on device, feed of %d values back)" % feed.shape[0]: t_feed,
+                      "lod_windows_per_s_feed_only": win / args.winsize / t_feed}))
 
 
 if __name__ == "__main__":
