@@ -25,7 +25,7 @@ SYMBOLS = [
     "garlic_panel_set_ld", "garlic_lod_out_layout", "garlic_lod_windows",
     "garlic_wlod_windows", "garlic_lod_flatten", "garlic_last_call_stats",
     "garlic_panel_compute_ld", "garlic_ld_counts", "garlic_ld_finish", "garlic_roh_coverage",
-    "garlic_lod_feed",
+    "garlic_lod_feed", "garlic_ctx_set_async",
 ]
 
 
@@ -62,6 +62,7 @@ def lib():
     L.garlic_ctx_create.argtypes = [C.c_int32, _vp, C.POINTER(_vp)]
     L.garlic_ctx_destroy.argtypes = [_vp]
     L.garlic_ctx_synchronize.argtypes = [_vp]
+    L.garlic_ctx_set_async.argtypes = [_vp, C.c_int32]
     L.garlic_panel_create.argtypes = [_vp, C.c_int32, _i32p, C.c_int32, C.POINTER(_vp)]
     L.garlic_panel_destroy.argtypes = [_vp]
     L.garlic_panel_set_map.argtypes = [_vp, _i32p, _f64p, _i32p, _i32p]
@@ -110,6 +111,10 @@ class Context:
 
     def synchronize(self):
         check(lib().garlic_ctx_synchronize(self.handle))
+
+    def set_async(self, on=True):
+        """device-output calls that repeat the previous call's arguments only enqueue (see garlic_hip.h)"""
+        check(lib().garlic_ctx_set_async(self.handle, int(on)))
 
     def close(self):
         if self.handle:

@@ -104,6 +104,7 @@ struct garlic_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;
+    bool async_device = false;   // garlic_ctx_set_async
 };
 
 struct garlic_panel {
@@ -171,6 +172,7 @@ struct garlic_panel {
     double decay_mu = 0;
     DevBuf<double> d_out;
     garlic_call_stats stats{};
+    bool stats_pending = false;                    // event times of the last call not read yet
     // work list of the last call, still on the device: repeated calls with the same arguments
     // (bench steps, window-size sweeps coming back to a size) skip planning and uploads
     struct {
@@ -569,6 +571,10 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     }
     const bool aligned16 = (pitch_align % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
 
+    // Everything this call puts on the stream.  (Replaying a repeated asynchronous pass as one HIP
+    // graph -- counter reset, MISSING fill, chain kernel, events -- was measured: no difference, the
+    // 1.6 ms kernel hides the launch gaps of the small operations once passes are enqueued back to back.)
+    auto enqueue = [&]() -> int {
     HIP_TRY(hipEventRecord(ctx->ev_begin, ctx->stream));
     if (!reuse) {
         HIP_TRY(hipMemcpyAsync(p->d_chrs.p, chrs.data(), sizeof(ChrDev) * chrs.size(),
@@ -671,14 +677,21 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     }
     HIP_TRY(hipEventRecord(ctx->ev_k1, ctx->stream));
     HIP_TRY(hipGetLastError());
+    return GARLIC_OK;
+    };   // enqueue
+    if ((rc = enqueue())) return rc;
     if (where == GARLIC_HOST)
         for (int c = 0; c < p->nchr; c++)
             HIP_TRY(hipMemcpy2DAsync(out + Lhost.base[c], sizeof(double) * Lhost.pitch[c], d_out + L.base[c],
                                      sizeof(double) * L.pitch[c], sizeof(double) * p->chr_nloci[c],
                                      (size_t)ind_count, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev_end, ctx->stream));
-    // The work list lives in host vectors and per-panel device scratch: finish before returning.
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // The work list lives in host vectors and per-panel device scratch: finish before returning --
+    // unless the context is asynchronous, the output stays on the device and the plan (already
+    // resident) is being reused: then nothing on the host is needed again and the call only enqueues.
+    const bool enqueue_only = ctx->async_device && where == GARLIC_DEVICE && reuse;
+    if (!enqueue_only) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    p->stats_pending = true;
 
     garlic_call_stats &st = p->stats;
     st.n_segments = (int64_t)p->boundaries.size();
@@ -691,8 +704,6 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     p->plan.n_items = n_items; p->plan.n_fill = n_fill; p->plan.n_runs = n_runs; p->plan.n_valid = n_valid;
     st.n_valid_windows = n_valid;
     st.n_missing = p->nloci - n_valid;
-    (void)hipEventElapsedTime(&st.chain_kernel_ms, ctx->ev_k0, ctx->ev_k1);
-    (void)hipEventElapsedTime(&st.total_ms, ctx->ev_begin, ctx->ev_end);
     return GARLIC_OK;
 }
 
@@ -1316,7 +1327,22 @@ int garlic_roh_coverage(garlic_panel *p, const double *scores, int32_t pitch_ali
 int garlic_last_call_stats(garlic_panel *p, garlic_call_stats *stats)
 {
     if (!p || !stats) return fail(GARLIC_ERR_INVALID, "panel and stats are required");
+    if (p->stats_pending) {   // the event times of the last call (waits for it if it is still running)
+        int rc;
+        if ((rc = set_device(p->ctx))) return rc;
+        HIP_TRY(hipEventSynchronize(p->ctx->ev_end));
+        (void)hipEventElapsedTime(&p->stats.chain_kernel_ms, p->ctx->ev_k0, p->ctx->ev_k1);
+        (void)hipEventElapsedTime(&p->stats.total_ms, p->ctx->ev_begin, p->ctx->ev_end);
+        p->stats_pending = false;
+    }
     *stats = p->stats;
+    return GARLIC_OK;
+}
+
+int garlic_ctx_set_async(garlic_ctx *ctx, int32_t on)
+{
+    if (!ctx) return fail(GARLIC_ERR_INVALID, "ctx is NULL");
+    ctx->async_device = on != 0;
     return GARLIC_OK;
 }
 

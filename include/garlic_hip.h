@@ -66,6 +66,13 @@ int garlic_hip_device_count(int32_t *count);
 int garlic_ctx_create(int32_t device, void *hip_stream, garlic_ctx **ctx);
 int garlic_ctx_destroy(garlic_ctx *ctx);
 int garlic_ctx_synchronize(garlic_ctx *ctx);
+/* By default every call returns after its device work has finished.  With on != 0,
+ * garlic_lod_windows / garlic_wlod_windows calls whose output stays on the device and whose
+ * arguments repeat the previous call's (same window size, range, layout: the work plan is reused)
+ * only enqueue their kernels on the context's stream; garlic_ctx_synchronize (or
+ * garlic_last_call_stats, or any synchronous call) waits.  For callers that issue passes back to
+ * back (benchmarks, pipelines that consume the scores on the same stream). */
+int garlic_ctx_set_async(garlic_ctx *ctx, int32_t on);
 
 /* Panel = what calcLODWindows borrows: HapData / MapData / FreqData (/ GenoLikeData / LDData)
  * of every chromosome, for the nind individuals this context owns (a shard of the TFAM order).

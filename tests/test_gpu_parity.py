@@ -164,3 +164,33 @@ def test_chunked_genotype_upload_and_repeat_calls(gpu_ctx):
         for W, err in ((20, 0.001), (50, 0.001), (20, 0.01), (20, 0.001)):
             out = panel.lod_windows(W, err, max_gap, pitch_align=32)
             check_against_oracle(out, *data, W, err, max_gap)
+
+
+def test_async_context_enqueues_repeated_calls(gpu_ctx):
+    """garlic_ctx_set_async: repeated device-output calls only enqueue; after garlic_ctx_synchronize (or a
+    stats read) the scores are the same bits as a synchronous call's"""
+    import torch
+    rng = np.random.default_rng(77)
+    sizes = [3000, 1200]
+    max_gap = 200000
+    data = make_multichr(rng, sizes, 130, max_gap)
+    genos, freqs, poss, css, ces = data
+    ctx = abi.Context(0)
+    ctx.set_async(True)
+    with abi.Panel(ctx, sizes, 130) as panel:
+        panel.set_map(np.concatenate(poss), css, ces)
+        panel.set_freq(np.concatenate(freqs))
+        panel.set_genotypes(np.concatenate(genos, axis=0))
+        base, pitch, total = panel.out_layout(32, 130)
+        out = torch.full((total,), float("nan"), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(4):                                   # first call plans, the others enqueue
+            panel.lod_windows_device(out.data_ptr(), 50, 0.001, max_gap, pitch_align=32)
+        assert panel.stats()["chain_kernel_ms"] > 0          # waits for the last pass
+        ctx.synchronize()
+        host = out.cpu().numpy()
+    ctx.close()
+    for c, n in enumerate(sizes):
+        got = host[base[c]: base[c] + 130 * pitch[c]].reshape(130, pitch[c])[:, :n]
+        want = ol.oracle_calc_lod(genos[c], freqs[c], poss[c], css[c], ces[c], 50, 0.001, max_gap)
+        assert ol.count_mismatch(np.ascontiguousarray(got), want) == 0
