@@ -175,12 +175,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # HIP-event duration of the dominant kernel, on the stream it runs on: a few more passes, each
-    # read back (outside the timed region; reading the events waits for the pass)
-    kernel_ms = []
-    for _ in range(min(args.steps, 5)):
-        step()
-        kernel_ms.append(panel.stats()["chain_kernel_ms"])
+    # HIP-event durations of the dominant kernel over the timed region, on the stream it runs on
+    # (one event pair per pass, read after the region: the passes were not waited for one by one)
+    kernel_ms = ctx.recent_kernel_ms(min(args.steps, 32))
     st = panel.stats()
     if rank == 0:
         windows_per_step = nloci * nind * world            # sliding windows (SNPs x inds)

@@ -26,6 +26,7 @@ SYMBOLS = [
     "garlic_wlod_windows", "garlic_lod_flatten", "garlic_last_call_stats",
     "garlic_panel_compute_ld", "garlic_ld_counts", "garlic_ld_finish", "garlic_roh_coverage",
     "garlic_lod_feed", "garlic_ctx_set_async",
+    "garlic_recent_kernel_ms",
 ]
 
 
@@ -63,6 +64,7 @@ def lib():
     L.garlic_ctx_destroy.argtypes = [_vp]
     L.garlic_ctx_synchronize.argtypes = [_vp]
     L.garlic_ctx_set_async.argtypes = [_vp, C.c_int32]
+    L.garlic_recent_kernel_ms.argtypes = [_vp, C.POINTER(C.c_float), C.c_int32, _i32p]
     L.garlic_panel_create.argtypes = [_vp, C.c_int32, _i32p, C.c_int32, C.POINTER(_vp)]
     L.garlic_panel_destroy.argtypes = [_vp]
     L.garlic_panel_set_map.argtypes = [_vp, _i32p, _f64p, _i32p, _i32p]
@@ -111,6 +113,13 @@ class Context:
 
     def synchronize(self):
         check(lib().garlic_ctx_synchronize(self.handle))
+
+    def recent_kernel_ms(self, n=32):
+        """HIP-event durations of the dominant kernel of the last <= n (<= 32) score calls, oldest first"""
+        buf = (C.c_float * n)()
+        got = C.c_int32()
+        check(lib().garlic_recent_kernel_ms(self.handle, buf, n, C.byref(got)))
+        return [float(buf[i]) for i in range(got.value)]
 
     def set_async(self, on=True):
         """device-output calls that repeat the previous call's arguments only enqueue (see garlic_hip.h)"""

@@ -105,6 +105,11 @@ struct garlic_ctx {
     bool own_stream = false;
     hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;
     bool async_device = false;   // garlic_ctx_set_async
+    // the dominant kernel of the last HIST calls, one event pair each (asynchronous passes are
+    // timed without being waited for one by one): garlic_recent_kernel_ms
+    static constexpr int HIST = 32;
+    hipEvent_t hist0[HIST] = {}, hist1[HIST] = {};
+    int64_t n_calls = 0;
 };
 
 struct garlic_panel {
@@ -599,6 +604,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     }
     if (n_items) HIP_TRY(hipMemsetAsync(p->d_counter.p, 0, sizeof(int32_t), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev_k0, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->hist0[ctx->n_calls % garlic_ctx::HIST], ctx->stream));
     if (wlod_fast) {
         const int nquad = (nblk + WLOD_WAVES - 1) / WLOD_WAVES;
         WlodArgs a{p->d_valid.p, p->d_chrs.p, p->d_tiles.p, p->nwordrows, p->nchr, ind_begin, ind_count, W, nquad,
@@ -676,6 +682,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         }
     }
     HIP_TRY(hipEventRecord(ctx->ev_k1, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->hist1[ctx->n_calls % garlic_ctx::HIST], ctx->stream));
+    ctx->n_calls++;
     HIP_TRY(hipGetLastError());
     return GARLIC_OK;
     };   // enqueue
@@ -766,6 +774,11 @@ int garlic_ctx_create(int32_t device, void *hip_stream, garlic_ctx **out)
             return fail(GARLIC_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(ee));
         }
     }
+    for (int i = 0; i < garlic_ctx::HIST; i++)
+        if (hipEventCreate(&ctx->hist0[i]) != hipSuccess || hipEventCreate(&ctx->hist1[i]) != hipSuccess) {
+            (void)garlic_ctx_destroy(ctx);
+            return fail(GARLIC_ERR_HIP, "hipEventCreate failed");
+        }
     *out = ctx;
     return GARLIC_OK;
 }
@@ -777,6 +790,10 @@ int garlic_ctx_destroy(garlic_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (hipEvent_t ev : {ctx->ev_begin, ctx->ev_k0, ctx->ev_k1, ctx->ev_end})
         if (ev) (void)hipEventDestroy(ev);
+    for (int i = 0; i < garlic_ctx::HIST; i++) {
+        if (ctx->hist0[i]) (void)hipEventDestroy(ctx->hist0[i]);
+        if (ctx->hist1[i]) (void)hipEventDestroy(ctx->hist1[i]);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return GARLIC_OK;
@@ -1336,6 +1353,21 @@ int garlic_last_call_stats(garlic_panel *p, garlic_call_stats *stats)
         p->stats_pending = false;
     }
     *stats = p->stats;
+    return GARLIC_OK;
+}
+
+int garlic_recent_kernel_ms(garlic_ctx *ctx, float *ms, int32_t n, int32_t *got)
+{
+    if (!ctx || !ms || !got || n < 1) return fail(GARLIC_ERR_INVALID, "ctx, ms, got are required; n >= 1");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const int64_t have = std::min<int64_t>(std::min<int64_t>(n, garlic_ctx::HIST), ctx->n_calls);
+    for (int64_t k = 0; k < have; k++) {       // oldest of the requested ones first
+        const int64_t call = ctx->n_calls - have + k;
+        ms[k] = 0.f;
+        (void)hipEventElapsedTime(&ms[k], ctx->hist0[call % garlic_ctx::HIST], ctx->hist1[call % garlic_ctx::HIST]);
+    }
+    *got = (int32_t)have;
     return GARLIC_OK;
 }
 

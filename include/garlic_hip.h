@@ -73,6 +73,10 @@ int garlic_ctx_synchronize(garlic_ctx *ctx);
  * garlic_last_call_stats, or any synchronous call) waits.  For callers that issue passes back to
  * back (benchmarks, pipelines that consume the scores on the same stream). */
 int garlic_ctx_set_async(garlic_ctx *ctx, int32_t on);
+/* HIP-event durations (ms) of the dominant kernel of the context's most recent window-score calls,
+ * oldest first, at most 32: lets a caller time asynchronous passes without waiting for each.  Waits
+ * for the stream.  *got = number of values written (<= n). */
+int garlic_recent_kernel_ms(garlic_ctx *ctx, float *ms, int32_t n, int32_t *got);
 
 /* Panel = what calcLODWindows borrows: HapData / MapData / FreqData (/ GenoLikeData / LDData)
  * of every chromosome, for the nind individuals this context owns (a shard of the TFAM order).
