@@ -194,3 +194,27 @@ def test_async_context_enqueues_repeated_calls(gpu_ctx):
         got = host[base[c]: base[c] + 130 * pitch[c]].reshape(130, pitch[c])[:, :n]
         want = ol.oracle_calc_lod(genos[c], freqs[c], poss[c], css[c], ces[c], 50, 0.001, max_gap)
         assert ol.count_mismatch(np.ascontiguousarray(got), want) == 0
+
+
+def test_random_configurations(gpu_ctx):
+    """40 random panels: chromosome counts and lengths, window sizes, gap density, individual counts,
+    sub-ranges and layouts drawn at random; every double against the oracle"""
+    rng = np.random.default_rng(20261004)
+    for trial in range(40):
+        nchr = int(rng.integers(1, 5))
+        sizes = [int(rng.integers(1, 2600)) for _ in range(nchr)]
+        W = int(rng.choice([2, 3, 7, 16, 33, 64, 100, 257]))
+        nind = int(rng.integers(1, 200))
+        max_gap = int(rng.choice([3000, 50000, 200000]))
+        data = make_multichr(rng, sizes, nind, max_gap, gaps=int(rng.integers(0, 6)), miss=float(rng.choice([0.0, 0.03, 0.3])))
+        i0 = int(rng.integers(0, nind))
+        cnt = int(rng.integers(1, nind - i0 + 1))
+        pa = int(rng.choice([1, 2, 32]))
+        err = float(rng.choice([1e-6, 0.001, 0.05, 0.5]))
+        out, st = run_gpu(gpu_ctx, *data, W, err, max_gap, pitch_align=pa, ind_begin=i0, ind_count=cnt)
+        genos, freqs, poss, css, ces = data
+        for c, g in enumerate(genos):
+            want = ol.oracle_calc_lod(g, freqs[c], poss[c], css[c], ces[c], W, err, max_gap)[i0:i0 + cnt]
+            bad = ol.count_mismatch(np.ascontiguousarray(out[c]), want)
+            assert bad == 0, (trial, sizes, W, nind, i0, cnt, pa, c, bad)
+        assert st["n_valid_windows"] + st["n_missing"] == sum(sizes)
