@@ -132,3 +132,18 @@ def test_ld_sharded_counts_on_device(gpu_ctx):
         panel.ld_finish_device(W, loc.data_ptr(), pair.data_ptr(), ld.data_ptr())
         assert same(ld.cpu().numpy(), want)
         panel.close()
+
+
+def test_ld_golden_from_the_reference_build(gpu_ctx):
+    """tests/golden/wlod.npz holds calcHR2LD's own output (tools/make_golden.py, real reference build)"""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wlod.npz"))
+    cs, ce = (int(x) for x in d["centro"])
+    n, nind = d["geno"].shape
+    with abi.Panel(gpu_ctx, [n], nind) as panel:
+        panel.set_map(d["pos"], [cs], [ce], gpos=d["gpos"])
+        panel.set_freq(d["freq"])
+        panel.set_genotypes(d["geno"])
+        for W in (10, 30):
+            assert same(panel.compute_ld(W), d[f"ld_W{W}"]), W
+

@@ -58,3 +58,17 @@ def test_wlod_random_panels():
         b = ol.ref_calc_wlod(geno, freq, pos, gpos, ld, cS, cE, W, 0.001, 200000, 1e-9, 7, gl=gl,
                              threads=int(rng.integers(1, 6)))
         assert ol.bits_equal(a, b)
+
+
+def test_ld_subsample_index():
+    """hr2 over an injected --ld-subsample index (garlic-data.cpp:361-364, 562-566): oracle == reference"""
+    rng = np.random.default_rng(9)
+    for _ in range(25):
+        nloci, nind, W = int(rng.integers(5, 200)), int(rng.integers(3, 40)), int(rng.integers(2, 30))
+        geno = ol.random_panel(rng, nloci, nind, miss=float(rng.choice([0.0, 0.05, 0.4])))[0]
+        idx = np.sort(rng.choice(nind, size=int(rng.integers(1, nind + 1)), replace=False)).astype(np.int32)
+        hom, ld = ol.ref_hr2_ld(geno, W, idx=idx, threads=int(rng.integers(1, 4)))
+        mine = ol.oracle_hr2_ld(geno, W, idx=idx)
+        nan = np.isnan(ld)
+        assert np.array_equal(nan, np.isnan(mine)) and ol.bits_equal(ld[~nan], mine[~nan])
+
