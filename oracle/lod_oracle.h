@@ -9,6 +9,10 @@
  * reference sources compiled into oracle/_ref/libgarlic_ref.so (tests/test_oracle_vs_ref.py,
  * build container only) and against fixtures generated from that build and committed
  * under tests/golden/ (tools/make_golden.py).
+ * One exception: oracle_roh_coverage restates six lines in the middle of assembleROHWindows
+ * (garlic-roh.cpp:446-454), which the reference does not expose as a function; it is integer
+ * counting, cross-checked against a brute-force numpy loop (tests/test_oracle_golden.py), not
+ * against the reference build -- parity UNPINNED for that one helper.
  *
  * All arrays are flat, row-major:
  *   genotypes  int16  [nloci][nind]   (reference HapData::data, garlic-data.h:35)

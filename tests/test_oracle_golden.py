@@ -128,3 +128,23 @@ def test_edge_shapes(W):
         assert ((win != ol.MISSING).sum(axis=1) == max(0, n - W + 1)).all()
         inside = ol.oracle_calc_lod(g, f, p, int(p[0]) - 1, int(p[-1]) + 1, W, 0.001, 200000)
         assert (inside == ol.MISSING).all()
+
+
+def test_roh_coverage_against_brute_force():
+    """oracle_roh_coverage (garlic-roh.cpp:446-454) vs the loop written out in numpy; this helper is the
+    one part of the oracle that is not pinned to the reference build (no separate function there)"""
+    rng = np.random.default_rng(0)
+    win = rng.normal(size=(5, 300))
+    win[rng.random(win.shape) < 0.1] = -9999.0
+    win[0, 5] = np.nan
+    for W in (2, 7, 50):
+        for cut in (0.0, -10000.0, 1.0):
+            got = ol.oracle_roh_coverage(win, W, cut)
+            q = win >= cut
+            want = np.zeros_like(got)
+            for w in range(300):
+                for i in range(W):
+                    if w + i < 300:
+                        want[:, w + i] += q[:, w]
+            assert np.array_equal(got, want)
+
