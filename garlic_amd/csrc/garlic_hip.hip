@@ -154,10 +154,7 @@ struct garlic_panel {
     bool tabgl_valid = false;
     DevBuf<double> d_glterms;                      // TGLS term matrix [blk][GOFF+nloci+pad][64]
     bool glterms_valid = false;
-    DevBuf<double> d_glscores;                     // (term * nomut) * norec, same shape (wLOD with GL)
-    bool glscores_valid = false;
-    int32_t glscores_M = 0;
-    double glscores_mu = 0;
+
     int tabgl_ncodes = 0;
     // wLOD
     bool have_ld = false, wlod_use_gl = false;
@@ -377,30 +374,6 @@ int ensure_gl_terms(garlic_panel *p)
                        dim3(256), 0, s, a, p->nloci, rows, p->d_glterms.p);
     HIP_TRY(hipGetLastError());
     p->glterms_valid = true;
-    p->glscores_valid = false;
-    return GARLIC_OK;
-}
-
-// ---- wLOD with GL: score matrix (term * nomut) * norec; leaves glscores_valid unset when the term
-// matrix or this one does not fit (the generic kernel runs then)
-int ensure_gl_scores(garlic_panel *p, int32_t M, double mu)
-{
-    int rc;
-    if ((rc = ensure_gl_terms(p))) return rc;
-    if (!p->glterms_valid) return GARLIC_OK;
-    if (p->glscores_valid && p->glscores_M == M && memcmp(&p->glscores_mu, &mu, sizeof mu) == 0) return GARLIC_OK;
-    const int64_t rows = GOFF + p->nloci + GPAD_BACK;
-    const size_t n = (size_t)rows * p->nind_pad;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GARLIC_OK;
-    if (p->d_glscores.cap < n && n * sizeof(double) + ((size_t)8 << 30) > free_b) return GARLIC_OK;
-    if ((rc = p->d_glscores.reserve(n))) return rc;
-    hipLaunchKernelGGL(gl_scores_kernel, dim3(4096), dim3(256), 0, p->ctx->stream, p->d_glterms.p, p->d_decay.p,
-                       rows, (int64_t)n, p->d_glscores.p);
-    HIP_TRY(hipGetLastError());
-    p->glscores_valid = true;
-    p->glscores_M = M;
-    p->glscores_mu = mu;
     return GARLIC_OK;
 }
 
@@ -491,8 +464,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // generic kernel
     const bool wlod_shape_ok = mode == MODE_WLOD && W >= WLOD_R && W + 64 <= GPAD_BACK &&
                                !getenv("GARLIC_WLOD_GENERIC");
-    if (wlod_shape_ok && use_gl && (rc = ensure_gl_scores(p, M, mu))) return rc;
-    const bool wlod_gl = wlod_shape_ok && use_gl && p->glscores_valid;      // scores from the term matrix
+    if (wlod_shape_ok && use_gl && (rc = ensure_gl_terms(p))) return rc;
+    const bool wlod_gl = wlod_shape_ok && use_gl && p->glterms_valid;       // terms from the TGLS term matrix
     bool wlod_fast = (wlod_shape_ok && !use_gl) || wlod_gl;                 // tile kernel, either variant
     if (wlod_fast && !wlod_gl && sizeof(double) * (size_t)(W + TILE) * 4 + 16 > 150 * 1024) wlod_fast = false;
     if (wlod_fast && !wlod_gl && (rc = ensure_score_rows(p, error, M, mu, W))) return rc;
@@ -609,9 +582,9 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         const int nquad = (nblk + WLOD_WAVES - 1) / WLOD_WAVES;
         WlodArgs a{p->d_valid.p, p->d_chrs.p, p->d_tiles.p, p->nwordrows, p->nchr, ind_begin, ind_count, W, nquad,
                    (uint32_t)((int64_t)p->plan.n_tiles * nquad), wlod_use_patch ? 1 : 0,
-                   (int64_t)(GOFF + p->nloci + GPAD_BACK)};
+                   (int64_t)(GOFF + p->nloci + GPAD_BACK), p->d_decay.p};
         const uint32_t *a_packed = p->d_packed.p;
-        const double *a_wtab = wlod_gl ? p->d_glscores.p : p->d_wtab.p, *a_skew = p->d_skew.p + SKEW_FRONT;
+        const double *a_wtab = wlod_gl ? p->d_glterms.p : p->d_wtab.p, *a_skew = p->d_skew.p + SKEW_FRONT;
         const unsigned wl_grid = (a.n_work + 7u) / 8u * 8u;
         const dim3 wl_block(WLOD_WAVES * WAVE);
         if (wlod_lds > 48 * 1024) {
@@ -861,7 +834,7 @@ int garlic_panel_destroy(garlic_panel *p)
     p->d_blk_offsets.release(); p->d_total.release(); p->d_boundaries.release();
     p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release(); p->d_row_counts.release(); p->d_codes.release(); p->d_tabgl.release();
     p->d_rld.release(); p->d_decay.release(); p->d_stage64.release();
-    p->d_glterms.release(); p->d_glscores.release(); p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release();
+    p->d_glterms.release(); p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release();
     p->d_out.release();
     delete p;
     return GARLIC_OK;

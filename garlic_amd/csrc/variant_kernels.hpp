@@ -324,7 +324,8 @@ struct WlodArgs {
     int32_t nchr, ind_begin, ind_count, winsize, nquad;   // nquad = workgroups per tile
     uint32_t n_work;           // tiles x nquad
     int32_t use_patch;         // transposed write-out through the LDS patch (allocated then)
-    int64_t score_rows;        // FROM_SCORES: SNP rows per 64-individual block of the score matrix
+    int64_t score_rows;        // FROM_SCORES: SNP rows per 64-individual block of the term matrix
+    const double *decay;       // FROM_SCORES: [GOFF + nloci + pad][2] = {nomut, norec}
 };
 
 // Ordered sums of windows s .. s+15 for this lane's individual: acc[r] = sum_j sc[s+r+j] * D[s+r+j][j],
@@ -358,26 +359,31 @@ __device__ __forceinline__ void wlod_group(const double *rows, const uint32_t *g
                  : GARLIC_WLOD_LOOP_CLOBBERS);
 }
 
-// wLOD with per-genotype likelihoods (garlic-roh.cpp:245, USE_GL): the score of (SNP, individual)
-// comes from the TGLS term matrix, scores[blk][G][64] = (term * nomut) * norec (gl_scores_kernel),
-// not from a 4-entry row -- one coalesced 512-B load per step instead of an LDS look-up.  This
-// variant is compiler-scheduled (scores are fetched 8 steps at a time, the weights by the scalar
+// wLOD with per-genotype likelihoods (garlic-roh.cpp:245, USE_GL): the term of (SNP, individual)
+// comes from the TGLS term matrix -- one coalesced 512-B load per step instead of an LDS look-up --
+// and is scaled by the SNP's two decay factors (wave-uniform, scalar loads) on the fly.  This
+// variant is compiler-scheduled (terms are fetched 8 steps at a time, the weights by the scalar
 // loads hipcc places); the hand-scheduled loop above assumes the LDS look-up.
 typedef const __attribute__((address_space(4))) double *const_f64_ptr;
 
 template <int R>
-__device__ __forceinline__ void wlod_group_scores(const double *scol, int64_t G, const double *Ds, int W,
-                                                  double (&acc)[R])
+__device__ __forceinline__ void wlod_group_scores(const double *tcol, const double *decay, int64_t G,
+                                                  const double *Ds, int W, double (&acc)[R])
 {
-    // weights through the constant address space: they never change during the kernel, and only
-    // then does the compiler keep their wave-uniform loads on the scalar path next to the stores
+    // weights and decay factors through the constant address space: they never change during the
+    // kernel, and only then does the compiler keep their wave-uniform loads on the scalar path
     const const_f64_ptr Dg = (const_f64_ptr)(uintptr_t)Ds;
+    const const_f64_ptr dec = (const_f64_ptr)(uintptr_t)(decay + 2 * G);     // {nomut, norec} per SNP
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0;
-    const double *sp = scol + G * WAVE;
+    const double *tp = tcol + G * WAVE;
+    // score of SNP s+i: (lod * nomut) * norec, in that order (garlic-roh.cpp:249)
+    // (a separate score matrix is 0.9 ms faster at 200k x 1000 but doubles the 8 B per genotype
+    // of the term matrix; the two factors as vector loads were measured slower than as scalar loads)
+    auto score = [&](int i) -> double { return (tp[i * WAVE] * dec[2 * i]) * dec[2 * i + 1]; };
     double up[R - 1];
 #pragma unroll
-    for (int i = 0; i < R - 1; i++) up[i] = sp[i * WAVE];
+    for (int i = 0; i < R - 1; i++) up[i] = score(i);
 #pragma unroll
     for (int i = 0; i < R - 1; i++) {                      // windows enter one by one
         const const_f64_ptr Dr = Dg + (int64_t)i * W;
@@ -388,7 +394,7 @@ __device__ __forceinline__ void wlod_group_scores(const double *scol, int64_t G,
     for (; i + 8 <= W; i += 8) {                           // all R windows take every SNP
         double sc[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) sc[q] = sp[(i + q) * WAVE];
+        for (int q = 0; q < 8; q++) sc[q] = score(i + q);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const const_f64_ptr Dr = Dg + (int64_t)(i + q) * W + (i + q - (R - 1));
@@ -397,14 +403,14 @@ __device__ __forceinline__ void wlod_group_scores(const double *scol, int64_t G,
         }
     }
     for (; i < W; i++) {
-        const double sc = sp[i * WAVE];
+        const double sc = score(i);
         const const_f64_ptr Dr = Dg + (int64_t)i * W + (i - (R - 1));
 #pragma unroll
         for (int r = 0; r < R; r++) acc[r] += sc * Dr[(R - 1) - r];
     }
     double dn[R - 1];
 #pragma unroll
-    for (int d = 0; d < R - 1; d++) dn[d] = sp[(W + d) * WAVE];
+    for (int d = 0; d < R - 1; d++) dn[d] = score(W + d);
 #pragma unroll
     for (int d = 0; d < R - 1; d++) {                      // and leave one by one
         const const_f64_ptr Dr = Dg + (int64_t)(W + d) * W;
@@ -413,21 +419,10 @@ __device__ __forceinline__ void wlod_group_scores(const double *scol, int64_t G,
     }
 }
 
-// scores[i] = (terms[i] * nomut[G]) * norec[G] over the whole term matrix (garlic-roh.cpp:249)
-__global__ void gl_scores_kernel(const double *__restrict__ terms, const double *__restrict__ decay,
-                                 int64_t rows, int64_t n, double *__restrict__ scores)
-{
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const int64_t G = (i >> 6) % rows;
-        scores[i] = (terms[i] * decay[2 * G]) * decay[2 * G + 1];
-    }
-}
-
 template <int R, bool ALIGNED16, bool FROM_SCORES>
 __global__ void __launch_bounds__(WLOD_WAVES * WAVE) __attribute__((amdgpu_num_vgpr(64)))   // 8 waves per SIMD
 wlod_tile_kernel(const uint32_t *__restrict__ packed,
-                 const double *__restrict__ wtab,   // [GOFF + nloci + pad][4]; FROM_SCORES: [blk][rows][64]
+                 const double *__restrict__ wtab,   // [GOFF + nloci + pad][4]; FROM_SCORES: term matrix [blk][rows][64]
                  const double *__restrict__ D,      // [nloci + pad][W], D[l][j] = 1.0 / LD[l - j][j]
                  double *__restrict__ out, WlodArgs p)
 {   // the read-only tables are separate __restrict__ arguments: only then are the wave-uniform
@@ -475,7 +470,7 @@ wlod_tile_kernel(const uint32_t *__restrict__ packed,
         const uint32_t gm = (vm >> (grp * R)) & ((1u << R) - 1u);
         if (gm != 0) {
             if (FROM_SCORES)
-                wlod_group_scores<R>(wtab + ((col >> 6) * p.score_rows) * WAVE + (col & 63), G0 + grp * R,
+                wlod_group_scores<R>(wtab + ((col >> 6) * p.score_rows) * WAVE + (col & 63), p.decay, G0 + grp * R,
                                      D + (c.loc_base + s0 + grp * R) * (int64_t)W, W, acc);
             else
                 wlod_group<R>(rows + grp * R * 4, gcol, G0 + grp * R,
