@@ -21,7 +21,7 @@ SYMBOLS = [
     "garlic_hip_abi_version", "garlic_hip_last_error", "garlic_hip_device_count",
     "garlic_ctx_create", "garlic_ctx_destroy", "garlic_ctx_synchronize",
     "garlic_panel_create", "garlic_panel_destroy", "garlic_panel_set_map",
-    "garlic_panel_set_freq", "garlic_panel_set_genotypes", "garlic_panel_set_gl",
+    "garlic_panel_set_freq", "garlic_panel_set_genotypes", "garlic_panel_set_gl", "garlic_panel_set_phase",
     "garlic_panel_set_ld", "garlic_lod_out_layout", "garlic_lod_windows",
     "garlic_wlod_windows", "garlic_lod_flatten", "garlic_last_call_stats",
     "garlic_panel_compute_ld", "garlic_ld_counts", "garlic_ld_finish", "garlic_roh_coverage",
@@ -71,6 +71,7 @@ def lib():
     L.garlic_panel_set_freq.argtypes = [_vp, _f64p]
     L.garlic_panel_set_genotypes.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
     L.garlic_panel_set_gl.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
+    L.garlic_panel_set_phase.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
     L.garlic_panel_set_ld.argtypes = [_vp, C.c_int32, _vp, C.c_int32]
     L.garlic_lod_out_layout.argtypes = [_vp, C.c_int32, C.c_int32, _i64p, _i64p, _i64p]
     L.garlic_lod_windows.argtypes = [_vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32,
@@ -79,9 +80,9 @@ def lib():
                                       C.c_double, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32]
     L.garlic_lod_flatten.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int64, _i64p]
     L.garlic_last_call_stats.argtypes = [_vp, C.POINTER(CallStats)]
-    L.garlic_panel_compute_ld.argtypes = [_vp, C.c_int32, _i32p, C.c_int32, _vp, C.c_int32]
-    L.garlic_ld_counts.argtypes = [_vp, C.c_int32, _i32p, C.c_int32, _vp, _vp, C.c_int32]
-    L.garlic_ld_finish.argtypes = [_vp, C.c_int32, _vp, _vp, _vp, C.c_int32]
+    L.garlic_panel_compute_ld.argtypes = [_vp, C.c_int32, C.c_int32, _i32p, C.c_int32, _vp, C.c_int32]
+    L.garlic_ld_counts.argtypes = [_vp, C.c_int32, C.c_int32, _i32p, C.c_int32, _vp, _vp, C.c_int32]
+    L.garlic_ld_finish.argtypes = [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32]
     L.garlic_lod_feed.argtypes = [_vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_double, C.c_int32, _vp, C.c_int64, _i64p, _i64p]
     L.garlic_roh_coverage.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, _vp, C.c_int32,
@@ -197,6 +198,14 @@ class Panel:
         check(lib().garlic_panel_set_gl(self.handle, _vp(gl.ctypes.data), gl.strides[0] // 8, locus_begin,
                                         gl.shape[0], HOST))
 
+    def set_phase(self, first_copy, locus_begin=0):
+        """first_copy: uint8/bool [nloci_chunk][nind], HapData::firstCopy (--phased)."""
+        fc = np.ascontiguousarray(first_copy).view(np.uint8) if np.asarray(first_copy).dtype == np.bool_ \
+            else np.ascontiguousarray(first_copy, dtype=np.uint8)
+        assert fc.ndim == 2 and fc.shape[1] >= self.nind
+        check(lib().garlic_panel_set_phase(self.handle, _vp(fc.ctypes.data), fc.shape[1], locus_begin,
+                                           fc.shape[0], HOST))
+
     def set_gl_device(self, ptr, ld, locus_begin, locus_count):
         """ptr: device address of float64 [locus_count][ld] per-genotype error probabilities."""
         check(lib().garlic_panel_set_gl(self.handle, _vp(ptr), ld, locus_begin, locus_count, DEVICE))
@@ -224,41 +233,42 @@ class Panel:
         sub = np.ascontiguousarray(sub_idx, dtype=np.int32)
         return sub, int(sub.shape[0])
 
-    def compute_ld(self, winsize, sub_idx=None, want_output=True):
-        """calcHR2LD on the device (sub_idx: the --ld-subsample individuals, None = all); installs
-        the weights for wlod_windows and returns them as float64 [nloci][winsize]."""
+    def compute_ld(self, winsize, sub_idx=None, want_output=True, phased=False):
+        """calcHR2LD (phased: calcR2LD) on the device (sub_idx: the --ld-subsample individuals,
+        None = all); installs the weights for wlod_windows and returns them as float64
+        [nloci][winsize]."""
         sub, n = self._sub(sub_idx)
         out = np.empty((self.nloci, winsize), dtype=np.float64) if want_output else None
-        check(lib().garlic_panel_compute_ld(self.handle, winsize, _ptr(sub, _i32p), n,
+        check(lib().garlic_panel_compute_ld(self.handle, winsize, int(phased), _ptr(sub, _i32p), n,
                                             _vp(out.ctypes.data) if want_output else None, HOST))
         return out
 
-    def ld_counts(self, winsize, sub_idx=None):
+    def ld_counts(self, winsize, sub_idx=None, phased=False):
         """Integer part of the LD weights for this shard's individuals: (locus_counts [nloci][2],
         pair_counts [nloci][winsize][2]) int32; sum over shards, then ld_finish."""
         sub, n = self._sub(sub_idx)
         loc = np.empty((self.nloci, 2), dtype=np.int32)
         pair = np.empty((self.nloci, winsize, 2), dtype=np.int32)
-        check(lib().garlic_ld_counts(self.handle, winsize, _ptr(sub, _i32p), n, _vp(loc.ctypes.data),
+        check(lib().garlic_ld_counts(self.handle, winsize, int(phased), _ptr(sub, _i32p), n, _vp(loc.ctypes.data),
                                      _vp(pair.ctypes.data), HOST))
         return loc, pair
 
-    def ld_finish(self, winsize, locus_counts, pair_counts, want_output=True):
+    def ld_finish(self, winsize, locus_counts, pair_counts, want_output=True, phased=False):
         loc = np.ascontiguousarray(locus_counts, dtype=np.int32)
         pair = np.ascontiguousarray(pair_counts, dtype=np.int32)
         assert loc.shape == (self.nloci, 2) and pair.shape == (self.nloci, winsize, 2)
         out = np.empty((self.nloci, winsize), dtype=np.float64) if want_output else None
-        check(lib().garlic_ld_finish(self.handle, winsize, _vp(loc.ctypes.data), _vp(pair.ctypes.data),
+        check(lib().garlic_ld_finish(self.handle, winsize, int(phased), _vp(loc.ctypes.data), _vp(pair.ctypes.data),
                                      _vp(out.ctypes.data) if want_output else None, HOST))
         return out
 
-    def ld_counts_device(self, winsize, locus_ptr, pair_ptr, sub_idx=None):
+    def ld_counts_device(self, winsize, locus_ptr, pair_ptr, sub_idx=None, phased=False):
         sub, n = self._sub(sub_idx)
-        check(lib().garlic_ld_counts(self.handle, winsize, _ptr(sub, _i32p), n, _vp(locus_ptr),
+        check(lib().garlic_ld_counts(self.handle, winsize, int(phased), _ptr(sub, _i32p), n, _vp(locus_ptr),
                                      _vp(pair_ptr), DEVICE))
 
-    def ld_finish_device(self, winsize, locus_ptr, pair_ptr, ld_ptr=None):
-        check(lib().garlic_ld_finish(self.handle, winsize, _vp(locus_ptr), _vp(pair_ptr),
+    def ld_finish_device(self, winsize, locus_ptr, pair_ptr, ld_ptr=None, phased=False):
+        check(lib().garlic_ld_finish(self.handle, winsize, int(phased), _vp(locus_ptr), _vp(pair_ptr),
                                      _vp(ld_ptr) if ld_ptr else None, DEVICE))
 
     def out_layout(self, pitch_align=1, nind_out=None):

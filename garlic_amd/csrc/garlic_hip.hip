@@ -160,6 +160,8 @@ struct garlic_panel {
     bool have_ld = false, wlod_use_gl = false;
     int32_t ld_winsize = 0;
     DevBuf<double> d_rld, d_decay, d_stage64;
+    DevBuf<uint64_t> d_phase;                      // HapData::firstCopy as bit planes [blk][nloci] (--phased LD)
+    bool have_phase = false;
     // tuned wLOD path: skewed reciprocal weights, per-SNP score rows, window mask, tile index
     DevBuf<double> d_skew, d_wtab;
     DevBuf<uint8_t> d_valid;
@@ -833,7 +835,7 @@ int garlic_panel_destroy(garlic_panel *p)
     p->d_chr_off.release(); p->d_tab.release(); p->d_blk_counts.release();
     p->d_blk_offsets.release(); p->d_total.release(); p->d_boundaries.release();
     p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release(); p->d_row_counts.release(); p->d_codes.release(); p->d_tabgl.release();
-    p->d_rld.release(); p->d_decay.release(); p->d_stage64.release();
+    p->d_rld.release(); p->d_decay.release(); p->d_stage64.release(); p->d_phase.release();
     p->d_glterms.release(); p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release();
     p->d_out.release();
     delete p;
@@ -973,6 +975,48 @@ int garlic_panel_set_gl(garlic_panel *p, const double *gl, int64_t ld, int64_t l
     return GARLIC_OK;
 }
 
+int garlic_panel_set_phase(garlic_panel *p, const uint8_t *first_copy, int64_t ld, int64_t locus_begin,
+                           int64_t locus_count, int32_t where)
+{
+    if (!p || !first_copy) return fail(GARLIC_ERR_INVALID, "panel and first_copy are required");
+    if (ld < p->nind) return fail(GARLIC_ERR_INVALID, "ld %lld < nind %d", (long long)ld, p->nind);
+    if (locus_begin < 0 || locus_count < 1 || locus_begin + locus_count > p->nloci)
+        return fail(GARLIC_ERR_INVALID, "locus range [%lld,+%lld) outside panel of %lld loci",
+                    (long long)locus_begin, (long long)locus_count, (long long)p->nloci);
+    int rc;
+    if ((rc = set_device(p->ctx))) return rc;
+    hipStream_t s = p->ctx->stream;
+    const int nblk = (int)(p->nind_pad / WAVE);
+    if (!p->d_phase.p) {
+        if ((rc = p->d_phase.reserve((size_t)nblk * p->nloci))) return rc;
+        HIP_TRY(hipMemsetAsync(p->d_phase.p, 0, sizeof(uint64_t) * nblk * p->nloci, s));
+    }
+    DevBuf<uint8_t> stage;
+    const int64_t slab_rows = (where == GARLIC_HOST) ? std::max<int64_t>(16, ((int64_t)256 << 20) / ld)
+                                                     : locus_count;
+    for (int64_t done = 0; done < locus_count; done += slab_rows) {
+        const int64_t rows = std::min(slab_rows, locus_count - done);
+        const uint8_t *src = first_copy + done * ld;
+        hipError_t e = hipSuccess;
+        if (where == GARLIC_HOST) {
+            if ((rc = stage.reserve((size_t)(rows * ld)))) { stage.release(); return rc; }
+            e = hipMemcpyAsync(stage.p, src, (size_t)(rows * ld), hipMemcpyHostToDevice, s);
+            src = stage.p;
+        }
+        if (e == hipSuccess) {
+            const int64_t waves = rows * nblk;
+            hipLaunchKernelGGL(phase_planes_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, src,
+                               ld, locus_begin + done, rows, p->nind, nblk, p->nloci, p->d_phase.p);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);                      // staging buffer is reused
+        if (e != hipSuccess) { stage.release(); return fail(GARLIC_ERR_HIP, "set_phase: %s", hipGetErrorString(e)); }
+    }
+    stage.release();
+    p->have_phase = true;
+    return GARLIC_OK;
+}
+
 // reciprocals of device-resident LD weights, plain and skewed (what the wLOD kernels read)
 static int install_ld(garlic_panel *p, int32_t winsize, const double *src)
 {
@@ -1018,20 +1062,25 @@ int garlic_panel_set_ld(garlic_panel *p, int32_t winsize, const double *ld, int3
 }
 
 // ---- LD weights on the device (ld_kernels.hpp)
-static int ld_check(garlic_panel *p, int32_t winsize)
+static int ld_check(garlic_panel *p, int32_t winsize, int32_t phased)
 {
     if (!p) return fail(GARLIC_ERR_INVALID, "panel is NULL");
+    if (!p->have_geno) return fail(GARLIC_ERR_STATE, "panel needs genotypes before LD weights");
+    if (phased && !p->have_phase)
+        return fail(GARLIC_ERR_STATE, "phased LD weights need garlic_panel_set_phase first");
+    if (phased && !p->have_freq)
+        return fail(GARLIC_ERR_STATE, "phased LD weights need the allele frequencies (garlic_panel_set_freq)");
     if (winsize <= 1) return fail(GARLIC_ERR_INVALID, "winsize must be > 1");
     if ((int64_t)p->nloci * winsize * 2 >= ((int64_t)1 << 40))
         return fail(GARLIC_ERR_INVALID, "LD table of %lld x %d too large", (long long)p->nloci, winsize);
     return set_device(p->ctx);
 }
 
-int garlic_ld_counts(garlic_panel *p, int32_t winsize, const int32_t *sub_idx, int32_t n_sub,
+int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int32_t *sub_idx, int32_t n_sub,
                      int32_t *locus_counts, int32_t *pair_counts, int32_t where)
 {
     int rc;
-    if ((rc = ld_check(p, winsize))) return rc;
+    if ((rc = ld_check(p, winsize, phased))) return rc;
     if (!locus_counts || !pair_counts) return fail(GARLIC_ERR_INVALID, "count buffers are required");
     if (n_sub < 0 || (n_sub > 0 && !sub_idx)) return fail(GARLIC_ERR_INVALID, "bad LD subsample");
     hipStream_t s = p->ctx->stream;
@@ -1051,11 +1100,12 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, const int32_t *sub_idx, i
             sub[i >> 6] |= (uint64_t)1 << (i & 63);
         }
     }
-    DevBuf<uint64_t> d_sub, d_m, d_h;
+    DevBuf<uint64_t> d_sub, d_m, d_h, d_o;
     DevBuf<int32_t> d_loc, d_pair;
-    auto done = [&](int code) { d_sub.release(); d_m.release(); d_h.release(); d_loc.release(); d_pair.release(); return code; };
+    auto done = [&](int code) { d_sub.release(); d_m.release(); d_h.release(); d_o.release(); d_loc.release(); d_pair.release(); return code; };
     const size_t npl = (size_t)nblk * p->nloci, npair = (size_t)p->nloci * winsize * 2;
     if ((rc = d_sub.reserve(nblk)) || (rc = d_m.reserve(npl)) || (rc = d_h.reserve(npl))) return done(rc);
+    if (phased && (rc = d_o.reserve(npl))) return done(rc);
     int32_t *loc = locus_counts, *pair = pair_counts;
     if (where == GARLIC_HOST) {
         if ((rc = d_loc.reserve((size_t)p->nloci * 2)) || (rc = d_pair.reserve(npair))) return done(rc);
@@ -1064,11 +1114,21 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, const int32_t *sub_idx, i
     hipError_t e = hipMemcpyAsync(d_sub.p, sub.data(), sizeof(uint64_t) * nblk, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(pair, 0, sizeof(int32_t) * npair, s);
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
-    hipLaunchKernelGGL(ld_planes_kernel, dim3((unsigned)p->nwordrows), dim3(256), 0, s, p->d_packed.p,
-                       p->nwordrows, nblk, d_sub.p, p->nloci, d_m.p, d_h.p, loc);
-    for (int c = 0; c < p->nchr; c++)
-        hipLaunchKernelGGL(ld_pair_kernel, dim3((unsigned)p->chr_nloci[c]), dim3(256), 0, s, d_m.p, d_h.p,
-                           nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1], winsize, pair);
+    if (phased)
+        hipLaunchKernelGGL(ld_planes_kernel<true>, dim3((unsigned)p->nwordrows), dim3(256), 0, s, p->d_packed.p,
+                           p->nwordrows, nblk, d_sub.p, p->nloci, d_m.p, d_h.p, d_o.p, loc);
+    else
+        hipLaunchKernelGGL(ld_planes_kernel<false>, dim3((unsigned)p->nwordrows), dim3(256), 0, s, p->d_packed.p,
+                           p->nwordrows, nblk, d_sub.p, p->nloci, d_m.p, d_h.p, (uint64_t *)nullptr, loc);
+    for (int c = 0; c < p->nchr; c++) {
+        if (phased)
+            hipLaunchKernelGGL(ld_pair_phased_kernel, dim3((unsigned)p->chr_nloci[c]), dim3(256), 0, s, d_m.p,
+                               d_h.p, d_o.p, p->d_phase.p, nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1],
+                               winsize, pair);
+        else
+            hipLaunchKernelGGL(ld_pair_kernel, dim3((unsigned)p->chr_nloci[c]), dim3(256), 0, s, d_m.p, d_h.p,
+                               nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1], winsize, pair);
+    }
     e = hipGetLastError();
     if (e == hipSuccess && where == GARLIC_HOST) {
         e = hipMemcpyAsync(locus_counts, loc, sizeof(int32_t) * p->nloci * 2, hipMemcpyDeviceToHost, s);
@@ -1080,11 +1140,11 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, const int32_t *sub_idx, i
     return done(GARLIC_OK);
 }
 
-int garlic_ld_finish(garlic_panel *p, int32_t winsize, const int32_t *locus_counts,
+int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int32_t *locus_counts,
                      const int32_t *pair_counts, double *ld_out, int32_t where)
 {
     int rc;
-    if ((rc = ld_check(p, winsize))) return rc;
+    if ((rc = ld_check(p, winsize, phased))) return rc;
     if (!locus_counts || !pair_counts) return fail(GARLIC_ERR_INVALID, "count buffers are required");
     hipStream_t s = p->ctx->stream;
     const size_t n = (size_t)p->nloci * winsize;
@@ -1108,8 +1168,13 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, const int32_t *locus_coun
     }
     if (e == hipSuccess) e = hipMemsetAsync(ld, 0, sizeof(double) * n, s);   // initLDData zero-fills
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
-    hipLaunchKernelGGL(ld_homfreq_kernel, dim3((unsigned)((p->nloci + 255) / 256)), dim3(256), 0, s, loc,
-                       p->nloci, d_hf.p);
+    if (phased) {       // r2 takes FreqData::freq where hr2 takes homFreq (garlic-data.cpp:587-588)
+        e = hipMemcpyAsync(d_hf.p, p->freq.data(), sizeof(double) * p->nloci, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
+    } else {
+        hipLaunchKernelGGL(ld_homfreq_kernel, dim3((unsigned)((p->nloci + 255) / 256)), dim3(256), 0, s, loc,
+                           p->nloci, d_hf.p);
+    }
     for (int c = 0; c < p->nchr; c++) {
         const int64_t lo = p->chr_off[c], hi = p->chr_off[c + 1];
         hipLaunchKernelGGL(ld_hr2_kernel, dim3((unsigned)(hi - lo)), dim3(256), 0, s, pair, d_hf.p, lo, hi,
@@ -1129,22 +1194,22 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, const int32_t *locus_coun
     return done(GARLIC_OK);
 }
 
-int garlic_panel_compute_ld(garlic_panel *p, int32_t winsize, const int32_t *sub_idx, int32_t n_sub,
-                            double *ld_out, int32_t where)
+int garlic_panel_compute_ld(garlic_panel *p, int32_t winsize, int32_t phased, const int32_t *sub_idx,
+                            int32_t n_sub, double *ld_out, int32_t where)
 {
     int rc;
-    if ((rc = ld_check(p, winsize))) return rc;
+    if ((rc = ld_check(p, winsize, phased))) return rc;
     DevBuf<int32_t> d_loc, d_pair;
     auto done = [&](int code) { d_loc.release(); d_pair.release(); return code; };
     if ((rc = d_loc.reserve((size_t)p->nloci * 2)) || (rc = d_pair.reserve((size_t)p->nloci * winsize * 2)))
         return done(rc);
-    if ((rc = garlic_ld_counts(p, winsize, sub_idx, n_sub, d_loc.p, d_pair.p, GARLIC_DEVICE))) return done(rc);
+    if ((rc = garlic_ld_counts(p, winsize, phased, sub_idx, n_sub, d_loc.p, d_pair.p, GARLIC_DEVICE))) return done(rc);
     if (where == GARLIC_DEVICE || !ld_out)
-        return done(garlic_ld_finish(p, winsize, d_loc.p, d_pair.p, ld_out, GARLIC_DEVICE));
+        return done(garlic_ld_finish(p, winsize, phased, d_loc.p, d_pair.p, ld_out, GARLIC_DEVICE));
     // host output: finish on the device, then copy out
     DevBuf<double> d_ld;
     if ((rc = d_ld.reserve((size_t)p->nloci * winsize))) return done(rc);
-    rc = garlic_ld_finish(p, winsize, d_loc.p, d_pair.p, d_ld.p, GARLIC_DEVICE);
+    rc = garlic_ld_finish(p, winsize, phased, d_loc.p, d_pair.p, d_ld.p, GARLIC_DEVICE);
     if (rc == GARLIC_OK) {
         hipError_t e = hipMemcpy(ld_out, d_ld.p, sizeof(double) * p->nloci * winsize, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(GARLIC_ERR_HIP, "LD copy-out: %s", hipGetErrorString(e));

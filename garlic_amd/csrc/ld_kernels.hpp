@@ -9,6 +9,14 @@
 //   LD[s][k]    = sum_{i = s .. s+W-1, in this order, from 0.0}  (i == s+k ? 1 : hr2(i, s+k))
 //                 for s <= nloci_c - W, 0 elsewhere                                  (:474-527)
 //
+// --phased (calcR2LD / r2, :426-535, 585-617) differs only in the pair statistic: with p = FreqData::freq,
+//   r2(i, j)    = 0 unless 0 < p < 1 at both SNPs; else with, over the LD subsample,
+//                   total = 2 * #(both non-missing),
+//                   x11   = 2 * #(2,2) + #(1,2) + #(2,1) + #(1,1 and firstCopy equal)
+//                 x11 /= total;  D = x11 - pi*pj;  min(1, D*D / (pi*(1-pi)*pj*(1-pj)))
+// -- the same expression as hr2 with (HA, HB, HAB, total) := (pi, pj, x11, total), so only the
+// planes and the pair counts have a phased variant.
+//
 // Split so that individuals can be sharded over GPUs: everything that depends on genotypes is an
 // INTEGER count (exact, order-free), summed over shards by the caller (RCCL all-reduce); the
 // floating-point part is replicated and runs in the reference's operation order.
@@ -28,10 +36,13 @@ namespace garlic {
 // planes: [blk][nloci] 64-bit masks, bit = individual of the block;  M = non-missing and in the LD
 // subsample, H = M and homozygous.  counts: [nloci][2] = {homozygous, non-missing} over every
 // individual of the shard (homFreq does not use the subsample, garlic-data.cpp:656).
+// PHASED: planeH holds "genotype 2" instead of "homozygous", planeO "genotype 1" (both within the
+// subsample); the counts stay {homozygous, non-missing}.
+template <bool PHASED>
 __global__ void __launch_bounds__(256)
 ld_planes_kernel(const uint32_t *__restrict__ packed, int64_t nwordrows, int nblk,
                  const uint64_t *__restrict__ submask, int64_t nloci, uint64_t *__restrict__ planeM,
-                 uint64_t *__restrict__ planeH, int32_t *__restrict__ counts)
+                 uint64_t *__restrict__ planeH, uint64_t *__restrict__ planeO, int32_t *__restrict__ counts)
 {
     __shared__ int32_t red[4][16][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -52,7 +63,15 @@ ld_planes_kernel(const uint32_t *__restrict__ packed, int64_t nwordrows, int nbl
                 const int64_t l = l0 + q;
                 if (l >= 0 && l < nloci) {
                     planeM[(int64_t)blk * nloci + l] = m & sub;
-                    planeH[(int64_t)blk * nloci + l] = h & sub;
+                    if (!PHASED) planeH[(int64_t)blk * nloci + l] = h & sub;
+                }
+            }
+            if (PHASED) {
+                const uint64_t two = __ballot(code == 2u), one = __ballot(code == 1u);
+                const int64_t l = l0 + q;
+                if (lane == q && l >= 0 && l < nloci) {
+                    planeH[(int64_t)blk * nloci + l] = two & sub;
+                    planeO[(int64_t)blk * nloci + l] = one & sub;
                 }
             }
         }
@@ -89,6 +108,47 @@ ld_pair_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__
         pair[(i * W + d) * 2 + 0] = tot;
         pair[(i * W + d) * 2 + 1] = hab;
     }
+}
+
+// --phased pair counts: pair = {2 * #(both non-missing), x11}  (r2, garlic-data.cpp:592-606)
+__global__ void __launch_bounds__(256)
+ld_pair_phased_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__ planeT,
+                      const uint64_t *__restrict__ planeO, const uint64_t *__restrict__ planeF, int nblk,
+                      int64_t nloci, int64_t lo, int64_t hi, int W, int32_t *__restrict__ pair)
+{
+    const int64_t i = lo + blockIdx.x;
+    for (int d = 1 + threadIdx.x; d < W; d += blockDim.x) {
+        const int64_t j = i + d;
+        int32_t tot = 0, x11 = 0;
+        if (j < hi) {
+            for (int blk = 0; blk < nblk; blk++) {
+                const int64_t base = (int64_t)blk * nloci;
+                const uint64_t ti = planeT[base + i], tj = planeT[base + j];
+                const uint64_t oi = planeO[base + i], oj = planeO[base + j];
+                tot += 2 * __popcll(planeM[base + i] & planeM[base + j]);
+                x11 += 2 * __popcll(ti & tj) + __popcll(oi & tj) + __popcll(ti & oj) +
+                       __popcll(oi & oj & ~(planeF[base + i] ^ planeF[base + j]));
+            }
+        }
+        pair[(i * W + d) * 2 + 0] = tot;
+        pair[(i * W + d) * 2 + 1] = x11;
+    }
+}
+
+// HapData::firstCopy rows (uint8 [count][ld], loci [l0, l0 + count)) -> bit planes [blk][nloci];
+// one wave per (locus, 64-individual block)
+__global__ void __launch_bounds__(256)
+phase_planes_kernel(const uint8_t *__restrict__ fc, int64_t ld, int64_t l0, int64_t count, int nind,
+                    int nblk, int64_t nloci, uint64_t *__restrict__ planeF)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave >= count * nblk) return;
+    const int64_t r = wave / nblk;
+    const int blk = (int)(wave % nblk);
+    const int ind = blk * WAVE + lane;
+    const uint64_t bits = __ballot(ind < nind && fc[r * ld + ind] != 0);
+    if (lane == 0) planeF[(int64_t)blk * nloci + l0 + r] = bits;
 }
 
 __global__ void ld_homfreq_kernel(const int32_t *__restrict__ counts, int64_t nloci, double *__restrict__ hf)

@@ -143,24 +143,33 @@ int centromere::centromereEnd(const std::string &chr)
 }
 
 // ------------------------------------------------------------------------- structs
-HapData *initHapData(unsigned int nind, unsigned int nloci)
+HapData *initHapData(unsigned int nind, unsigned int nloci, bool PHASED)
 {
     if (nind < 1 || nloci < 1) fail("Can not allocate HapData object: counts must be positive.");
     HapData *d = new HapData;
     d->nind = nind;
     d->nloci = nloci;
     d->data = new short *[nloci];
+    d->firstCopy = PHASED ? new bool *[nloci] : nullptr;
     for (unsigned l = 0; l < nloci; l++) {
         d->data[l] = new short[nind];
         std::fill(d->data[l], d->data[l] + nind, (short)MISSING);
+        if (PHASED) {
+            d->firstCopy[l] = new bool[nind];
+            std::fill(d->firstCopy[l], d->firstCopy[l] + nind, false);
+        }
     }
     return d;
 }
 void releaseHapData(HapData *d)
 {
     if (!d) return;
-    for (int l = 0; l < d->nloci; l++) delete[] d->data[l];
+    for (int l = 0; l < d->nloci; l++) {
+        delete[] d->data[l];
+        if (d->firstCopy) delete[] d->firstCopy[l];
+    }
     delete[] d->data;
+    delete[] d->firstCopy;
     delete d;
 }
 void releaseHapData(std::vector<HapData *> *v) { for (auto d : *v) releaseHapData(d); delete v; }
@@ -308,7 +317,7 @@ void releaseIndData(IndData *d) { if (d) { delete[] d->indID; delete d; } }
 
 // ------------------------------------------------------------------------- ingest
 namespace {
-void flushChromosome(const std::string &chr, std::vector<short *> &hap, std::vector<double> &gpos,
+void flushChromosome(const std::string &chr, std::vector<short *> &hap, std::vector<bool *> &fc, std::vector<double> &gpos,
                      std::vector<double> &ppos, std::vector<std::string> &names, std::vector<char> &allele,
                      std::vector<double> &freq, int numInd, std::vector<HapData *> *haps,
                      std::vector<MapData *> *maps, std::vector<FreqData *> *freqs)
@@ -320,8 +329,10 @@ void flushChromosome(const std::string &chr, std::vector<short *> &hap, std::vec
     h->nind = numInd;
     h->nloci = n;
     h->data = new short *[n];
+    h->firstCopy = fc.empty() ? nullptr : new bool *[n];
     FreqData *f = initFreqData(n);
     for (int l = 0; l < n; l++) {
+        if (h->firstCopy) h->firstCopy[l] = fc[l];
         m->physicalPos[l] = (int)ppos[l]; // read as double, stored as int (garlic-data.cpp:41,229)
         m->geneticPos[l] = gpos[l];
         m->locusName[l] = names[l];
@@ -332,19 +343,20 @@ void flushChromosome(const std::string &chr, std::vector<short *> &hap, std::vec
     maps->push_back(m);
     haps->push_back(h);
     freqs->push_back(f);
-    hap.clear(); gpos.clear(); ppos.clear(); names.clear(); allele.clear(); freq.clear();
+    hap.clear(); fc.clear(); gpos.clear(); ppos.clear(); names.clear(); allele.clear(); freq.clear();
 }
 } // namespace
 
 void loadTPEDData(const std::string &tpedfile, int &numLoci, int &numInd, std::vector<HapData *> **hapDataByChr,
                   std::vector<MapData *> **mapDataByChr, std::vector<FreqData *> **freqDataByChr,
-                  char TPED_MISSING)
+                  char TPED_MISSING, bool PHASED)
 {
     LineReader in(tpedfile);
     *hapDataByChr = new std::vector<HapData *>;
     *mapDataByChr = new std::vector<MapData *>;
     *freqDataByChr = new std::vector<FreqData *>;
     std::vector<short *> hap;
+    std::vector<bool *> fc;
     std::vector<double> gpos, ppos, freq;
     std::vector<std::string> names;
     std::vector<char> allele;
@@ -360,11 +372,12 @@ void loadTPEDData(const std::string &tpedfile, int &numLoci, int &numInd, std::v
         ss >> chr >> name >> g >> p;
         if (numLoci == 1) prevChr = chr;
         if (chr != prevChr) { // new chromosome when the chr string changes (garlic-data.cpp:68-91)
-            flushChromosome(prevChr, hap, gpos, ppos, names, allele, freq, numInd, *hapDataByChr,
+            flushChromosome(prevChr, hap, fc, gpos, ppos, names, allele, freq, numInd, *hapDataByChr,
                             *mapDataByChr, *freqDataByChr);
             prevChr = chr;
         }
         short *data = new short[numInd];
+        bool *first = PHASED ? new bool[numInd] : nullptr;
         char one = TPED_MISSING; // the first non-missing allele on the line is the counted one
         int nalleles = 0, total = 0;
         for (int i = 0; i < numInd; i++) {
@@ -378,8 +391,10 @@ void loadTPEDData(const std::string &tpedfile, int &numLoci, int &numInd, std::v
                 else { total++; if (a == one) { v += 1; nalleles++; } }
             }
             data[i] = (short)(v < 0 ? -9 : v);
+            if (first) first[i] = (a1 == one);   // garlic-data.cpp:129
         }
         hap.push_back(data);
+        if (first) fc.push_back(first);
         gpos.push_back(g);
         ppos.push_back(p);
         names.push_back(name);
@@ -387,7 +402,7 @@ void loadTPEDData(const std::string &tpedfile, int &numLoci, int &numInd, std::v
         freq.push_back(total == 0 ? 0.0 : double(nalleles) / double(total)); // garlic-data.cpp:140-141
     }
     if (numLoci == 0) fail("no loci in " + tpedfile);
-    flushChromosome(chr, hap, gpos, ppos, names, allele, freq, numInd, *hapDataByChr, *mapDataByChr,
+    flushChromosome(chr, hap, fc, gpos, ppos, names, allele, freq, numInd, *hapDataByChr, *mapDataByChr,
                     *freqDataByChr);
 }
 
@@ -515,20 +530,26 @@ void filterSites(size_t c, const std::vector<char> &keep, std::vector<MapData *>
     if (n < 1) fail("no sites left on " + m->chr + " after filtering");
     MapData *m2 = initMapData(n);
     m2->chr = m->chr;
-    HapData *h2 = new HapData{new short *[n], h->nind, n};
+    HapData *h2 = new HapData{new short *[n], h->nind, n, h->firstCopy ? new bool *[n] : nullptr};
     FreqData *f2 = initFreqData(n);
     GenoLikeData *g2 = g ? new GenoLikeData{new double *[n], g->nind, n} : nullptr;
     int j = 0;
     for (int l = 0; l < m->nloci; l++) {
-        if (!keep[l]) { delete[] h->data[l]; if (g) delete[] g->data[l]; continue; }
+        if (!keep[l]) {
+            delete[] h->data[l];
+            if (h->firstCopy) delete[] h->firstCopy[l];
+            if (g) delete[] g->data[l];
+            continue;
+        }
         m2->physicalPos[j] = m->physicalPos[l]; m2->geneticPos[j] = m->geneticPos[l];
         m2->locusName[j] = m->locusName[l]; m2->allele[j] = m->allele[l];
         h2->data[j] = h->data[l];
+        if (h->firstCopy) h2->firstCopy[j] = h->firstCopy[l];
         f2->freq[j] = f->freq[l];
         if (g) g2->data[j] = g->data[l];
         j++;
     }
-    delete[] h->data; delete h;
+    delete[] h->data; delete[] h->firstCopy; delete h;
     if (g) { delete[] g->data; delete g; (*gls)[c] = g2; }
     releaseMapData(m); releaseFreqData(f);
     (*maps)[c] = m2; (*haps)[c] = h2; (*freqs)[c] = f2;
@@ -635,7 +656,8 @@ int interpolateGeneticmap(std::vector<MapData *> *maps, std::vector<GenMapScaffo
 // ------------------------------------------------------------------------- genotype cache
 namespace {
 const char CACHE_MAGIC[8] = {'G', 'A', 'R', 'L', 'I', 'C', '2', 'B'};
-const uint32_t CACHE_VERSION = 1;
+const uint32_t CACHE_VERSION = 2;       // 2: a flags word after the chromosome count
+const uint32_t CACHE_FLAG_PHASE = 1;    // HapData::firstCopy rows (1 bit each) follow every chromosome's genotypes
 
 struct CacheOut {
     FILE *f;
@@ -671,8 +693,11 @@ void writeGenotypeCache(const std::string &path, std::vector<HapData *> *haps, s
     o.val<uint32_t>(CACHE_VERSION);
     o.val<uint32_t>((uint32_t)nind);
     o.val<uint32_t>((uint32_t)maps->size());
-    const size_t row = ((size_t)nind + 3) / 4;
-    std::vector<uint8_t> bits(row);
+    bool phased = true;
+    for (auto h : *haps) phased = phased && h->firstCopy;
+    o.val<uint32_t>(phased ? CACHE_FLAG_PHASE : 0u);
+    const size_t row = ((size_t)nind + 3) / 4, prow = ((size_t)nind + 7) / 8;
+    std::vector<uint8_t> bits(row), pbits(prow);
     for (size_t c = 0; c < maps->size(); c++) {
         const MapData *m = maps->at(c);
         const HapData *h = haps->at(c);
@@ -692,6 +717,13 @@ void writeGenotypeCache(const std::string &path, std::vector<HapData *> *haps, s
             }
             o.put(bits.data(), row);
         }
+        if (phased)
+            for (int l = 0; l < m->nloci; l++) {   // HapData::firstCopy, one bit per individual
+                std::fill(pbits.begin(), pbits.end(), 0);
+                for (int i = 0; i < nind; i++)
+                    if (h->firstCopy[l][i]) pbits[i >> 3] |= (uint8_t)(1u << (i & 7));
+                o.put(pbits.data(), prow);
+            }
     }
 }
 
@@ -705,12 +737,15 @@ void loadGenotypeCache(const std::string &path, int &numLoci, int &numInd, std::
     if (in.val<uint32_t>() != CACHE_VERSION) fail(path + ": unsupported genotype cache version");
     const int nind = (int)in.val<uint32_t>();
     const uint32_t nchr = in.val<uint32_t>();
-    if (nind < 1 || nchr < 1 || nchr > 100000) fail(path + ": corrupt genotype cache header");
+    const uint32_t flags = in.val<uint32_t>();
+    if (nind < 1 || nchr < 1 || nchr > 100000 || (flags & ~CACHE_FLAG_PHASE))
+        fail(path + ": corrupt genotype cache header");
+    const bool phased = (flags & CACHE_FLAG_PHASE) != 0;
     *haps = new std::vector<HapData *>;
     *maps = new std::vector<MapData *>;
     *freqs = new std::vector<FreqData *>;
-    const size_t row = ((size_t)nind + 3) / 4;
-    std::vector<uint8_t> bits(row);
+    const size_t row = ((size_t)nind + 3) / 4, prow = ((size_t)nind + 7) / 8;
+    std::vector<uint8_t> bits(row), pbits(prow);
     static const short DECODE[4] = {0, 1, 2, -9};
     numLoci = 0;
     for (uint32_t c = 0; c < nchr; c++) {
@@ -724,11 +759,19 @@ void loadGenotypeCache(const std::string &path, int &numLoci, int &numInd, std::
         FreqData *f = initFreqData(n);
         in.get(f->freq, sizeof(double) * n);
         for (int l = 0; l < n; l++) m->locusName[l] = in.str();
-        HapData *h = new HapData{new short *[n], nind, n};
+        HapData *h = new HapData{new short *[n], nind, n, nullptr};
         for (int l = 0; l < n; l++) {
             in.get(bits.data(), row);
             short *d = h->data[l] = new short[nind];
             for (int i = 0; i < nind; i++) d[i] = DECODE[(bits[i >> 2] >> (2 * (i & 3))) & 3];
+        }
+        if (phased) {
+            h->firstCopy = new bool *[n];
+            for (int l = 0; l < n; l++) {
+                in.get(pbits.data(), prow);
+                bool *d = h->firstCopy[l] = new bool[nind];
+                for (int i = 0; i < nind; i++) d[i] = (pbits[i >> 3] >> (i & 7)) & 1;
+            }
         }
         (*maps)->push_back(m); (*haps)->push_back(h); (*freqs)->push_back(f);
         numLoci += n;
@@ -750,6 +793,7 @@ struct LodEngine::Impl {
     std::vector<MapData *> *maps;
     int nind = 0;
     bool use_gl = false;
+    bool have_phase = false;   // every HapData carries firstCopy: the panels hold the phase planes
 };
 
 LodEngine::LodEngine(std::vector<HapData *> *haps, std::vector<FreqData *> *freqs, std::vector<MapData *> *maps,
@@ -795,6 +839,9 @@ LodEngine::LodEngine(std::vector<HapData *> *haps, std::vector<FreqData *> *freq
     const int64_t slab = std::max<int64_t>(1, ((int64_t)64 << 20) / (2 * (int64_t)impl->nind));
     std::vector<int16_t> stage;
     std::vector<double> stage_gl;
+    std::vector<uint8_t> stage_fc;
+    impl->have_phase = true;
+    for (auto h : *haps) impl->have_phase = impl->have_phase && h->firstCopy;
     o = 0;
     for (int c = 0; c < nchr; c++) {
         const HapData *h = haps->at(c);
@@ -808,9 +855,18 @@ LodEngine::LodEngine(std::vector<HapData *> *haps, std::vector<FreqData *> *freq
                 for (int r = 0; r < rows; r++)
                     memcpy(&stage_gl[(size_t)r * impl->nind], gls->at(c)->data[l0 + r], sizeof(double) * impl->nind);
             }
+            if (impl->have_phase) {
+                stage_fc.resize((size_t)rows * impl->nind);
+                for (int r = 0; r < rows; r++)
+                    for (int i = 0; i < impl->nind; i++)
+                        stage_fc[(size_t)r * impl->nind + i] = h->firstCopy[l0 + r][i];
+            }
             for (auto &s : impl->shards) {
                 check(garlic_panel_set_genotypes(s.panel, stage.data() + s.ind_begin, impl->nind, o + l0, rows,
                                                  GARLIC_HOST), "garlic_panel_set_genotypes");
+                if (impl->have_phase)
+                    check(garlic_panel_set_phase(s.panel, stage_fc.data() + s.ind_begin, impl->nind, o + l0, rows,
+                                                 GARLIC_HOST), "garlic_panel_set_phase");
                 if (USE_GL)
                     check(garlic_panel_set_gl(s.panel, stage_gl.data() + s.ind_begin, impl->nind, o + l0, rows,
                                               GARLIC_HOST), "garlic_panel_set_gl");
@@ -896,8 +952,11 @@ DoubleData *LodEngine::lodFeed(int winsize, double error, int MAX_GAP, int step,
     return d;
 }
 
-std::vector<LDData *> *LodEngine::ldWeights(int winsize, const std::vector<int> &subsample, bool want_host)
+std::vector<LDData *> *LodEngine::ldWeights(int winsize, const std::vector<int> &subsample, bool want_host,
+                                            bool phased)
 {
+    if (phased && !impl->have_phase) fail("--phased: the genotypes were loaded without phase (HapData::firstCopy)");
+    const int32_t ph = phased ? 1 : 0;
     std::cerr << "Calculating LD weights with winsize " << winsize << ".\n";
     int64_t nloci = 0;
     for (int n : impl->chr_nloci) nloci += n;
@@ -913,10 +972,10 @@ std::vector<LDData *> *LodEngine::ldWeights(int winsize, const std::vector<int> 
         lo.resize(loc.size()); pa.resize(pair.size());
         if (!subsample.empty() && sub.empty()) {   // none of the subsample lives here: only homFreq counts
             // (an empty list would mean "all": count everything, then drop the pair counts)
-            check(garlic_ld_counts(s.panel, winsize, nullptr, 0, lo.data(), pa.data(), GARLIC_HOST), "garlic_ld_counts");
+            check(garlic_ld_counts(s.panel, winsize, ph, nullptr, 0, lo.data(), pa.data(), GARLIC_HOST), "garlic_ld_counts");
             std::fill(pa.begin(), pa.end(), 0);
         } else {
-            check(garlic_ld_counts(s.panel, winsize, sub.empty() ? nullptr : sub.data(), (int32_t)sub.size(),
+            check(garlic_ld_counts(s.panel, winsize, ph, sub.empty() ? nullptr : sub.data(), (int32_t)sub.size(),
                                    lo.data(), pa.data(), GARLIC_HOST), "garlic_ld_counts");
         }
         if (!single) {
@@ -927,7 +986,7 @@ std::vector<LDData *> *LodEngine::ldWeights(int winsize, const std::vector<int> 
     std::vector<double> flat;
     if (want_host) flat.resize((size_t)nloci * winsize);
     for (size_t k = 0; k < impl->shards.size(); k++)
-        check(garlic_ld_finish(impl->shards[k].panel, winsize, loc.data(), pair.data(),
+        check(garlic_ld_finish(impl->shards[k].panel, winsize, ph, loc.data(), pair.data(),
                                (want_host && k == 0) ? flat.data() : nullptr, GARLIC_HOST), "garlic_ld_finish");
     if (!want_host) return nullptr;
     std::vector<LDData *> *out = new std::vector<LDData *>;
@@ -1001,9 +1060,9 @@ std::vector<LDData *> *calcLDData(std::vector<HapData *> *haps, std::vector<Freq
                                   centromere *centro, int winsize, int /*MAX_GAP*/, bool PHASED,
                                   int /*numThreads*/, int ldSubsample)
 {
-    if (PHASED) fail("--phased (r2 from haplotype phase) is not available: this engine holds unphased genotypes");
     LodEngine engine(haps, freqs, maps, nullptr, centro, false, g_options.devices);
-    return engine.ldWeights(winsize, drawLdSubsample(haps->at(0)->nind, ldSubsample, g_options.ld_seed));
+    return engine.ldWeights(winsize, drawLdSubsample(haps->at(0)->nind, ldSubsample, g_options.ld_seed), true,
+                            PHASED);
 }
 
 std::vector<WinData *> *calcLODWindows(std::vector<HapData *> *haps, std::vector<FreqData *> *freqs,

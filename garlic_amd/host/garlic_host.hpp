@@ -22,6 +22,7 @@ struct HapData {           // src/garlic-data.h:32-38
     short **data;          // [locus][ind]: copies of the counted allele, -9 = missing
     int nind;
     int nloci;
+    bool **firstCopy;      // --phased only (else NULL): the first allele of the pair is the counted one
 };
 struct MapData {           // src/garlic-data.h:51-60
     int *physicalPos;
@@ -83,7 +84,7 @@ private:
 std::string checkChrName(std::string chr); // "1" -> "chr1" (garlic-data.cpp:1886-1891)
 
 // ---- allocation helpers with the reference's semantics
-HapData *initHapData(unsigned int nind, unsigned int nloci);
+HapData *initHapData(unsigned int nind, unsigned int nloci, bool PHASED = false);   // garlic-data.cpp:1749
 void releaseHapData(HapData *d);
 void releaseHapData(std::vector<HapData *> *v);
 MapData *initMapData(int nloci);
@@ -110,7 +111,8 @@ void releaseIndData(IndData *d);
 // ---- ingest (what main does before the path, src/garlic-main.cpp:216-279)
 void loadTPEDData(const std::string &tpedfile, int &numLoci, int &numInd,
                   std::vector<HapData *> **hapDataByChr, std::vector<MapData *> **mapDataByChr,
-                  std::vector<FreqData *> **freqDataByChr, char TPED_MISSING);   // garlic-data.cpp:10
+                  std::vector<FreqData *> **freqDataByChr, char TPED_MISSING,
+                  bool PHASED = false);                                          // garlic-data.cpp:10
 void scanIndData3(const std::string &filename, int &numInd, std::string &popName);  // :1893
 IndData *readIndData3(const std::string &filename, int numInd);                     // :1963
 std::vector<GenoLikeData *> *readTGLSData(const std::string &filename, int expectedLoci, int expectedInd,
@@ -142,8 +144,9 @@ int interpolateGeneticmap(std::vector<MapData *> *mapDataByChr, std::vector<GenM
 // Binary sidecar of what loadTPEDData produces: parsing a 10M x 10k TPED is ~400 GB
 // of text and dwarfs the GPU time; the cache holds the same genotypes at 2 bits each (4 per byte,
 // SNP-major; 3 = missing), positions, genetic positions, locus names, counted alleles and
-// frequencies, and loads at memory speed.  Same (hap, map, freq) triple as the TPED path, so
-// everything downstream is unchanged.  `throw 0` on I/O or format errors.
+// frequencies, and loads at memory speed; if the genotypes were read with PHASED, also
+// HapData::firstCopy at 1 bit each.  Same (hap, map, freq) triple as the TPED path, so everything
+// downstream is unchanged.  `throw 0` on I/O or format errors.
 void writeGenotypeCache(const std::string &path, std::vector<HapData *> *hapDataByChr,
                         std::vector<MapData *> *mapDataByChr, std::vector<FreqData *> *freqDataByChr);
 void loadGenotypeCache(const std::string &path, int &numLoci, int &numInd,
@@ -175,7 +178,8 @@ std::vector<WinData *> *calcwLODWindows(std::vector<HapData *> *hapDataByChr,
 
 // LD weights of wLOD (garlic-data.cpp:330-375).  Same arguments as the reference; the counts come
 // from the device(s), so genoFreqDataByChr is not read (the device recomputes the same fractions
-// from the genotypes) and numThreads is ignored.  PHASED (calcR2LD) is refused: `throw 0`.
+// from the genotypes) and numThreads is ignored.  PHASED (calcR2LD) needs HapData::firstCopy
+// (loadTPEDData with PHASED), else `throw 0`.
 std::vector<LDData *> *calcLDData(std::vector<HapData *> *hapDataByChr, std::vector<FreqData *> *freqDataByChr,
                                   std::vector<MapData *> *mapDataByChr,
                                   std::vector<GenoFreqData *> *genoFreqDataByChr, centromere *centro,
@@ -198,7 +202,9 @@ public:
     // LD weights for winsize from the resident genotypes (subsample: panel-wide individual indices,
     // empty = all); they stay installed on the device(s) for wlodWindowsResident.  Returns the
     // reference-shaped host copy when want_host is set, else NULL.
-    std::vector<LDData *> *ldWeights(int winsize, const std::vector<int> &subsample, bool want_host = true);
+    // phased: calcR2LD (r2 from HapData::firstCopy and FreqData::freq) instead of calcHR2LD.
+    std::vector<LDData *> *ldWeights(int winsize, const std::vector<int> &subsample, bool want_host = true,
+                                     bool phased = false);
     std::vector<WinData *> *wlodWindowsResident(int winsize, double error, int MAX_GAP, int M, double mu);
     // What exploreWinsizes / selectWinsize keep of a window size (garlic-roh.cpp:741-745, 816-823):
     // convertWinData2DoubleData(calcLODWindows(...), step), with the scores thinned on the device(s)

@@ -127,8 +127,12 @@ int main(int argc, char **argv)
             fclose(probe);
             loadGenotypeCache(a.cache, numLoci, numInd, &haps, &maps, &freqs);
             std::cerr << "Loaded genotype cache " << a.cache << "\n";
+            if (a.phased && !haps->at(0)->firstCopy) {
+                std::cerr << "ERROR: --phased, but " << a.cache << " was written without phase; delete it to re-read the tped\n";
+                return 1;
+            }
         } else {
-            loadTPEDData(a.tped, numLoci, numInd, &haps, &maps, &freqs, a.tped_missing);
+            loadTPEDData(a.tped, numLoci, numInd, &haps, &maps, &freqs, a.tped_missing, a.phased);
             if (a.cache != "none") {
                 writeGenotypeCache(a.cache, haps, maps, freqs);
                 std::cerr << "Wrote genotype cache " << a.cache << "\n";
@@ -165,13 +169,12 @@ int main(int argc, char **argv)
         std::vector<int> devices = a.devices;
         if (devices.empty())
             for (int d = 0; d < a.gpus; d++) devices.push_back(d);
-        if (a.weighted && a.phased) { std::cerr << "ERROR: --phased needs haplotype phase, which this engine does not hold\n"; return 1; }
 
         std::vector<int> sizes = a.winsize_multi.empty() ? std::vector<int>{a.winsize} : a.winsize_multi;
         LodEngine engine(haps, freqs, maps, gls, &centro, USE_GL, devices); // one upload, many window sizes
         const std::vector<int> ldsub = a.weighted ? drawLdSubsample(numInd, a.ld_subsample, a.ld_seed) : std::vector<int>();
         for (int W : sizes) {
-            if (a.weighted) engine.ldWeights(W, ldsub, false);   // garlic-main.cpp:346-357: LD weights per window size
+            if (a.weighted) engine.ldWeights(W, ldsub, false, a.phased);   // garlic-main.cpp:346-357: LD weights per window size
             const std::string feed_path = a.out + "." + std::to_string(W) + "SNPs.lod.f64";
             if (!a.raw_lod) {   // only the KDE feed is wanted: thin on the device, no full-score download
                 DoubleData *feed = engine.lodFeed(W, a.error, a.max_gap, a.kde_thinning ? W : 1, a.weighted, a.M, a.mu);

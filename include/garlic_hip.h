@@ -106,32 +106,42 @@ int garlic_panel_set_genotypes(garlic_panel *panel, const int16_t *geno, int64_t
 int garlic_panel_set_gl(garlic_panel *panel, const double *gl, int64_t ld, int64_t locus_begin,
                         int64_t locus_count, int32_t where);
 
+/* HapData::firstCopy (src/garlic-data.h:36; filled by readTPED under --phased,
+ * src/garlic-data.cpp:106,129: "the first allele of the pair is the counted allele"), one byte per
+ * genotype, non-zero = true; same addressing as genotypes.  Only the phased LD weights read it. */
+int garlic_panel_set_phase(garlic_panel *panel, const uint8_t *first_copy, int64_t ld,
+                           int64_t locus_begin, int64_t locus_count, int32_t where);
+
 /* LDData::LD (src/garlic-data.h:105) for winsize: ld[l * winsize + k], l global locus. */
 int garlic_panel_set_ld(garlic_panel *panel, int32_t winsize, const double *ld, int32_t where);
 
-/* calcLDData / calcHR2LD (src/garlic-data.cpp:330-527, hr2 :558-583), the unphased LD weights of
- * wLOD, computed on the device from the panel's genotypes:
- *     LD[s][k] = sum_{i = s .. s+winsize-1, in order} (i == s+k ? 1 : hr2(i, s+k))   for s <= nloci_c - winsize
- * homFreq (:656-676) is taken over every individual of the panel, the pair counts of hr2 over the
- * individuals sub_idx[0 .. n_sub) (n_sub = 0: all).  The reference draws that subsample with a
- * time-seeded RNG (:346-364, --ld-subsample); here the caller supplies it.  The result is installed
- * as the panel's LD weights for winsize (as garlic_panel_set_ld would) and, if ld_out is not NULL,
- * also written there (nloci * winsize doubles, ld[l * winsize + k]).  --phased (calcR2LD) needs
- * haplotype phase, which this panel does not hold. */
-int garlic_panel_compute_ld(garlic_panel *panel, int32_t winsize, const int32_t *sub_idx, int32_t n_sub,
-                            double *ld_out, int32_t where);
+/* calcLDData (src/garlic-data.cpp:330-375): the LD weights of wLOD, computed on the device from the
+ * panel's genotypes,
+ *     LD[s][k] = sum_{i = s .. s+winsize-1, in order} (i == s+k ? 1 : c(i, s+k))   for s <= nloci_c - winsize
+ * with  phased == 0:  c = hr2 (calcHR2LD :377-527, hr2 :558-583), from homFreq (:656-676) taken over
+ *                     every individual of the panel;
+ *       phased != 0:  c = r2  (calcR2LD :426-535, r2 :585-617; --phased), from the allele
+ *                     frequencies of garlic_panel_set_freq and the phase of garlic_panel_set_phase.
+ * The pair counts run over the individuals sub_idx[0 .. n_sub) (n_sub = 0: all).  The reference
+ * draws that subsample with a time-seeded RNG (:346-364, --ld-subsample); here the caller supplies
+ * it.  The result is installed as the panel's LD weights for winsize (as garlic_panel_set_ld would)
+ * and, if ld_out is not NULL, also written there (nloci * winsize doubles, ld[l * winsize + k]). */
+int garlic_panel_compute_ld(garlic_panel *panel, int32_t winsize, int32_t phased, const int32_t *sub_idx,
+                            int32_t n_sub, double *ld_out, int32_t where);
 
 /* The same in two steps for panels whose individuals are sharded over GPUs: everything that
  * depends on genotypes is an integer count, exact and order-free --
  *     locus_counts[l][2]            = {homozygous, non-missing} individuals of this shard
- *     pair_counts[l][winsize][2]    = {both non-missing, both non-missing and homozygous} over the
- *                                     shard's part of the subsample, for SNP pairs (l, l+d), d >= 1
+ *     pair_counts[l][winsize][2]    = over the shard's part of the subsample, for SNP pairs (l, l+d), d >= 1:
+ *                                     {both non-missing, both non-missing and homozygous}   (hr2), or
+ *                                     {2 * both non-missing, x11 of r2 :592-606}            (phased)
  * -- so the caller sums the count arrays of all shards element-wise (one all-reduce) and every
  * shard finishes with the summed counts; the floating-point part then runs in the reference's
- * operation order and is identical on every GPU.  sub_idx is shard-local. */
-int garlic_ld_counts(garlic_panel *panel, int32_t winsize, const int32_t *sub_idx, int32_t n_sub,
-                     int32_t *locus_counts, int32_t *pair_counts, int32_t where);
-int garlic_ld_finish(garlic_panel *panel, int32_t winsize, const int32_t *locus_counts,
+ * operation order and is identical on every GPU.  sub_idx is shard-local.  (Phased: the allele
+ * frequencies are the caller's, over all individuals, as for the LOD scores.) */
+int garlic_ld_counts(garlic_panel *panel, int32_t winsize, int32_t phased, const int32_t *sub_idx,
+                     int32_t n_sub, int32_t *locus_counts, int32_t *pair_counts, int32_t where);
+int garlic_ld_finish(garlic_panel *panel, int32_t winsize, int32_t phased, const int32_t *locus_counts,
                      const int32_t *pair_counts, double *ld_out, int32_t where);
 
 /* Output addressing for this panel: pitch_align = 1 gives the reference's dense rows

@@ -285,6 +285,50 @@ void oracle_hr2_ld(int nloci, int nind, const int16_t *g, const double *hom_freq
     }
 }
 
+/* garlic-data.cpp:585-617 (--phased): r2 from the count of chromosomes carrying the counted allele
+ * at both SNPs; a double heterozygote counts once if its first copies agree. */
+static double r2_pair(int nind, const int16_t *g, const uint8_t *fc, const double *freq, int i, int j,
+                      const int32_t *idx, int n_idx)
+{
+    double pi = freq[i], pj = freq[j];
+    if (!(pi > 0 && pi < 1 && pj > 0 && pj < 1)) return 0;
+    double x11 = 0, total = 0;
+    for (int k = 0; k < n_idx; k++) {
+        int ind = idx[k];
+        int a = g[(size_t)i * nind + ind], b = g[(size_t)j * nind + ind];
+        if (a != -9 && b != -9) {
+            total += 2;
+            if (a == 2 && b == 2) x11 += 2;
+            else if (a == 1 && b == 2) x11++;
+            else if (a == 2 && b == 1) x11++;
+            else if (a == 1 && b == 1 && fc[(size_t)j * nind + ind] == fc[(size_t)i * nind + ind]) x11++;
+        }
+    }
+    x11 /= total;
+    double D = x11 - pi * pj;
+    double v = D * D / (pi * (1 - pi) * pj * (1 - pj));
+    return (v > 1) ? 1 : v;
+}
+
+/* garlic-data.cpp:426-535 (calcR2LD / parallelR2 / ldR2): as oracle_hr2_ld with r2 */
+void oracle_r2_ld(int nloci, int nind, const int16_t *g, const uint8_t *first_copy, const double *freq,
+                  int winsize, const int32_t *idx, int n_idx, double *ld)
+{
+    for (size_t k = 0; k < (size_t)nloci * winsize; k++) ld[k] = 0;
+    int stop = nloci - winsize + 1;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int s = 0; s < stop; s++) {
+        for (int site = s; site < s + winsize; site++) {
+            double acc = 0;
+            for (int i = s; i <= s + winsize - 1; i++) {
+                if (i != site) acc += r2_pair(nind, g, first_copy, freq, i, site, idx, n_idx);
+                else acc += 1;
+            }
+            ld[(size_t)s * winsize + (site - s)] = acc;
+        }
+    }
+}
+
 /* garlic-data.cpp:2026-2069 */
 int64_t oracle_flatten(int nloci, int nind, const double *win, int step, double *out)
 {

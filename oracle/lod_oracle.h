@@ -69,6 +69,11 @@ void oracle_geno_freq(int nloci, int nind, const int16_t *genotypes, double *hom
 void oracle_hr2_ld(int nloci, int nind, const int16_t *genotypes, const double *hom_freq,
                    int winsize, const int32_t *ind_index, int n_index, double *ld);
 
+/* garlic-data.cpp:426-535, 585-617 (calcR2LD / r2, --phased); first_copy = HapData::firstCopy,
+ * uint8 [nloci][nind]; freq = FreqData::freq. */
+void oracle_r2_ld(int nloci, int nind, const int16_t *genotypes, const uint8_t *first_copy,
+                  const double *freq, int winsize, const int32_t *ind_index, int n_index, double *ld);
+
 /* garlic-data.cpp:2026-2069, one chromosome; returns number of values written. */
 int64_t oracle_flatten(int nloci, int nind, const double *win, int step, double *out);
 void oracle_roh_coverage(int nloci, int nind, const double *win, int winsize, double cutoff,

@@ -15,6 +15,7 @@
 //   calcLOD        garlic-roh.cpp:18
 //   calcwLOD       garlic-roh.cpp:144   (+ parallelwLOD :204)
 //   calcHR2LD      garlic-data.cpp:377  (explicit individual index, no RNG)
+//   calcR2LD       garlic-data.cpp:426  (--phased; same)
 //   calculateGenoFreq garlic-data.cpp:656
 //   readTGLSData   garlic-data.cpp:1516 (GQ/GL/PL -> error probability)
 //   convertWinData2DoubleData garlic-data.cpp:2026
@@ -218,6 +219,33 @@ REF_API int ref_calcHR2LD(int nloci, int nind, const short *genotypes, int winsi
             memcpy(ld_out + (size_t)l * winsize, L->LD[l], sizeof(double) * winsize);
         releaseLDData(L);
         releaseGenoFreq(gf);
+        free_hap(hap);
+    } catch (...) { return 1; }
+    return 0;
+}
+
+// calcR2LD (--phased, garlic-data.cpp:426): first_copy = HapData::firstCopy, uint8 [nloci][nind];
+// freq = FreqData::freq.  ld_out: double[nloci][winsize]
+REF_API int ref_calcR2LD(int nloci, int nind, const short *genotypes, const unsigned char *first_copy,
+                         const double *freq, int winsize, int numThreads, const int *ind_index,
+                         int n_index, double *ld_out)
+{
+    StderrSilencer quiet;
+    try {
+        HapData *hap = make_hap(nloci, nind, genotypes);
+        hap->firstCopy = new bool*[nloci];
+        for (int l = 0; l < nloci; l++) {
+            hap->firstCopy[l] = new bool[nind];
+            for (int i = 0; i < nind; i++) hap->firstCopy[l][i] = first_copy[(size_t)l * nind + i] != 0;
+        }
+        FreqData fd; fd.freq = const_cast<double *>(freq); fd.nloci = nloci;
+        LDData *L = calcR2LD(hap, &fd, winsize, numThreads, const_cast<int *>(ind_index), n_index);
+        for (int l = 0; l < nloci; l++)
+            memcpy(ld_out + (size_t)l * winsize, L->LD[l], sizeof(double) * winsize);
+        releaseLDData(L);
+        for (int l = 0; l < nloci; l++) delete [] hap->firstCopy[l];
+        delete [] hap->firstCopy;
+        hap->firstCopy = NULL;
         free_hap(hap);
     } catch (...) { return 1; }
     return 0;

@@ -63,6 +63,8 @@ def oracle():
         lib.oracle_geno_freq.argtypes = [C.c_int, C.c_int, _sp, _dp]
         lib.oracle_hr2_ld.restype = None
         lib.oracle_hr2_ld.argtypes = [C.c_int, C.c_int, _sp, _dp, C.c_int, _ip, C.c_int, _dp]
+        lib.oracle_r2_ld.restype = None
+        lib.oracle_r2_ld.argtypes = [C.c_int, C.c_int, _sp, _bp, _dp, C.c_int, _ip, C.c_int, _dp]
         lib.oracle_flatten.restype = C.c_int64
         lib.oracle_flatten.argtypes = [C.c_int, C.c_int, _dp, C.c_int, _dp]
         lib.oracle_roh_coverage.restype = None
@@ -101,6 +103,8 @@ def ref():
                                      C.c_double, C.c_int, C.c_int, _dp]
         lib.ref_calcHR2LD.restype = C.c_int
         lib.ref_calcHR2LD.argtypes = [C.c_int, C.c_int, _sp, C.c_int, C.c_int, _ip, C.c_int, _dp, _dp]
+        lib.ref_calcR2LD.restype = C.c_int
+        lib.ref_calcR2LD.argtypes = [C.c_int, C.c_int, _sp, _bp, _dp, C.c_int, C.c_int, _ip, C.c_int, _dp]
         lib.ref_readTGLS.restype = C.c_int
         lib.ref_readTGLS.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, _dp]
         lib.ref_flatten.restype = C.c_int
@@ -173,6 +177,21 @@ def oracle_hr2_ld(geno, W, idx=None):
     return ld
 
 
+def oracle_r2_ld(geno, first_copy, freq, W, idx=None):
+    """--phased LD weights (calcR2LD); first_copy uint8 [nloci][nind]"""
+    geno = np.ascontiguousarray(geno, dtype=np.int16)
+    fc = np.ascontiguousarray(first_copy, dtype=np.uint8)
+    freq = np.ascontiguousarray(freq, dtype=np.float64)
+    nloci, nind = geno.shape
+    if idx is None:
+        idx = np.arange(nind, dtype=np.int32)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    ld = np.empty((nloci, W), dtype=np.float64)
+    oracle().oracle_r2_ld(nloci, nind, _p(geno, _sp), _p(fc, _bp), _p(freq, _dp), W, _p(idx, _ip),
+                          idx.shape[0], _p(ld, _dp))
+    return ld
+
+
 def oracle_flatten(win, step):
     win = np.ascontiguousarray(win, dtype=np.float64)
     nind, nloci = win.shape
@@ -225,6 +244,21 @@ def ref_hr2_ld(geno, W, idx=None, threads=1):
                              _p(hom, _dp), _p(ld, _dp))
     assert rc == 0
     return hom, ld
+
+
+def ref_r2_ld(geno, first_copy, freq, W, idx=None, threads=1):
+    geno = np.ascontiguousarray(geno, dtype=np.int16)
+    fc = np.ascontiguousarray(first_copy, dtype=np.uint8)
+    freq = np.ascontiguousarray(freq, dtype=np.float64)
+    nloci, nind = geno.shape
+    if idx is None:
+        idx = np.arange(nind, dtype=np.int32)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    ld = np.empty((nloci, W), dtype=np.float64)
+    rc = ref().ref_calcR2LD(nloci, nind, _p(geno, _sp), _p(fc, _bp), _p(freq, _dp), W, threads,
+                            _p(idx, _ip), idx.shape[0], _p(ld, _dp))
+    assert rc == 0
+    return ld
 
 
 def ref_flatten(win, step):

@@ -51,12 +51,15 @@ def test_freq_and_raw_lod_match_reference_binary(tmp_path):
     assert n_same / n_tok > 0.999, (n_same, n_tok)
 
 
-def test_weighted_raw_lod_matches_reference_binary(tmp_path):
-    """--weighted end to end: genetic-map interpolation, LD weights (all individuals), wLOD -- against
-    the raw windows the reference's prebuilt binary wrote for the same command (6 printed digits)."""
-    out = run_tool(tmp_path, "--winsize", "30", "--raw-lod", "--weighted", "--map", os.path.join(E2E, "tiny.map"))
+@pytest.mark.parametrize("tag,flags", [("refw", []), ("refp", ["--phased"])])
+def test_weighted_raw_lod_matches_reference_binary(tmp_path, tag, flags):
+    """--weighted end to end: genetic-map interpolation, LD weights (all individuals; hr2, or r2 from
+    the TPED's allele order with --phased), wLOD -- against the raw windows the reference's prebuilt
+    binary wrote for the same command (6 printed digits)."""
+    out = run_tool(tmp_path, "--winsize", "30", "--raw-lod", "--weighted", "--map", os.path.join(E2E, "tiny.map"),
+                   *flags)
     n_tok = n_same = 0
-    for ref in sorted(glob.glob(os.path.join(E2E, "refw.POP.*.raw.lod.windows.gz"))):
+    for ref in sorted(glob.glob(os.path.join(E2E, tag + ".POP.*.raw.lod.windows.gz"))):
         mine = out + os.path.basename(ref)[4:]
         a, b = read_rows(ref), read_rows(mine)
         assert len(a) == len(b) == 24
@@ -118,7 +121,8 @@ def test_sharded_run_equals_single_device(tmp_path):
     weighted = ["--weighted", "--map", os.path.join(E2E, "tiny.map"), "--ld-subsample", "11", "--ld-seed", "5"]
     # with --raw-lod the full scores come back; without, only the feed thinned on the devices
     cases = ((["--winsize", "30", "--raw-lod"], []), (["--winsize", "30", "--raw-lod"], weighted),
-             (["--winsize-multi", "20", "45"], []), (["--winsize", "30", "--no-kde-thinning"], weighted))
+             (["--winsize-multi", "20", "45"], []), (["--winsize", "30", "--no-kde-thinning"], weighted),
+             (["--winsize", "30", "--raw-lod", "--phased"], weighted))
     for case, (common, extra) in enumerate(cases):
         outs = []
         for k, devs in enumerate(("0", "0,0", "0,0,0,0,0")):
@@ -146,3 +150,29 @@ def test_genotype_cache_gives_identical_outputs(tmp_path):
     for n in names:
         assert filecmp.cmp(outs[0] + n, outs[1] + n, shallow=False), n
 
+
+
+def test_genotype_cache_keeps_the_phase(tmp_path):
+    """--phased through the sidecar: the firstCopy bits travel with the genotypes; a cache written
+    without them is refused for a --phased run instead of silently giving hr2 weights"""
+    import filecmp
+    weighted = ["--winsize", "30", "--raw-lod", "--weighted", "--phased", "--map", os.path.join(E2E, "tiny.map")]
+    cache = str(tmp_path / "tiny.g2b")
+    outs = []
+    for k in range(2):
+        d = tmp_path / f"p{k}"
+        d.mkdir()
+        outs.append(run_tool(d, *weighted, "--genotype-cache", cache))
+    names = sorted(os.path.basename(p)[len("mine"):] for p in glob.glob(outs[0] + "*"))
+    assert len(names) >= 4
+    for n in names:
+        assert filecmp.cmp(outs[0] + n, outs[1] + n, shallow=False), n
+    plain = str(tmp_path / "plain.g2b")
+    d = tmp_path / "u"
+    d.mkdir()
+    run_tool(d, "--winsize", "30", "--raw-lod", "--genotype-cache", plain)
+    cmd = [TOOL, "--tped", os.path.join(E2E, "tiny.tped.gz"), "--tfam", os.path.join(E2E, "tiny.tfam"),
+           "--centromere", os.path.join(E2E, "tiny.centromeres.txt"), "--error", "0.001", "--out", str(d / "x"),
+           *weighted, "--genotype-cache", plain]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode != 0 and "without phase" in r.stderr

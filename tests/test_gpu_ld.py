@@ -147,3 +147,53 @@ def test_ld_golden_from_the_reference_build(gpu_ctx):
         for W in (10, 30):
             assert same(panel.compute_ld(W), d[f"ld_W{W}"]), W
 
+
+
+def oracle_r2(chroms, phase, W, sub=None):
+    out, l0 = [], 0
+    for g, f, *_ in chroms:
+        out.append(ol.oracle_r2_ld(g, phase[l0:l0 + g.shape[0]], f, W, idx=sub))
+        l0 += g.shape[0]
+    return np.concatenate(out, axis=0)
+
+
+@pytest.mark.parametrize("W", [2, 9, 40])
+@pytest.mark.parametrize("nind", [33, 64, 150])
+def test_phased_ld_matches_oracle(gpu_ctx, W, nind):
+    """--phased: calcR2LD / r2 (garlic-data.cpp:426-535, 585-617) from the firstCopy bits"""
+    rng = np.random.default_rng(5 * W + nind)
+    sizes = [300, 1, max(1, W - 1), W, W + 1, 129]
+    chroms = [list(ol.random_panel(rng, n, nind, max_gap=10 ** 9, gaps=0, miss=0.05)) for n in sizes]
+    chroms[0][1][3] = 0.0                                  # frequency 0 / 1: r2 = 0 whatever the genotypes
+    chroms[0][1][4] = 1.0
+    chroms[0][0][13, :] = -9                               # no pair has both genotypes: 0/0
+    nloci = sum(sizes)
+    phase = rng.integers(0, 2, size=(nloci, nind)).astype(np.uint8)
+    with make_panel(gpu_ctx, chroms, nind) as panel:
+        with pytest.raises(abi.GarlicError):
+            panel.compute_ld(W, phased=True)               # no phase yet
+        panel.set_phase(phase[:100])                       # streamed in two chunks
+        panel.set_phase(phase[100:], locus_begin=100)
+        assert same(panel.compute_ld(W, phased=True), oracle_r2(chroms, phase, W))
+        sub = np.sort(rng.choice(nind, size=max(2, nind // 3), replace=False)).astype(np.int32)
+        assert same(panel.compute_ld(W, sub_idx=sub, phased=True), oracle_r2(chroms, phase, W, sub))
+        assert same(panel.compute_ld(W), oracle_ld(chroms, W))     # the unphased weights are still hr2
+
+
+def test_phased_ld_sharded(gpu_ctx):
+    rng = np.random.default_rng(12)
+    W, nind = 20, 130
+    chroms = [ol.random_panel(rng, n, nind, max_gap=10 ** 9, gaps=0, miss=0.03) for n in (200, 90)]
+    phase = rng.integers(0, 2, size=(290, nind)).astype(np.uint8)
+    want = oracle_r2(chroms, phase, W)
+    parts = []
+    for lo, hi in ((0, 70), (70, nind)):
+        shard = [(g[:, lo:hi].copy(), f, p, cs, ce) for g, f, p, cs, ce in chroms]   # freq: whole panel's
+        panel = make_panel(gpu_ctx, shard, hi - lo)
+        panel.set_phase(phase[:, lo:hi].copy())
+        parts.append(panel)
+    counts = [panel.ld_counts(W, phased=True) for panel in parts]
+    loc, pair = counts[0][0] + counts[1][0], counts[0][1] + counts[1][1]
+    for panel in parts:
+        assert same(panel.ld_finish(W, loc, pair, phased=True), want)
+        panel.close()

@@ -72,3 +72,21 @@ def test_ld_subsample_index():
         nan = np.isnan(ld)
         assert np.array_equal(nan, np.isnan(mine)) and ol.bits_equal(ld[~nan], mine[~nan])
 
+
+
+def test_phased_r2_ld():
+    """--phased LD weights (calcR2LD / r2, garlic-data.cpp:426-535, 585-617): oracle == reference"""
+    rng = np.random.default_rng(31)
+    for _ in range(25):
+        nloci, nind, W = int(rng.integers(5, 200)), int(rng.integers(3, 40)), int(rng.integers(2, 30))
+        geno, freq = ol.random_panel(rng, nloci, nind, miss=float(rng.choice([0.0, 0.05, 0.4])))[:2]
+        freq = freq.copy()
+        freq[rng.random(nloci) < 0.1] = rng.choice([0.0, 1.0])       # monomorphic by frequency: r2 = 0
+        fc = rng.integers(0, 2, size=geno.shape).astype(np.uint8)
+        idx = None
+        if rng.integers(0, 2):
+            idx = np.sort(rng.choice(nind, size=int(rng.integers(1, nind + 1)), replace=False)).astype(np.int32)
+        ld = ol.ref_r2_ld(geno, fc, freq, W, idx=idx, threads=int(rng.integers(1, 4)))
+        mine = ol.oracle_r2_ld(geno, fc, freq, W, idx=idx)
+        nan = np.isnan(ld)
+        assert np.array_equal(nan, np.isnan(mine)) and ol.bits_equal(ld[~nan], mine[~nan])

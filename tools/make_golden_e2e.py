@@ -76,9 +76,17 @@ def main():
     for p in glob.glob(os.path.join(tmp, "refw.*.raw.lod.windows.gz")):
         print(" ", os.path.basename(p), os.path.getsize(p))
         shutil.copy(p, os.path.join(OUT, os.path.basename(p)))
+    # --weighted --phased: r2 from the allele order in the TPED (first allele of each pair)
+    cmdp = cmd[:-1] + [os.path.join(tmp, "refp"), "--weighted", "--phased", "--map", os.path.join(OUT, "tiny.map"),
+                       "--threads", "8"]
+    r = subprocess.run(cmdp, capture_output=True, text=True)
+    print(r.stdout[-400:], r.stderr[-800:])
+    for p in glob.glob(os.path.join(tmp, "refp.*.raw.lod.windows.gz")):
+        print(" ", os.path.basename(p), os.path.getsize(p))
+        shutil.copy(p, os.path.join(OUT, os.path.basename(p)))
     with open(os.path.join(OUT, "COMMAND.txt"), "w") as f:
         f.write("garlic v1.1.6a prebuilt binary:\n")
-        for c in (cmd, cmdw):
+        for c in (cmd, cmdw, cmdp):
             f.write(" ".join(os.path.basename(x) if x.startswith("/") else x for x in c) + "\n")
     shutil.rmtree(tmp)
 
