@@ -748,33 +748,41 @@ void loadGenotypeCache(const std::string &path, int &numLoci, int &numInd, std::
     std::vector<uint8_t> bits(row), pbits(prow);
     static const short DECODE[4] = {0, 1, 2, -9};
     numLoci = 0;
-    for (uint32_t c = 0; c < nchr; c++) {
-        const std::string chr = in.str();
-        const int n = (int)in.val<uint32_t>();
-        MapData *m = initMapData(n);
-        m->chr = chr;
-        in.get(m->physicalPos, sizeof(int) * n);
-        in.get(m->geneticPos, sizeof(double) * n);
-        in.get(m->allele, (size_t)n);
-        FreqData *f = initFreqData(n);
-        in.get(f->freq, sizeof(double) * n);
-        for (int l = 0; l < n; l++) m->locusName[l] = in.str();
-        HapData *h = new HapData{new short *[n], nind, n, nullptr};
-        for (int l = 0; l < n; l++) {
-            in.get(bits.data(), row);
-            short *d = h->data[l] = new short[nind];
-            for (int i = 0; i < nind; i++) d[i] = DECODE[(bits[i >> 2] >> (2 * (i & 3))) & 3];
-        }
-        if (phased) {
-            h->firstCopy = new bool *[n];
+    try {
+        for (uint32_t c = 0; c < nchr; c++) {
+            const std::string chr = in.str();
+            const int n = (int)in.val<uint32_t>();
+            if (n < 1) fail(path + ": corrupt genotype cache (empty chromosome)");
+            // each object joins its container as soon as it exists (rows still NULL), so that a
+            // file that ends early leaves nothing behind
+            MapData *m = initMapData(n);
+            (*maps)->push_back(m);
+            m->chr = chr;
+            in.get(m->physicalPos, sizeof(int) * n);
+            in.get(m->geneticPos, sizeof(double) * n);
+            in.get(m->allele, (size_t)n);
+            FreqData *f = initFreqData(n);
+            (*freqs)->push_back(f);
+            in.get(f->freq, sizeof(double) * n);
+            for (int l = 0; l < n; l++) m->locusName[l] = in.str();
+            HapData *h = new HapData{new short *[n](), nind, n, phased ? new bool *[n]() : nullptr};
+            (*haps)->push_back(h);
             for (int l = 0; l < n; l++) {
+                in.get(bits.data(), row);
+                short *d = h->data[l] = new short[nind];
+                for (int i = 0; i < nind; i++) d[i] = DECODE[(bits[i >> 2] >> (2 * (i & 3))) & 3];
+            }
+            for (int l = 0; phased && l < n; l++) {
                 in.get(pbits.data(), prow);
                 bool *d = h->firstCopy[l] = new bool[nind];
                 for (int i = 0; i < nind; i++) d[i] = (pbits[i >> 3] >> (i & 7)) & 1;
             }
+            numLoci += n;
         }
-        (*maps)->push_back(m); (*haps)->push_back(h); (*freqs)->push_back(f);
-        numLoci += n;
+    } catch (...) {
+        releaseHapData(*haps); releaseMapData(*maps); releaseFreqData(*freqs);
+        *haps = nullptr; *maps = nullptr; *freqs = nullptr;
+        throw;
     }
     numInd = nind;
 }
@@ -801,6 +809,28 @@ LodEngine::LodEngine(std::vector<HapData *> *haps, std::vector<FreqData *> *freq
                      const std::vector<int> &devices)
     : impl(new Impl)
 {
+    try {
+        upload(haps, freqs, maps, gls, centro, USE_GL, devices);
+    } catch (...) {   // a constructor that throws runs no destructor: release what was created
+        release();
+        throw;
+    }
+}
+
+void LodEngine::release()
+{
+    for (auto &s : impl->shards) {
+        if (s.panel) garlic_panel_destroy(s.panel);
+        if (s.ctx) garlic_ctx_destroy(s.ctx);
+    }
+    delete impl;
+    impl = nullptr;
+}
+
+void LodEngine::upload(std::vector<HapData *> *haps, std::vector<FreqData *> *freqs, std::vector<MapData *> *maps,
+                       std::vector<GenoLikeData *> *gls, centromere *centro, bool USE_GL,
+                       const std::vector<int> &devices)
+{
     const int nchr = (int)maps->size();
     impl->maps = maps;
     impl->nind = haps->at(0)->nind;
@@ -824,16 +854,16 @@ LodEngine::LodEngine(std::vector<HapData *> *haps, std::vector<FreqData *> *freq
     const int nd = std::min<int>((int)devs.size(), impl->nind);
     const int per = (impl->nind + nd - 1) / nd; // contiguous blocks in TFAM order
     for (int d = 0; d < nd; d++) {
-        Impl::Shard s;
+        if (std::min(per, impl->nind - d * per) < 1) break;
+        impl->shards.emplace_back();
+        Impl::Shard &s = impl->shards.back();
         s.device = devs[d];
         s.ind_begin = d * per;
         s.nind = std::min(per, impl->nind - s.ind_begin);
-        if (s.nind < 1) break;
         check(garlic_ctx_create(s.device, nullptr, &s.ctx), "garlic_ctx_create");
         check(garlic_panel_create(s.ctx, nchr, impl->chr_nloci.data(), s.nind, &s.panel), "garlic_panel_create");
         check(garlic_panel_set_map(s.panel, pos.data(), gpos.data(), cs.data(), ce.data()), "garlic_panel_set_map");
         check(garlic_panel_set_freq(s.panel, freq.data()), "garlic_panel_set_freq");
-        impl->shards.push_back(s);
     }
     // genotype rows are separate allocations in HapData: stage a slab of SNP rows at a time
     const int64_t slab = std::max<int64_t>(1, ((int64_t)64 << 20) / (2 * (int64_t)impl->nind));
@@ -876,14 +906,7 @@ LodEngine::LodEngine(std::vector<HapData *> *haps, std::vector<FreqData *> *freq
     }
 }
 
-LodEngine::~LodEngine()
-{
-    for (auto &s : impl->shards) {
-        garlic_panel_destroy(s.panel);
-        garlic_ctx_destroy(s.ctx);
-    }
-    delete impl;
-}
+LodEngine::~LodEngine() { release(); }
 
 std::vector<WinData *> *LodEngine::lodWindows(int winsize, double error, int MAX_GAP)
 {

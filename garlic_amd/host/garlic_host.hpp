@@ -216,6 +216,9 @@ public:
 
 private:
     std::vector<WinData *> *run(bool weighted, int winsize, double error, int MAX_GAP, int M, double mu);
+    void upload(std::vector<HapData *> *haps, std::vector<FreqData *> *freqs, std::vector<MapData *> *maps,
+                std::vector<GenoLikeData *> *gls, centromere *centro, bool USE_GL, const std::vector<int> &devices);
+    void release();
     struct Impl;
     Impl *impl;
 };

@@ -121,7 +121,21 @@ int main(int argc, char **argv)
     try {
         centromere centro(a.build, a.centromere, "none");
         int numLoci = 0, numInd = 0;
-        std::vector<HapData *> *haps; std::vector<MapData *> *maps; std::vector<FreqData *> *freqs;
+        std::vector<HapData *> *haps = nullptr; std::vector<MapData *> *maps = nullptr;
+        std::vector<FreqData *> *freqs = nullptr; std::vector<GenoLikeData *> *gls = nullptr;
+        IndData *ind = nullptr;
+        struct Owner {   // the reference-shaped containers are raw pointers: release them on every way out
+            std::vector<HapData *> *&haps; std::vector<MapData *> *&maps; std::vector<FreqData *> *&freqs;
+            std::vector<GenoLikeData *> *&gls; IndData *&ind;
+            ~Owner()
+            {
+                if (ind) releaseIndData(ind);
+                if (haps) releaseHapData(haps);
+                if (maps) releaseMapData(maps);
+                if (freqs) releaseFreqData(freqs);
+                if (gls) releaseGLData(gls);
+            }
+        } owner{haps, maps, freqs, gls, ind};
         FILE *probe = a.cache == "none" ? nullptr : fopen(a.cache.c_str(), "rb");
         if (probe) {   // parsed before: load the 2-bit sidecar instead of the text
             fclose(probe);
@@ -142,19 +156,19 @@ int main(int argc, char **argv)
         int nindFam = 0;
         scanIndData3(a.tfam, nindFam, pop);
         if (nindFam != numInd) { std::cerr << "ERROR: tfam lists " << nindFam << " individuals, tped has " << numInd << "\n"; return 1; }
-        IndData *ind = readIndData3(a.tfam, numInd);
+        ind = readIndData3(a.tfam, numInd);
         std::cerr << "Loaded " << numLoci << " loci x " << numInd << " individuals (" << maps->size() << " chromosomes)\n";
 
         const bool USE_GL = a.tgls != "none";
-        std::vector<GenoLikeData *> *gls = nullptr;
         if (USE_GL) gls = readTGLSData(a.tgls, numLoci, numInd, maps, a.gl_type); // rows in pre-filter TPED order
-        if (a.freq_file != "none") { releaseFreqData(freqs); freqs = readFreqData(a.freq_file, maps); }
+        if (a.freq_file != "none") { releaseFreqData(freqs); freqs = nullptr; freqs = readFreqData(a.freq_file, maps); }
         else writeFreqData(a.out + ".freq", freqs, maps);                        // garlic-main.cpp:245-253
         int kept;
         if (a.weighted) {   // garlic-main.cpp:233-239, 267-276
             std::vector<GenMapScaffold *> *scaffold = loadMapScaffold(a.map, &centro);
             if (scaffold->size() != maps->size()) {
                 std::cerr << "ERROR: Scaffold genetic map does not have the same number of chromosomes as data.\n";
+                releaseGenMapScaffold(scaffold);
                 return 1;
             }
             kept = filterMonomorphicAndOOBSites(&maps, &haps, &freqs, &gls, scaffold, USE_GL);
@@ -192,9 +206,6 @@ int main(int argc, char **argv)
         }
         if (a.auto_winsize)
             std::cerr << "NOTE: --auto-winsize picks among the feeds above in GARLIC's KDE stage (Phase II, not part of this tool)\n";
-        releaseIndData(ind);
-        releaseHapData(haps); releaseMapData(maps); releaseFreqData(freqs);
-        if (gls) releaseGLData(gls);
     } catch (...) {
         return 1;
     }

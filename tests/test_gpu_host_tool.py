@@ -74,6 +74,31 @@ def test_weighted_raw_lod_matches_reference_binary(tmp_path, tag, flags):
     assert n_tok > 100000 and n_same / n_tok > 0.999, (n_same, n_tok)
 
 
+def test_tgls_raw_lod_matches_reference_binary(tmp_path):
+    """--tgls --gl-type GQ end to end (readTGLSData's conversion, the filter keeping GL rows aligned,
+    the TGLS kernels) against the reference binary's raw windows"""
+    out = str(tmp_path / "mine")
+    cmd = [TOOL, "--tped", os.path.join(E2E, "tiny.tped.gz"), "--tfam", os.path.join(E2E, "tiny.tfam"),
+           "--centromere", os.path.join(E2E, "tiny.centromeres.txt"), "--out", out, "--winsize", "30", "--raw-lod",
+           "--tgls", os.path.join(E2E, "tiny.tgls.gz"), "--gl-type", "GQ"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    n_tok = n_same = 0
+    for ref in sorted(glob.glob(os.path.join(E2E, "reft.POP.*.raw.lod.windows.gz"))):
+        mine = out + os.path.basename(ref)[4:]
+        a, b = read_rows(ref), read_rows(mine)
+        assert len(a) == len(b) == 24
+        for ra, rb in zip(a, b):
+            assert len(ra) == len(rb)
+            assert [x == "NA" for x in ra] == [x == "NA" for x in rb]
+            va = np.array([float(x) for x in ra if x != "NA"])
+            vb = np.array([float(x) for x in rb if x != "NA"])
+            assert np.allclose(va, vb, rtol=2e-5, atol=2e-6)
+            n_tok += len(ra)
+            n_same += sum(x == y for x, y in zip(ra, rb))
+    assert n_tok > 100000 and n_same / n_tok > 0.999, (n_same, n_tok)
+
+
 def test_kde_feed_matches_oracle(tmp_path):
     """<out>.<W>SNPs.lod.f64 = convertWinData2DoubleData of the scores (garlic-data.cpp:2026), bit exact."""
     out = run_tool(tmp_path, "--winsize-multi", "20", "45")

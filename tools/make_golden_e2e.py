@@ -43,8 +43,9 @@ def main():
                 else:
                     g += [A if rng.random() < freq[l] else B, A if rng.random() < freq[l] else B]
             lines.append(f"{c} rs{c}_{l} 0 {int(pos[l])} " + " ".join(g))
-    with gzip.open(os.path.join(OUT, "tiny.tped.gz"), "wt") as f:
-        f.write("\n".join(lines) + "\n")
+    with open(os.path.join(OUT, "tiny.tped.gz"), "wb") as raw, \
+            gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0) as f:   # mtime 0: same bytes every run
+        f.write(("\n".join(lines) + "\n").encode())
     with open(os.path.join(OUT, "tiny.tfam"), "w") as f:
         for i in range(nind):
             f.write(f"POP ind{i} 0 0 0 -9\n")
@@ -84,9 +85,23 @@ def main():
     for p in glob.glob(os.path.join(tmp, "refp.*.raw.lod.windows.gz")):
         print(" ", os.path.basename(p), os.path.getsize(p))
         shutil.copy(p, os.path.join(OUT, os.path.basename(p)))
+    # --tgls: per-genotype GQ (chr snpid gpos ppos, then one integer per individual), no --error
+    rng3 = np.random.default_rng(20260107)
+    with open(os.path.join(OUT, "tiny.tgls.gz"), "wb") as raw, \
+            gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0) as f:
+        for line in lines:
+            t = line.split()[:4]
+            f.write((" ".join(t) + " " + " ".join(str(int(q)) for q in rng3.integers(3, 61, size=nind)) + "\n").encode())
+    cmdt = [x for x in cmd[:-1] if x not in ("--error", "0.001")] + \
+           [os.path.join(tmp, "reft"), "--tgls", os.path.join(OUT, "tiny.tgls.gz"), "--gl-type", "GQ"]
+    r = subprocess.run(cmdt, capture_output=True, text=True)
+    print(r.stdout[-400:], r.stderr[-800:])
+    for p in glob.glob(os.path.join(tmp, "reft.*.raw.lod.windows.gz")):
+        print(" ", os.path.basename(p), os.path.getsize(p))
+        shutil.copy(p, os.path.join(OUT, os.path.basename(p)))
     with open(os.path.join(OUT, "COMMAND.txt"), "w") as f:
         f.write("garlic v1.1.6a prebuilt binary:\n")
-        for c in (cmd, cmdw, cmdp):
+        for c in (cmd, cmdw, cmdp, cmdt):
             f.write(" ".join(os.path.basename(x) if x.startswith("/") else x for x in c) + "\n")
     shutil.rmtree(tmp)
 
