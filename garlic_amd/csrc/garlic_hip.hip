@@ -174,7 +174,7 @@ struct garlic_panel {
     bool decay_valid = false;
     int32_t decay_M = 0;
     double decay_mu = 0;
-    DevBuf<double> d_out;
+    DevBuf<double> d_out, d_feed;
     garlic_call_stats stats{};
     bool stats_pending = false;                    // event times of the last call not read yet
     // work list of the last call, still on the device: repeated calls with the same arguments
@@ -185,6 +185,7 @@ struct garlic_panel {
         int32_t W = 0, max_gap = 0, ind_begin = 0, ind_count = 0, pitch_align = 0;
         size_t n_items = 0, n_fill = 0;
         bool wlod_fast = false;
+        int32_t thin_step = 0;
         int32_t n_tiles = 0;
         int64_t n_runs = 0, n_valid = 0;
     } plan;
@@ -265,7 +266,9 @@ struct Layout {
     int64_t total = 0;
 };
 
-Layout make_layout(const garlic_panel *p, int32_t pitch_align, int32_t nind_out)
+// thin_step > 0: the layout of the thinned score matrix (KDE feed) -- per chromosome
+// ceil(nloci / thin_step) columns instead of nloci
+Layout make_layout(const garlic_panel *p, int32_t pitch_align, int32_t nind_out, int32_t thin_step = 0)
 {
     Layout L;
     L.base.resize(p->nchr);
@@ -276,7 +279,8 @@ Layout make_layout(const garlic_panel *p, int32_t pitch_align, int32_t nind_out)
     // stores 64 full rows (the pad rows belong to the caller's buffer and are never read back)
     const int64_t rows = (pitch_align >= 2) ? ((int64_t)nind_out + 63) / 64 * 64 : nind_out;
     for (int c = 0; c < p->nchr; c++) {
-        int64_t pitch = ((int64_t)p->chr_nloci[c] + al - 1) / al * al;
+        const int64_t cols = thin_step > 0 ? ((int64_t)p->chr_nloci[c] + thin_step - 1) / thin_step : p->chr_nloci[c];
+        int64_t pitch = (cols + al - 1) / al * al;
         off = (off + al - 1) / al * al;
         L.base[c] = off;
         L.pitch[c] = pitch;
@@ -434,8 +438,12 @@ int ensure_score_rows(garlic_panel *p, double error, int32_t M, double mu, int32
     return GARLIC_OK;
 }
 
+// thin_step > 0 (unweighted scores, device output, pitch_align 32 only): `out` is the thinned matrix
+// of make_layout(p, 32, ind_count, thin_step) -- the chain kernel stores only the windows at loci
+// 0, thin_step, 2 * thin_step, .. of each chromosome, everything else of that matrix is MISSING.
 int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_gap, int32_t M, double mu,
-               int32_t ind_begin, int32_t ind_count, int32_t pitch_align, double *out, int32_t where)
+               int32_t ind_begin, int32_t ind_count, int32_t pitch_align, double *out, int32_t where,
+               int32_t thin_step = 0)
 {
     garlic_ctx *ctx = p->ctx;
     int rc;
@@ -449,6 +457,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     if (!out) return fail(GARLIC_ERR_INVALID, "out is NULL");
     if (pitch_align < 1) return fail(GARLIC_ERR_INVALID, "pitch_align must be >= 1");
     const bool use_gl = (mode == MODE_LOD_GL) || (mode == MODE_WLOD && p->wlod_use_gl);
+    if (thin_step > 0 && (mode != MODE_LOD || where != GARLIC_DEVICE || pitch_align != 32))
+        return fail(GARLIC_ERR_INVALID, "internal: thinned output is for unweighted device scores");
 
     if ((rc = ensure_segments(p, max_gap))) return rc;
     if (use_gl) {
@@ -481,7 +491,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // rows are copied out into the caller's (possibly dense) layout by strided D2H copies.
     const Layout Lhost = make_layout(p, pitch_align, ind_count);
     if (where == GARLIC_HOST) pitch_align = std::max(pitch_align, 32);
-    Layout L = make_layout(p, pitch_align, ind_count);
+    Layout L = make_layout(p, pitch_align, ind_count, thin_step);
     for (int c = 0; c < p->nchr; c++)
         if (3 * L.pitch[c] * 8 + 512 >= (int64_t)1 << 32)
             return fail(GARLIC_ERR_INVALID, "chromosome %d too long for 32-bit row offsets", c);
@@ -489,7 +499,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     const bool reuse = p->plan.valid && p->plan.mode == (int)mode && p->plan.W == W &&
                        p->plan.max_gap == max_gap && p->plan.ind_begin == ind_begin &&
                        p->plan.ind_count == ind_count && p->plan.pitch_align == pitch_align &&
-                       p->plan.wlod_fast == wlod_fast;
+                       p->plan.wlod_fast == wlod_fast && p->plan.thin_step == thin_step;
     const int nblk = (ind_count + WAVE - 1) / WAVE;
     std::vector<Run> runs;
     std::vector<FillItem> fill;
@@ -572,7 +582,9 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                                    hipMemcpyHostToDevice, ctx->stream));
         }
     }
-    if (n_fill && !wlod_fast) {   // the tuned wLOD kernel writes MISSING itself
+    if (thin_step > 0) {          // small matrix: MISSING everywhere, the chain kernel overwrites the scored samples
+        hipLaunchKernelGGL(fill_value_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_out, L.total, MISSING_D);
+    } else if (n_fill && !wlod_fast) {   // the tuned wLOD kernel writes MISSING itself
         dim3 grid((unsigned)n_fill, (unsigned)((ind_count + FILL_ROWS - 1) / FILL_ROWS));
         hipLaunchKernelGGL(fill_missing_kernel, grid, dim3(256), 0, ctx->stream, p->d_fill.p,
                            p->d_chrs.p, ind_count, d_out);
@@ -610,18 +622,21 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                                a_packed, a_wtab, a_skew, d_out, a);
     } else if (n_items && mode == MODE_LOD) {
         ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p,     p->d_chrs.p,     d_out, p->nind_pad, p->nwordrows,
-                    ind_begin,     ind_count,  W,               (int32_t)n_items, p->d_counter.p, nullptr};
+                    ind_begin,     ind_count,  W,               (int32_t)n_items, thin_step, p->d_counter.p, nullptr};
         DevBuf<int64_t> d_trace;   // debugging aid: GARLIC_TRACE=<file> dumps per-item timestamps
         const char *trace_path = getenv("GARLIC_TRACE");
         if (trace_path && d_trace.reserve(4 * n_items) == GARLIC_OK) {
             (void)hipMemsetAsync(d_trace.p, 0, sizeof(int64_t) * 4 * n_items, ctx->stream);
             a.trace = d_trace.p;
         }
-        if (aligned16)
-            hipLaunchKernelGGL(lod_chain_kernel<true>, dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
+        if (thin_step > 0)
+            hipLaunchKernelGGL((lod_chain_kernel<true, true>), dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
+                               ctx->stream, a);
+        else if (aligned16)
+            hipLaunchKernelGGL((lod_chain_kernel<true, false>), dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
                                ctx->stream, a);
         else
-            hipLaunchKernelGGL(lod_chain_kernel<false>, dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
+            hipLaunchKernelGGL((lod_chain_kernel<false, false>), dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
                                ctx->stream, a);
         if (a.trace) {
             std::vector<int64_t> tr(4 * n_items);
@@ -683,7 +698,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     p->plan.valid = true;
     p->plan.mode = (int)mode; p->plan.W = W; p->plan.max_gap = max_gap; p->plan.ind_begin = ind_begin;
     p->plan.ind_count = ind_count; p->plan.pitch_align = pitch_align;
-    p->plan.wlod_fast = wlod_fast;
+    p->plan.wlod_fast = wlod_fast; p->plan.thin_step = thin_step;
     p->plan.n_items = n_items; p->plan.n_fill = n_fill; p->plan.n_runs = n_runs; p->plan.n_valid = n_valid;
     st.n_valid_windows = n_valid;
     st.n_missing = p->nloci - n_valid;
@@ -837,7 +852,7 @@ int garlic_panel_destroy(garlic_panel *p)
     p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release(); p->d_row_counts.release(); p->d_codes.release(); p->d_tabgl.release();
     p->d_rld.release(); p->d_decay.release(); p->d_stage64.release(); p->d_phase.release();
     p->d_glterms.release(); p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release();
-    p->d_out.release();
+    p->d_out.release(); p->d_feed.release();
     delete p;
     return GARLIC_OK;
 }
@@ -1252,8 +1267,11 @@ int garlic_wlod_windows(garlic_panel *p, int32_t winsize, double error, int32_t 
                       out, where);
 }
 
+// thinned > 0: `scores` is already the thinned matrix of make_layout(.., thinned) (every column is a
+// sample); else the full score matrix, sampled every `step` loci
 static int flatten_impl(garlic_panel *p, const double *scores, int32_t pitch_align, int32_t nind_out,
-                        int32_t step, double *feed, int64_t feed_capacity, int64_t *count, int64_t *chr_counts)
+                        int32_t step, double *feed, int64_t feed_capacity, int64_t *count, int64_t *chr_counts,
+                        int32_t thinned = 0)
 {
     if (!p || !scores || !count) return fail(GARLIC_ERR_INVALID, "panel, scores and count are required");
     if (step < 1 || pitch_align < 1 || nind_out < 1)
@@ -1261,9 +1279,13 @@ static int flatten_impl(garlic_panel *p, const double *scores, int32_t pitch_ali
     int rc;
     if ((rc = set_device(p->ctx))) return rc;
     hipStream_t s = p->ctx->stream;
-    Layout L = make_layout(p, pitch_align, nind_out);
+    Layout L = make_layout(p, pitch_align, nind_out, thinned);
     std::vector<ChrDev> chrs(p->nchr);
-    for (int c = 0; c < p->nchr; c++) chrs[c] = ChrDev{p->chr_off[c], L.base[c], L.pitch[c], p->chr_nloci[c], 0};
+    for (int c = 0; c < p->nchr; c++) {
+        const int32_t cols = thinned > 0 ? (p->chr_nloci[c] + thinned - 1) / thinned : p->chr_nloci[c];
+        chrs[c] = ChrDev{p->chr_off[c], L.base[c], L.pitch[c], cols, 0};
+    }
+    if (thinned > 0) step = 1;
     const int nrows = p->nchr * nind_out;
     if ((rc = p->d_chrs.reserve(chrs.size()))) return rc;
     if ((rc = p->d_row_counts.reserve((size_t)nrows))) return rc;
@@ -1307,22 +1329,25 @@ int garlic_lod_feed(garlic_panel *p, int32_t winsize, double error, int32_t max_
     if (step < 1) return fail(GARLIC_ERR_INVALID, "step must be >= 1");
     int rc;
     if ((rc = set_device(p->ctx))) return rc;
-    const Layout L = make_layout(p, 32, p->nind);
-    // scores go to the panel's device scratch (the one host-output calls use; it stays allocated,
-    // hipMalloc of 8 GB per call would cost more than the kernels)
+    // Unweighted --error scores with a real thinning step: the chain kernel stores only the sampled
+    // windows (8/step B per window instead of 8 B, no full-size scratch).  Otherwise the full scores
+    // go to the panel's device scratch (the one host-output calls use; it stays allocated, hipMalloc
+    // of 8 GB per call would cost more than the kernels) and are sampled from there.
+    const int32_t thinned = (!weighted && !use_gl && step >= 4 && !getenv("GARLIC_FEED_FULL")) ? step : 0;
+    const Layout L = make_layout(p, 32, p->nind, thinned);
     DevBuf<double> &scores = p->d_out;
-    DevBuf<double> d_feed;
-    auto done = [&](int code) { d_feed.release(); return code; };
+    DevBuf<double> &d_feed = p->d_feed;            // kept with the panel: window-size sweeps call this repeatedly
+    auto done = [&](int code) { return code; };
     if ((rc = scores.reserve((size_t)L.total))) return done(rc);
     if (weighted) p->wlod_use_gl = use_gl != 0;
     rc = launch_lod(p, weighted ? MODE_WLOD : (use_gl ? MODE_LOD_GL : MODE_LOD), winsize, error, max_gap, M, mu, 0,
-                    p->nind, 32, scores.p, GARLIC_DEVICE);
+                    p->nind, 32, scores.p, GARLIC_DEVICE, thinned);
     if (rc) return done(rc);
     // at most ceil(nloci_c / step) values per (chromosome, individual)
     int64_t cap = 0;
     for (int c = 0; c < p->nchr; c++) cap += ((int64_t)p->chr_nloci[c] + step - 1) / step * p->nind;
     if ((rc = d_feed.reserve((size_t)std::max<int64_t>(cap, 1)))) return done(rc);
-    if ((rc = flatten_impl(p, scores.p, 32, p->nind, step, d_feed.p, cap, count, chr_counts))) return done(rc);
+    if ((rc = flatten_impl(p, scores.p, 32, p->nind, step, d_feed.p, cap, count, chr_counts, thinned))) return done(rc);
     if (*count > feed_capacity || *count == 0) return done(GARLIC_OK);
     if (!feed) return done(fail(GARLIC_ERR_INVALID, "feed is NULL"));
     hipError_t e = hipMemcpy(feed, d_feed.p, sizeof(double) * (size_t)*count, hipMemcpyDeviceToHost);

@@ -187,7 +187,10 @@ int garlic_lod_flatten(garlic_panel *panel, const double *scores, int32_t pitch_
  * doubles; *count = values produced (nothing is copied if it exceeds the capacity: an upper bound is
  * sum_c ceil(nloci_c / step) * nind); chr_counts (may be NULL): values per chromosome, so that
  * feeds of individual shards can be merged in the reference's chromosome -> individual order.
- * 8 / step bytes per window cross PCIe instead of 8. */
+ * 8 / step bytes per window cross PCIe instead of 8.  Unweighted --error scores with step >= 4 are
+ * thinned by the LOD kernel itself (only the sampled windows are ever stored: 8 / step bytes per
+ * window of HBM writes, no full-size scratch); the other variants compute the full scores into
+ * device scratch and sample them there.  Same values either way. */
 int garlic_lod_feed(garlic_panel *panel, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
                     int32_t weighted, int32_t M, double mu, int32_t step, double *feed,
                     int64_t feed_capacity, int64_t *count, int64_t *chr_counts);

@@ -253,3 +253,28 @@ def test_lod_feed_one_call(gpu_ctx):
                 assert [len(w) for w in want] == list(per_chr), (mode, step)
                 assert ol.bits_equal(feed, np.concatenate(want)), (mode, step)
 
+
+
+@pytest.mark.parametrize("W,step", [(30, 30), (100, 100), (100, 7), (50, 33), (64, 64), (20, 4), (100, 1000)])
+def test_lod_feed_thinned_write_out(gpu_ctx, W, step):
+    """unweighted feed with step >= 4: the chain kernel itself stores only the sampled windows (POST's
+    thinned role in the hand-scheduled loop, the masked head/tail tiles elsewhere).  Runs long enough
+    for the loop, several chromosomes, gaps, a ragged last block -- equal to flatten(oracle scores)."""
+    rng = np.random.default_rng(1000 * W + step)
+    mg, nind = 200000, 150
+    sizes = [5000, 37, 2111, W, W + 1]
+    chroms = [ol.random_panel(rng, n, nind, max_gap=mg, gaps=3 if n > 1000 else 0) for n in sizes]
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms])
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        for _ in range(2):                                   # second call: resident plan
+            feed, per_chr = panel.lod_feed(W, 0.001, mg, step)
+            want = [ol.oracle_flatten(ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg), step)
+                    for g, f, p, cs, ce in chroms]
+            assert [len(w) for w in want] == list(per_chr)
+            assert ol.bits_equal(feed, np.concatenate(want))
+        # the full scores afterwards are not disturbed by the thinned plan
+        got = panel.lod_windows(W, 0.001, mg)
+        for c, (g, f, p, cs, ce) in enumerate(chroms):
+            assert ol.bits_equal(got[c], ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg)), c

@@ -78,7 +78,25 @@ def main():
         print(json.dumps({"mode": "ld", "snps": nloci, "inds": nind, "winsize": W, "call_ms": dt * 1e3,
                           "loci_per_s": nloci / dt, "pair_counts_per_s": nloci * (W - 1) / dt,
                           "ld_sums_terms_per_s": nloci * W * W / dt}))
-    for mode in [m for m in args.modes.split(",") if m != "ld"]:
+    if "feed" in args.modes.split(","):
+        # KDE feed (garlic_lod_feed, unweighted, step = W): chain kernel with the thinned write-out, then
+        # the compaction.  chain_kernel_ms = the chain kernel alone; call_ms = wall clock incl. the D2H
+        # of the feed.  GARLIC_FEED_FULL=1 in the environment gives the full-scores-then-sample path.
+        import time
+        panel.lod_feed(W, error, max_gap, W)
+        ms, wall = [], []
+        for _ in range(args.steps):
+            t0 = time.perf_counter()
+            feed, _ = panel.lod_feed(W, error, max_gap, W)
+            wall.append(time.perf_counter() - t0)
+            ms.append(panel.stats()["chain_kernel_ms"])
+        k = float(np.mean(ms))
+        print(json.dumps({"mode": "feed", "snps": nloci, "inds": nind, "winsize": W, "step": W,
+                          "feed_values": int(feed.shape[0]), "chain_kernel_ms": k,
+                          "call_ms": float(np.mean(wall)) * 1e3,
+                          "sliding_windows_per_s": nloci * nind / (k * 1e-3),
+                          "full_path": bool(os.environ.get("GARLIC_FEED_FULL"))}))
+    for mode in [m for m in args.modes.split(",") if m not in ("ld", "feed")]:
         run(mode)
         ms = []
         for _ in range(args.steps):
