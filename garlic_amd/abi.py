@@ -49,6 +49,9 @@ _i64p = C.POINTER(C.c_int64)
 _f64p = C.POINTER(C.c_double)
 
 
+ABI_VERSION = 2   # GARLIC_HIP_ABI_VERSION of include/garlic_hip.h these bindings were written against
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -58,6 +61,9 @@ def lib():
                           "or `make -C garlic_amd/csrc` (there is no CPU fallback)")
     L = C.CDLL(LIB_PATH)
     L.garlic_hip_abi_version.restype = C.c_int
+    if L.garlic_hip_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {L.garlic_hip_abi_version()}, these bindings need "
+                          f"{ABI_VERSION}: rebuild it (make -C garlic_amd/csrc)")
     L.garlic_hip_last_error.restype = C.c_char_p
     L.garlic_hip_device_count.argtypes = [_i32p]
     L.garlic_ctx_create.argtypes = [C.c_int32, _vp, C.POINTER(_vp)]

@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define GARLIC_HIP_ABI_VERSION 1
+/* 2: the LD functions take `phased`; garlic_panel_set_phase */
+#define GARLIC_HIP_ABI_VERSION 2
 
 #define GARLIC_OK 0
 #define GARLIC_ERR_INVALID 1  /* bad argument (e.g. winsize <= 1: src/garlic-cli.cpp:433-442) */
