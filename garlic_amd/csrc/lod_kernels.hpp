@@ -422,10 +422,10 @@ lod_chain_kernel(ChainArgs p)
     // full tiles go through the 4-role hand-scheduled loop.
     for (;;) {
     if (threadIdx.x == 0)
-        *reinterpret_cast<volatile int *>(smem + LDS_ITEM) = atomicAdd(p.next_item, 1);
+        *reinterpret_cast<int *>(smem + LDS_ITEM) = atomicAdd(p.next_item, 1);
     __syncthreads();
     const int item_idx =
-        __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int *>(smem + LDS_ITEM));
+        __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(smem + LDS_ITEM));   // (barriers on both sides)
     __syncthreads();
     if (item_idx >= p.n_items) return;
     if (p.trace && threadIdx.x == 0) {

@@ -135,6 +135,20 @@ lod_chain_gl_kernel(VariantArgs p, int n_items)
     }
 }
 
+// Hand-off of LDS data between the waves of one workgroup through a counter in LDS.  A CU executes
+// one wave's LDS instructions in issue order, so a counter written after the data is seen after the
+// data and only the COMPILER must be kept from reordering: wavefront-scope fences.  (A
+// workgroup-scope release also waits for the wave's global memory operations -- s_waitcnt vmcnt(0):
+// the chain wave would wait for its prefetched next tile, the store wave for HBM to take the tile
+// it has just issued, once per tile.)
+// The counters themselves: relaxed workgroup-scope atomics on the __shared__ array itself, so that
+// they stay ds_read / ds_write (through a `volatile int *` the compiler loses the address space and
+// emits flat loads, which count as vector-memory operations too: every poll then waits vmcnt(0)).
+#define LDS_FLAG_GET(x) __hip_atomic_load(&(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define LDS_FLAG_SET(x, v) __hip_atomic_store(&(x), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+__device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
+__device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+
 // ---- TGLS in two passes.  The term of (SNP, individual) does not depend on the window size, and
 // looking it up costs two dependent loads plus a gather that drags in 15 cache lines of the
 // ncodes x 32 B term row for 64 values.  Inside the sequential chain that latency is exposed three
@@ -162,12 +176,17 @@ gl_terms_kernel(VariantArgs p, int64_t nloci, int64_t rows, double *__restrict__
 // split over two waves: wave 0 loads (one tile ahead) and runs the chain into one of two LDS
 // tiles, wave 1 writes finished tiles out (transposed, 16-B non-temporal stores).  Two counters in
 // LDS (tiles written / tiles stored) instead of barriers, as in the unweighted kernel.
+// Every term is read twice (entering the window and, W-1 SNPs later, leaving it); at scale the
+// second read misses L2 (FETCH_SIZE x 2 = 40 GB for 20 GB of terms at 2M x 1280) but not the
+// memory-side cache: a variant that staged the rows through a 124-KB LDS ring (LDS-DMA, one fetch
+// per term, one workgroup per CU) ran no faster (9.4 vs 8.8 ms) -- terms once + scores once at
+// 16 B per window is what the kernel moves through HBM either way, at the rate the unweighted
+// kernel writes at on the same box.
 __global__ void __launch_bounds__(2 * WAVE)
 lod_chain_terms_kernel(VariantArgs p, int n_items, int64_t rows, const double *__restrict__ terms)
 {
     __shared__ double tiles[2][WAVE * TPITCH];
     __shared__ int flags[2];                               // [0] tiles written, [1] tiles stored
-    volatile int *vflags = flags;
     const int item = blockIdx.x;
     if (item >= n_items) return;
     const ChainItem it = p.items[item];
@@ -184,11 +203,11 @@ lod_chain_terms_kernel(VariantArgs p, int n_items, int64_t rows, const double *_
     if (wave == 1) {   // ---- write-out
         int k = 0;
         for (int s0 = first; s0 <= b; s0 += TILE, k++) {
-            while (vflags[0] <= k) __builtin_amdgcn_s_sleep(1);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            while (LDS_FLAG_GET(flags[0]) <= k) __builtin_amdgcn_s_sleep(1);
+            lds_acquire();
             variant_store(tiles[k & 1], s0, a, b, lane, rows_valid, out_row0 + s0, c.out_pitch);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) vflags[1] = k + 1;
+            lds_release();
+            if (lane == 0) LDS_FLAG_SET(flags[1], k + 1);
         }
         return;
     }
@@ -228,8 +247,8 @@ lod_chain_terms_kernel(VariantArgs p, int n_items, int64_t rows, const double *_
             n_in[j] = tcol[(Gin + TILE + j) * WAVE];
             n_out[j] = tcol[(Gout + TILE + j) * WAVE];
         }
-        while (vflags[1] + 2 <= k) __builtin_amdgcn_s_sleep(1);   // tile buffer k & 1 has been written out
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        while (LDS_FLAG_GET(flags[1]) + 2 <= k) __builtin_amdgcn_s_sleep(1);   // tile buffer k & 1 has been written out
+        lds_acquire();
         double *tile = tiles[k & 1];
 #pragma unroll
         for (int j = 0; j < TILE; j++) {
@@ -240,8 +259,8 @@ lod_chain_terms_kernel(VariantArgs p, int n_items, int64_t rows, const double *_
             acc = (acc - to) + ti;
             tile[lane * TPITCH + j] = acc;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) vflags[0] = k + 1;
+        lds_release();
+        if (lane == 0) LDS_FLAG_SET(flags[0], k + 1);
     }
 }
 
