@@ -602,23 +602,23 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         const unsigned wl_grid = (a.n_work + 7u) / 8u * 8u;
         const dim3 wl_block(WLOD_WAVES * WAVE);
         if (wlod_lds > 48 * 1024) {
-            const void *fn = wlod_gl ? (aligned16 ? (const void *)wlod_tile_kernel<WLOD_R, true, true>
-                                                  : (const void *)wlod_tile_kernel<WLOD_R, false, true>)
-                                     : (aligned16 ? (const void *)wlod_tile_kernel<WLOD_R, true, false>
-                                                  : (const void *)wlod_tile_kernel<WLOD_R, false, false>);
+            const void *fn = wlod_gl ? (aligned16 ? (const void *)wlod_tile_gl_kernel<WLOD_R, true>
+                                                  : (const void *)wlod_tile_gl_kernel<WLOD_R, false>)
+                                     : (aligned16 ? (const void *)wlod_tile_kernel<WLOD_R, true>
+                                                  : (const void *)wlod_tile_kernel<WLOD_R, false>);
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlod_lds));
         }
         if (wlod_gl && aligned16)
-            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, true, true>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
+            hipLaunchKernelGGL((wlod_tile_gl_kernel<WLOD_R, true>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
                                a_packed, a_wtab, a_skew, d_out, a);
         else if (wlod_gl)
-            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, false, true>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
+            hipLaunchKernelGGL((wlod_tile_gl_kernel<WLOD_R, false>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
                                a_packed, a_wtab, a_skew, d_out, a);
         else if (aligned16)
-            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, true, false>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
+            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, true>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
                                a_packed, a_wtab, a_skew, d_out, a);
         else
-            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, false, false>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
+            hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, false>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
                                a_packed, a_wtab, a_skew, d_out, a);
     } else if (n_items && mode == MODE_LOD) {
         ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p,     p->d_chrs.p,     d_out, p->nind_pad, p->nwordrows,

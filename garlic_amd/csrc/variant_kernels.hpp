@@ -439,11 +439,11 @@ __device__ __forceinline__ void wlod_group_scores(const double *tcol, const doub
 }
 
 template <int R, bool ALIGNED16, bool FROM_SCORES>
-__global__ void __launch_bounds__(WLOD_WAVES * WAVE) __attribute__((amdgpu_num_vgpr(64)))   // 8 waves per SIMD
-wlod_tile_kernel(const uint32_t *__restrict__ packed,
-                 const double *__restrict__ wtab,   // [GOFF + nloci + pad][4]; FROM_SCORES: term matrix [blk][rows][64]
-                 const double *__restrict__ D,      // [nloci + pad][W], D[l][j] = 1.0 / LD[l - j][j]
-                 double *__restrict__ out, WlodArgs p)
+__device__ __forceinline__ void
+wlod_tile_body(const uint32_t *__restrict__ packed,
+               const double *__restrict__ wtab,   // [GOFF + nloci + pad][4]; FROM_SCORES: term matrix [blk][rows][64]
+               const double *__restrict__ D,      // [nloci + pad][W], D[l][j] = 1.0 / LD[l - j][j]
+               double *__restrict__ out, const WlodArgs &p)
 {   // the read-only tables are separate __restrict__ arguments: only then are the wave-uniform
     // weight loads provably unclobbered by the score stores and issued as scalar loads
     extern __shared__ __attribute__((aligned(16))) double dyn[];
@@ -546,6 +546,25 @@ wlod_tile_kernel(const uint32_t *__restrict__ packed,
             }
         }
     }
+}
+
+// The two kernels differ in their register budget (an attribute cannot depend on a template
+// argument): 64 VGPRs = 8 waves per SIMD for the hand-scheduled variant, whose scalar weight loads
+// need the occupancy; 96 for the term-matrix variant, which spilled at 64.
+template <int R, bool ALIGNED16>
+__global__ void __launch_bounds__(WLOD_WAVES * WAVE) __attribute__((amdgpu_num_vgpr(64)))
+wlod_tile_kernel(const uint32_t *__restrict__ packed, const double *__restrict__ wtab,
+                 const double *__restrict__ D, double *__restrict__ out, WlodArgs p)
+{
+    wlod_tile_body<R, ALIGNED16, false>(packed, wtab, D, out, p);
+}
+
+template <int R, bool ALIGNED16>
+__global__ void __launch_bounds__(WLOD_WAVES * WAVE) __attribute__((amdgpu_num_vgpr(96)))
+wlod_tile_gl_kernel(const uint32_t *__restrict__ packed, const double *__restrict__ terms,
+                    const double *__restrict__ D, double *__restrict__ out, WlodArgs p)
+{
+    wlod_tile_body<R, ALIGNED16, true>(packed, terms, D, out, p);
 }
 
 // D[l][j] = 1.0 / LD[l - j][j] for the windows s = l - j of SNP l's own chromosome [lo, hi)
