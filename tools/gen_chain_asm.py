@@ -132,6 +132,8 @@ S_TMP = 55
 S_K = 56
 S_F0, S_F1 = 57, 58
 S_ROWS = 59                # POST: valid individuals (rows) of this item
+S_NEXT, S_STEP = 40, 41    # thinned output, CHAIN and POST: next sampled window (from the loop's first), step
+S_MASK, S_EXEC = 42, 44    # thinned output, POST: lanes that are rows of the shard; saved exec
 
 CLOBBER_V = list(range(64, 188))
 CLOBBER_S = list(range(40, 60))
@@ -201,8 +203,9 @@ def gen_R(g, slot, n):
     return last
 
 
-def gen_C(g, n, a_ops, tbuf):
-    """chain of batch n, the next-but-one batch's address ops woven in (1 per step)"""
+def gen_C(g, n, a_ops, tbuf, write=True):
+    """chain of batch n, the next-but-one batch's address ops woven in (1 per step); write=False:
+    the tile holds no sampled window (thinned output), nothing of it is kept"""
     buf = V_BUF[n % 2]
     a_ops = list(a_ops)
     P0, P1 = V_ACC, V_ACC + 2
@@ -217,7 +220,7 @@ def gen_C(g, n, a_ops, tbuf):
             g.emit(f"v_add_f64 {pair(dst)}, {pair(dst)}, {pair(buf + 4 * i + 2)}")
         if a_ops:
             g.emit(a_ops.pop(0))
-        if j % 2 == 1 and "chainwrite" not in ABL:
+        if j % 2 == 1 and write and "chainwrite" not in ABL:
             g.lds(f"ds_write_b128 v{V_TWR}, {quad(V_ACC)} offset:{tbuf * TILE_BUF + 8 * (j - 1)}")
     assert not a_ops
 
@@ -231,9 +234,11 @@ def gen_exp_reads(g, slot, eset):
     return last
 
 
-def chain_tile(g, slot, uid):
+def chain_tile(g, slot, uid, thin=False):
     """CHAIN, one tile k (unrolled position slot = k % NSLOT): COMB/EXP slot k % NEXP, tile buffer
-    k % NTILE"""
+    k % NTILE.  thin: tiles without a sampled window (S_NEXT >= the tile's end) take a copy of the
+    schedule without the 16 tile writes -- a ds_write_b128 holds the wave for ~28 cycles, and with
+    the stores gone CHAIN's pace is the kernel's."""
     tbuf = slot % NTILE
     nxt = (slot + 1) % NEXP
     slot = slot % NEXP
@@ -261,23 +266,43 @@ def chain_tile(g, slot, uid):
         e("s_waitcnt lgkmcnt(0)")
     g.drained()
     es, en = slot % 2, (slot + 1) % 2   # expanded-offset register set of this / the next tile
-    # batch 0: R(k,0) is complete (the poll drained the LDS queue)
-    r1 = gen_R(g, slot, 1)
-    gen_C(g, 0, all_addr_ops(2, es), tbuf)
-    # batch 1: fetch the next tile's expanded offsets into the other register set
-    exp = gen_exp_reads(g, nxt, en)
-    g.wait_lds(r1)
-    r2 = gen_R(g, slot, 2)
-    gen_C(g, 1, all_addr_ops(3, es), tbuf)
-    # batch 2
-    g.wait_lds(r2)
-    assert exp <= g.complete
-    r3 = gen_R(g, slot, 3)
-    gen_C(g, 2, all_addr_ops(0, en), tbuf)
-    # batch 3
-    g.wait_lds(r3)
-    gen_R(g, nxt, 0)
-    gen_C(g, 3, all_addr_ops(1, en), tbuf)
+
+    def body(write):
+        # batch 0: R(k,0) is complete (the poll drained the LDS queue)
+        r1 = gen_R(g, slot, 1)
+        gen_C(g, 0, all_addr_ops(2, es), tbuf, write)
+        # batch 1: fetch the next tile's expanded offsets into the other register set
+        exp = gen_exp_reads(g, nxt, en)
+        g.wait_lds(r1)
+        r2 = gen_R(g, slot, 2)
+        gen_C(g, 1, all_addr_ops(3, es), tbuf, write)
+        # batch 2
+        g.wait_lds(r2)
+        assert exp <= g.complete
+        r3 = gen_R(g, slot, 3)
+        gen_C(g, 2, all_addr_ops(0, en), tbuf, write)
+        # batch 3
+        g.wait_lds(r3)
+        gen_R(g, nxt, 0)
+        gen_C(g, 3, all_addr_ops(1, en), tbuf, write)
+
+    if thin:
+        e(f"s_lshl_b32 s{S_TMP}, s{S_K}, 5")
+        e(f"s_add_u32 s{S_TMP}, s{S_TMP}, 32")                 # first window of tile k + 1
+        e(f"s_cmp_lt_u32 s{S_NEXT}, s{S_TMP}")
+        e(f"s_cbranch_scc0 CHAIN_NOWR_{uid}_%=")
+        body(True)
+        e(f"CHAIN_ADV_{uid}_%=:")                                # past this tile's samples
+        e(f"s_add_u32 s{S_NEXT}, s{S_NEXT}, s{S_STEP}")
+        e(f"s_cmp_lt_u32 s{S_NEXT}, s{S_TMP}")
+        e(f"s_cbranch_scc1 CHAIN_ADV_{uid}_%=")
+        e(f"s_branch CHAIN_JOIN_{uid}_%=")
+        e(f"CHAIN_NOWR_{uid}_%=:")
+        g.drained()                                              # same state as at the branch
+        body(False)
+        e(f"CHAIN_JOIN_{uid}_%=:")
+    else:
+        body(True)
     # publish: tile k complete in LDS (its writes are waited for), input slot k released
     e(f"s_add_u32 s{S_K}, s{S_K}, 1")
     e(f"v_mov_b32_e32 v{V_TMP0}, s{S_K}")
@@ -286,9 +311,12 @@ def chain_tile(g, slot, uid):
     e(f"ds_write_b32 v{V_FLAG}, v{V_TMP0}")
 
 
-def gen_chain(g):
+def gen_chain(g, thin=False):
     e = g.emit
     e("ROLE_CHAIN_%=:")
+    if thin:
+        e(f"s_mov_b32 s{S_NEXT}, %[next]")
+        e(f"s_mov_b32 s{S_STEP}, %[step]")
     e(f"s_mov_b32 s{S_CNT}, %[ntiles]")
     e(f"s_mov_b32 s{S_K}, 0")
     e(f"v_mov_b64 {pair(V_ACC + 2)}, %[acc]")
@@ -326,7 +354,7 @@ def gen_chain(g):
         e(op)
     e("CHAIN_LOOP_%=:")
     for slot in range(NSLOT):
-        chain_tile(g, slot, slot)
+        chain_tile(g, slot, slot, thin)
         e(f"s_cmp_eq_u32 s{S_K}, s{S_CNT}")
         if slot < NSLOT - 1:
             e("s_cbranch_scc1 CHAIN_DONE_%=")
@@ -486,9 +514,6 @@ def post_tile(g, slot, uid):
 # the tile's one or few sampled columns go to a [individual][sample] matrix, 8 B per lane; nothing
 # else is stored, so the kernel runs at CHAIN's pace.  S_NEXT = next sampled window, counted from
 # the loop's first window; S_OUT = address of that sample's column in the item's first row.
-S_NEXT, S_STEP, S_MASK, S_EXEC = 40, 41, 42, 44
-
-
 def post_tile_thin(g, slot, uid):
     tbuf = slot % NTILE
     assert tbuf * TILE_BUF + 31 * 8 <= 65535
@@ -739,7 +764,7 @@ def gen_all(thin=False):
     e("s_cbranch_scc1 ROLE_PRE_%=")
     e("s_cmp_eq_u32 %[wave], 3")
     e("s_cbranch_scc1 ROLE_COMB_%=")
-    gen_chain(g)
+    gen_chain(g, thin)
     if thin:
         gen_post_thin(g)
     else:
