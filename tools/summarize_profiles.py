@@ -18,7 +18,7 @@ PROF = os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
-    hits = sorted(glob.glob(os.path.join(OUT, pattern), recursive=True))
+    hits = sorted(glob.glob(os.path.join(OUT, pattern), recursive=True), key=os.path.getmtime)   # newest run
     if not hits:
         sys.exit(f"missing {pattern} under gpurun_out/ -- run tools/profile_r01.sh on the GPU box first")
     return hits[-1]
