@@ -1165,7 +1165,8 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
     const size_t n = (size_t)p->nloci * winsize;
     DevBuf<int32_t> d_loc, d_pair;
     DevBuf<double> d_hf, d_fwd, d_bwd, d_ld;
-    auto done = [&](int code) { d_loc.release(); d_pair.release(); d_hf.release(); d_fwd.release(); d_bwd.release(); d_ld.release(); return code; };
+    DevBuf<LdSumChr> d_sum_chrs;
+    auto done = [&](int code) { d_loc.release(); d_pair.release(); d_hf.release(); d_fwd.release(); d_bwd.release(); d_ld.release(); d_sum_chrs.release(); return code; };
     const int32_t *loc = locus_counts, *pair = pair_counts;
     hipError_t e = hipSuccess;
     if (where == GARLIC_HOST) {
@@ -1190,13 +1191,32 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
         hipLaunchKernelGGL(ld_homfreq_kernel, dim3((unsigned)((p->nloci + 255) / 256)), dim3(256), 0, s, loc,
                            p->nloci, d_hf.p);
     }
+    // ordered sums: LDS-tiled kernel (one thread per column of the LD row) unless the window is too wide
+    const bool tiled = winsize <= LD_SUM_MAX_W && !getenv("GARLIC_LD_SUM_L2");
+    std::vector<LdSumChr> sum_chrs;
+    int64_t sum_blocks = 0;
+    for (int c = 0; tiled && c < p->nchr; c++) {
+        const int64_t nstarts = p->chr_off[c + 1] - p->chr_off[c] - winsize + 1;
+        if (nstarts < 1) continue;
+        sum_chrs.push_back(LdSumChr{p->chr_off[c], nstarts, sum_blocks});
+        sum_blocks += (nstarts + LD_SUM_B - 1) / LD_SUM_B;
+    }
+    if (tiled && (rc = d_sum_chrs.reserve(std::max<size_t>(sum_chrs.size(), 1)))) return done(rc);
     for (int c = 0; c < p->nchr; c++) {
         const int64_t lo = p->chr_off[c], hi = p->chr_off[c + 1];
         hipLaunchKernelGGL(ld_hr2_kernel, dim3((unsigned)(hi - lo)), dim3(256), 0, s, pair, d_hf.p, lo, hi,
                            winsize, d_fwd.p, d_bwd.p);
-        if (hi - lo >= winsize)
-            hipLaunchKernelGGL(ld_sum_kernel, dim3((unsigned)(hi - lo - winsize + 1)), dim3(256), 0, s,
-                               d_fwd.p, d_bwd.p, lo, winsize, ld);
+        if (hi - lo >= winsize && !tiled)
+            hipLaunchKernelGGL(ld_sum_kernel, dim3((unsigned)(hi - lo - winsize + 1)), dim3(256), 0, s, d_fwd.p, d_bwd.p,
+                               lo, winsize, ld);
+    }
+    if (tiled && !sum_chrs.empty()) {   // all chromosomes in one grid, after every hr2 value exists
+        e = hipMemcpyAsync(d_sum_chrs.p, sum_chrs.data(), sizeof(LdSumChr) * sum_chrs.size(), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
+        const int threads = (winsize + WAVE - 1) / WAVE * WAVE;
+        hipLaunchKernelGGL(ld_sum_tiled_kernel, dim3((unsigned)sum_blocks), dim3(threads),
+                           sizeof(double) * 2 * (2 * (size_t)winsize - 1 + 128 + threads), s, d_fwd.p, d_bwd.p, d_sum_chrs.p,
+                           (int)sum_chrs.size(), winsize, ld);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));

@@ -208,4 +208,95 @@ ld_sum_kernel(const double *__restrict__ fwd, const double *__restrict__ bwd, in
     }
 }
 
+// The same sums with the W^2 terms of a window start read from LDS instead of L2 (ld_sum_kernel
+// moves 16 W^2 bytes per window start through L2 and is bound by that: 21.6 ms of a 39-ms call at
+// 2M SNPs x 1280).  One workgroup = LD_SUM_B consecutive window starts s0 .. s0+B-1; thread k holds
+// the B accumulators LD[s0+q][k] in registers.  The workgroup walks the SNPs i = s0, s0+1, ..; per
+// step it stages ONE combined row
+//     C_i[x] = hr2(i, i + d),  d = x - (W-1) in (-W, W):   bwd[i][-d] | 1.0 | fwd[i][d]
+// (2W-1 doubles, double-buffered) and every accumulator whose window contains i -- a wave-uniform
+// condition on q -- adds C_i[(s0+q+k) - i + W-1]: consecutive lanes read consecutive doubles.  The
+// terms of one accumulator arrive in the order i = s .. s+W-1, from 0.0, as in ldHR2
+// (garlic-data.cpp:521-527).
+constexpr int LD_SUM_B = 64;
+constexpr int LD_SUM_AHEAD = 4;
+constexpr int LD_SUM_MAX_W = 256;                              // one thread per column; 64 accumulators need the registers
+struct LdSumChr {        // one chromosome's share of the grid
+    int64_t lo;          // global index of its first SNP
+    int64_t nstarts;     // window starts with a full window (>= 1)
+    int64_t block0;      // first workgroup of the chromosome
+};
+__global__ void __launch_bounds__(LD_SUM_MAX_W)
+ld_sum_tiled_kernel(const double *__restrict__ fwd, const double *__restrict__ bwd,
+                    const LdSumChr *__restrict__ chrs, int nchr, int W, double *__restrict__ ld)
+{
+    // two row buffers of L = 64 + (2W-1) + 64 + blockDim doubles: the row proper sits 64 doubles in,
+    // so that every accumulator of every lane -- whether its window contains the step's SNP or not,
+    // lanes k >= W included -- reads inside its buffer and the look-ups need no clamping
+    extern __shared__ double ld_rows[];
+    const int k = threadIdx.x, nthreads = blockDim.x, RW = 2 * W - 1, L = RW + 128 + nthreads;
+    int c = 0;                                                // all chromosomes in one grid
+    while (c + 1 < nchr && (int64_t)blockIdx.x >= chrs[c + 1].block0) c++;
+    const int64_t s0 = chrs[c].lo + ((int64_t)blockIdx.x - chrs[c].block0) * LD_SUM_B;
+    const int ns = (int)min<int64_t>(LD_SUM_B, chrs[c].lo + chrs[c].nstarts - s0);
+    const int nsteps = ns + W - 1;
+    auto term = [&](int64_t i, int x) -> double {            // C_i[x]
+        return x < W - 1 ? bwd[i * W + (W - 1 - x)] : (x == W - 1 ? 1.0 : fwd[i * W + (x - W + 1)]);
+    };
+    double acc[LD_SUM_B];
+#pragma unroll
+    for (int q = 0; q < LD_SUM_B; q++) acc[q] = 0.0;
+    // rows are requested LD_SUM_AHEAD steps before they are staged (a step is far shorter than a trip
+    // to memory); at most 2 elements per thread and row (RW < 2 * nthreads)
+    const int x0 = min(k, RW - 1), x1 = min(k + nthreads, RW - 1);
+    double pre[LD_SUM_AHEAD][2];
+#pragma unroll
+    for (int u = 0; u < LD_SUM_AHEAD; u++) {
+        const int64_t i = s0 + min(u, nsteps - 1);
+        pre[u][0] = term(i, x0);
+        pre[u][1] = term(i, x1);
+    }
+    for (int j0 = 0; j0 < nsteps; j0 += LD_SUM_AHEAD) {
+#pragma unroll
+        for (int u = 0; u < LD_SUM_AHEAD; u++) {
+            const int j = j0 + u;
+            if (j >= nsteps) break;
+            double *row = ld_rows + (j & 1) * L + 64;
+            if (k < RW) row[k] = pre[u][0];
+            if (k + nthreads < RW) row[k + nthreads] = pre[u][1];
+            {
+                const int64_t i = s0 + min(j + LD_SUM_AHEAD, nsteps - 1);
+                pre[u][0] = term(i, x0);
+                pre[u][1] = term(i, x1);
+            }
+            __syncthreads();                                  // (the other buffer was last read two steps ago)
+            // accumulators q in [qlo, qhi] take a term of this row.  Per group of 16 that touches the
+            // range: all 16 look-ups in flight (immediate offsets), then the adds, each behind a
+            // wave-uniform branch -- a test in front of each look-up would pay one LDS round trip per
+            // term, a select per add costs twice the add (and one test per quad of adds, tried, made
+            // the compiler's code slower).
+            const int qlo = max(0, j - W + 1), qhi = min(j, ns - 1);
+            const double *cp = row + (W - 1 + k - j);         // + q
+#pragma unroll
+            for (int g = 0; g < LD_SUM_B; g += 16) {
+                if (g > qhi || g + 15 < qlo) continue;
+                double t[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) t[r] = cp[g + r];
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    if (g + r >= qlo && g + r <= qhi) {
+                        acc[g + r] += t[r];
+                        asm volatile("" ::: "memory");        // keeps the branch a branch
+                    }
+            }
+        }
+    }
+    if (k < W) {
+#pragma unroll
+        for (int q = 0; q < LD_SUM_B; q++)
+            if (q < ns) ld[(s0 + q) * W + k] = acc[q];
+    }
+}
+
 } // namespace garlic
