@@ -25,6 +25,7 @@ SYMBOLS = [
     "garlic_panel_set_ld", "garlic_lod_out_layout", "garlic_lod_windows",
     "garlic_wlod_windows", "garlic_lod_flatten", "garlic_last_call_stats",
     "garlic_panel_compute_ld", "garlic_ld_counts", "garlic_ld_finish", "garlic_roh_coverage",
+    "garlic_panel_release_scratch",
     "garlic_lod_feed", "garlic_ctx_set_async",
     "garlic_recent_kernel_ms",
 ]
@@ -77,6 +78,7 @@ def lib():
     L.garlic_panel_set_freq.argtypes = [_vp, _f64p]
     L.garlic_panel_set_genotypes.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
     L.garlic_panel_set_gl.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
+    L.garlic_panel_release_scratch.argtypes = [_vp]
     L.garlic_panel_set_phase.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
     L.garlic_panel_set_ld.argtypes = [_vp, C.c_int32, _vp, C.c_int32]
     L.garlic_lod_out_layout.argtypes = [_vp, C.c_int32, C.c_int32, _i64p, _i64p, _i64p]
@@ -203,6 +205,10 @@ class Panel:
         assert gl.dtype == np.float64 and gl.ndim == 2 and gl.strides[1] == 8
         check(lib().garlic_panel_set_gl(self.handle, _vp(gl.ctypes.data), gl.strides[0] // 8, locus_begin,
                                         gl.shape[0], HOST))
+
+    def release_scratch(self):
+        """free the device scratch the panel keeps between calls (LD buffers, score / feed scratch)"""
+        check(lib().garlic_panel_release_scratch(self.handle))
 
     def set_phase(self, first_copy, locus_begin=0):
         """first_copy: uint8/bool [nloci_chunk][nind], HapData::firstCopy (--phased)."""

@@ -162,6 +162,19 @@ struct garlic_panel {
     DevBuf<double> d_rld, d_decay, d_stage64;
     DevBuf<uint64_t> d_phase;                      // HapData::firstCopy as bit planes [blk][nloci] (--phased LD)
     bool have_phase = false;
+    // scratch of the LD-weight kernels, kept between calls (window-size sweeps): at 10M SNPs the six
+    // 8-GB allocations and frees of a call cost 9x its kernels.  garlic_panel_release_scratch drops it.
+    struct {
+        DevBuf<uint64_t> sub, m, h, o;
+        DevBuf<int32_t> loc, pair;
+        DevBuf<double> hf, fwd, bwd, ld;
+        DevBuf<LdSumChr> sum_chrs;
+        void release()
+        {
+            sub.release(); m.release(); h.release(); o.release(); loc.release(); pair.release();
+            hf.release(); fwd.release(); bwd.release(); ld.release(); sum_chrs.release();
+        }
+    } lds;
     // tuned wLOD path: skewed reciprocal weights, per-SNP score rows, window mask, tile index
     DevBuf<double> d_skew, d_wtab;
     DevBuf<uint8_t> d_valid;
@@ -850,7 +863,7 @@ int garlic_panel_destroy(garlic_panel *p)
     p->d_chr_off.release(); p->d_tab.release(); p->d_blk_counts.release();
     p->d_blk_offsets.release(); p->d_total.release(); p->d_boundaries.release();
     p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release(); p->d_row_counts.release(); p->d_codes.release(); p->d_tabgl.release();
-    p->d_rld.release(); p->d_decay.release(); p->d_stage64.release(); p->d_phase.release();
+    p->d_rld.release(); p->d_decay.release(); p->d_stage64.release(); p->d_phase.release(); p->lds.release();
     p->d_glterms.release(); p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release();
     p->d_out.release(); p->d_feed.release();
     delete p;
@@ -1115,9 +1128,9 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
             sub[i >> 6] |= (uint64_t)1 << (i & 63);
         }
     }
-    DevBuf<uint64_t> d_sub, d_m, d_h, d_o;
-    DevBuf<int32_t> d_loc, d_pair;
-    auto done = [&](int code) { d_sub.release(); d_m.release(); d_h.release(); d_o.release(); d_loc.release(); d_pair.release(); return code; };
+    DevBuf<uint64_t> &d_sub = p->lds.sub, &d_m = p->lds.m, &d_h = p->lds.h, &d_o = p->lds.o;
+    DevBuf<int32_t> &d_loc = p->lds.loc, &d_pair = p->lds.pair;
+    auto done = [&](int code) { return code; };   // the scratch stays with the panel
     const size_t npl = (size_t)nblk * p->nloci, npair = (size_t)p->nloci * winsize * 2;
     if ((rc = d_sub.reserve(nblk)) || (rc = d_m.reserve(npl)) || (rc = d_h.reserve(npl))) return done(rc);
     if (phased && (rc = d_o.reserve(npl))) return done(rc);
@@ -1164,10 +1177,10 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
     if (!locus_counts || !pair_counts) return fail(GARLIC_ERR_INVALID, "count buffers are required");
     hipStream_t s = p->ctx->stream;
     const size_t n = (size_t)p->nloci * winsize;
-    DevBuf<int32_t> d_loc, d_pair;
-    DevBuf<double> d_hf, d_fwd, d_bwd, d_ld;
-    DevBuf<LdSumChr> d_sum_chrs;
-    auto done = [&](int code) { d_loc.release(); d_pair.release(); d_hf.release(); d_fwd.release(); d_bwd.release(); d_ld.release(); d_sum_chrs.release(); return code; };
+    DevBuf<int32_t> &d_loc = p->lds.loc, &d_pair = p->lds.pair;
+    DevBuf<double> &d_hf = p->lds.hf, &d_fwd = p->lds.fwd, &d_bwd = p->lds.bwd, &d_ld = p->lds.ld;
+    DevBuf<LdSumChr> &d_sum_chrs = p->lds.sum_chrs;
+    auto done = [&](int code) { return code; };   // the scratch stays with the panel
     const int32_t *loc = locus_counts, *pair = pair_counts;
     hipError_t e = hipSuccess;
     if (where == GARLIC_HOST) {
@@ -1235,23 +1248,36 @@ int garlic_panel_compute_ld(garlic_panel *p, int32_t winsize, int32_t phased, co
 {
     int rc;
     if ((rc = ld_check(p, winsize, phased))) return rc;
-    DevBuf<int32_t> d_loc, d_pair;
-    auto done = [&](int code) { d_loc.release(); d_pair.release(); return code; };
+    DevBuf<int32_t> &d_loc = p->lds.loc, &d_pair = p->lds.pair;   // kept with the panel, as all LD scratch
     if ((rc = d_loc.reserve((size_t)p->nloci * 2)) || (rc = d_pair.reserve((size_t)p->nloci * winsize * 2)))
-        return done(rc);
-    if ((rc = garlic_ld_counts(p, winsize, phased, sub_idx, n_sub, d_loc.p, d_pair.p, GARLIC_DEVICE))) return done(rc);
+        return rc;
+    if ((rc = garlic_ld_counts(p, winsize, phased, sub_idx, n_sub, d_loc.p, d_pair.p, GARLIC_DEVICE))) return rc;
     if (where == GARLIC_DEVICE || !ld_out)
-        return done(garlic_ld_finish(p, winsize, phased, d_loc.p, d_pair.p, ld_out, GARLIC_DEVICE));
+        return garlic_ld_finish(p, winsize, phased, d_loc.p, d_pair.p, ld_out, GARLIC_DEVICE);
     // host output: finish on the device, then copy out
-    DevBuf<double> d_ld;
-    if ((rc = d_ld.reserve((size_t)p->nloci * winsize))) return done(rc);
+    DevBuf<double> &d_ld = p->lds.ld;
+    if ((rc = d_ld.reserve((size_t)p->nloci * winsize))) return rc;
     rc = garlic_ld_finish(p, winsize, phased, d_loc.p, d_pair.p, d_ld.p, GARLIC_DEVICE);
     if (rc == GARLIC_OK) {
         hipError_t e = hipMemcpy(ld_out, d_ld.p, sizeof(double) * p->nloci * winsize, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(GARLIC_ERR_HIP, "LD copy-out: %s", hipGetErrorString(e));
     }
-    d_ld.release();
-    return done(rc);
+    return rc;
+}
+
+// Drops everything the panel keeps only to make the next call cheaper: LD scratch, the score and
+// feed scratch of host-output / feed calls, staging buffers.  Inputs, tables, LD weights and the
+// TGLS term matrix stay.
+int garlic_panel_release_scratch(garlic_panel *p)
+{
+    if (!p) return fail(GARLIC_ERR_INVALID, "panel is NULL");
+    int rc;
+    if ((rc = set_device(p->ctx))) return rc;
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    p->lds.release();
+    p->d_out.release(); p->d_feed.release();
+    p->d_stage16.release(); p->d_stage64.release();
+    return GARLIC_OK;
 }
 
 int garlic_lod_out_layout(garlic_panel *p, int32_t pitch_align, int32_t nind_out, int64_t *chr_base,

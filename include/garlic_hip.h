@@ -145,6 +145,12 @@ int garlic_ld_counts(garlic_panel *panel, int32_t winsize, int32_t phased, const
 int garlic_ld_finish(garlic_panel *panel, int32_t winsize, int32_t phased, const int32_t *locus_counts,
                      const int32_t *pair_counts, double *ld_out, int32_t where);
 
+/* A panel keeps its device scratch between calls (LD counting and summing buffers: about
+ * 5 x nloci x winsize x 8 bytes; the score scratch of host-output and feed calls), because at scale
+ * allocating it costs more than the kernels.  This frees it; inputs, tables, the installed LD weights
+ * and the TGLS term matrix stay, and the next call allocates again what it needs. */
+int garlic_panel_release_scratch(garlic_panel *panel);
+
 /* Output addressing for this panel: pitch_align = 1 gives the reference's dense rows
  * (chr_pitch[c] = chr_nloci[c], chromosome blocks back to back).  A larger value rounds every row
  * pitch and chromosome base up to that many doubles AND reserves rows up to the next multiple of

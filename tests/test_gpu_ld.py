@@ -178,6 +178,8 @@ def test_phased_ld_matches_oracle(gpu_ctx, W, nind):
         sub = np.sort(rng.choice(nind, size=max(2, nind // 3), replace=False)).astype(np.int32)
         assert same(panel.compute_ld(W, sub_idx=sub, phased=True), oracle_r2(chroms, phase, W, sub))
         assert same(panel.compute_ld(W), oracle_ld(chroms, W))     # the unphased weights are still hr2
+        panel.release_scratch()                                     # cached LD buffers gone: allocated again
+        assert same(panel.compute_ld(W, phased=True), oracle_r2(chroms, phase, W))
 
 
 def test_phased_ld_sharded(gpu_ctx):
