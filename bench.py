@@ -142,7 +142,8 @@ def main():
     panel = abi.Panel(ctx, spec.chr_nloci, nind)
     panel.set_map(spec.pos, spec.centro_start, spec.centro_end, gpos=spec.gpos)
     panel.set_freq(spec.freq)
-    n_cpu = 0 if (args.no_cpu or rank != 0) else min(args.cpu_inds, nind)
+    # CPU baseline: rank 0 of the single-GPU run only (the other ranks of a larger run would wait for it)
+    n_cpu = 0 if (args.no_cpu or rank != 0 or world > 1) else min(args.cpu_inds, nind)
     geno_sample = np.empty((nloci, n_cpu), dtype=np.int16) if n_cpu else None
     for l0, g in synth.genotype_chunks(spec, nind, dev, ind_offset=rank * nind):
         torch.cuda.synchronize()
