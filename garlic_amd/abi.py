@@ -21,7 +21,8 @@ SYMBOLS = [
     "garlic_hip_abi_version", "garlic_hip_last_error", "garlic_hip_device_count",
     "garlic_ctx_create", "garlic_ctx_destroy", "garlic_ctx_synchronize",
     "garlic_panel_create", "garlic_panel_destroy", "garlic_panel_set_map",
-    "garlic_panel_set_freq", "garlic_panel_set_genotypes", "garlic_panel_set_gl", "garlic_panel_set_phase",
+    "garlic_panel_set_freq", "garlic_panel_set_genotypes", "garlic_panel_set_genotypes_2bit", "garlic_panel_set_gl",
+    "garlic_panel_set_phase",
     "garlic_panel_set_ld", "garlic_lod_out_layout", "garlic_lod_windows",
     "garlic_wlod_windows", "garlic_lod_flatten", "garlic_last_call_stats",
     "garlic_panel_compute_ld", "garlic_ld_counts", "garlic_ld_finish", "garlic_roh_coverage",
@@ -79,6 +80,7 @@ def lib():
     L.garlic_panel_set_genotypes.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
     L.garlic_panel_set_gl.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
     L.garlic_panel_release_scratch.argtypes = [_vp]
+    L.garlic_panel_set_genotypes_2bit.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
     L.garlic_panel_set_phase.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
     L.garlic_panel_set_ld.argtypes = [_vp, C.c_int32, _vp, C.c_int32]
     L.garlic_lod_out_layout.argtypes = [_vp, C.c_int32, C.c_int32, _i64p, _i64p, _i64p]
@@ -205,6 +207,14 @@ class Panel:
         assert gl.dtype == np.float64 and gl.ndim == 2 and gl.strides[1] == 8
         check(lib().garlic_panel_set_gl(self.handle, _vp(gl.ctypes.data), gl.strides[0] // 8, locus_begin,
                                         gl.shape[0], HOST))
+
+    def set_genotypes_2bit(self, rows, ind_offset=0, locus_begin=0):
+        """rows: uint8 [nloci_chunk][row_bytes], 4 genotypes per byte (3 = missing), individuals of the
+        whole data set; this panel's individuals start at ind_offset."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        assert rows.ndim == 2
+        check(lib().garlic_panel_set_genotypes_2bit(self.handle, _vp(rows.ctypes.data), rows.shape[1], ind_offset,
+                                                    locus_begin, rows.shape[0], HOST))
 
     def release_scratch(self):
         """free the device scratch the panel keeps between calls (LD buffers, score / feed scratch)"""

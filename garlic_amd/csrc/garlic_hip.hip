@@ -951,6 +951,50 @@ int garlic_panel_set_genotypes(garlic_panel *p, const int16_t *geno, int64_t ld,
     return GARLIC_OK;
 }
 
+int garlic_panel_set_genotypes_2bit(garlic_panel *p, const uint8_t *rows, int64_t row_bytes, int64_t ind_offset,
+                                    int64_t locus_begin, int64_t locus_count, int32_t where)
+{
+    if (!p || !rows) return fail(GARLIC_ERR_INVALID, "panel and rows are required");
+    if (ind_offset < 0 || row_bytes < (ind_offset + p->nind + 3) / 4)
+        return fail(GARLIC_ERR_INVALID, "row_bytes %lld too small for individuals [%lld,+%d)", (long long)row_bytes,
+                    (long long)ind_offset, p->nind);
+    if (locus_begin < 0 || locus_count < 1 || locus_begin + locus_count > p->nloci)
+        return fail(GARLIC_ERR_INVALID, "locus range [%lld,+%lld) outside panel of %lld loci",
+                    (long long)locus_begin, (long long)locus_count, (long long)p->nloci);
+    int rc;
+    if ((rc = set_device(p->ctx))) return rc;
+    hipStream_t s = p->ctx->stream;
+    DevBuf<uint8_t> stage;
+    const int64_t slab_rows = (where == GARLIC_HOST) ? std::max<int64_t>(16, ((int64_t)256 << 20) / row_bytes)
+                                                     : locus_count;
+    for (int64_t done = 0; done < locus_count; done += slab_rows) {
+        const int64_t nrows = std::min(slab_rows, locus_count - done);
+        const int64_t l0 = locus_begin + done;
+        const uint8_t *src = rows + done * row_bytes;
+        hipError_t e = hipSuccess;
+        if (where == GARLIC_HOST) {
+            if ((rc = stage.reserve((size_t)(nrows * row_bytes)))) { stage.release(); return rc; }
+            e = hipMemcpyAsync(stage.p, src, (size_t)(nrows * row_bytes), hipMemcpyHostToDevice, s);
+            src = stage.p;
+        }
+        const int64_t w_lo = (GOFF + l0) >> 4;
+        const int64_t w_hi = ((GOFF + l0 + nrows - 1) >> 4) + 1;
+        for (int64_t w = w_lo; e == hipSuccess && w < w_hi; w += 65535) {
+            const int64_t wn = std::min<int64_t>(65535, w_hi - w);
+            dim3 grid((unsigned)((p->nind_pad + 255) / 256), (unsigned)wn);
+            hipLaunchKernelGGL(pack_genotypes_2bit_kernel, grid, dim3(256), 0, s, src, row_bytes, ind_offset, l0, nrows,
+                               p->nind, p->nind_pad, p->nwordrows, p->d_packed.p, w, w + wn);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);                      // staging buffer is reused
+        if (e != hipSuccess) { stage.release(); return fail(GARLIC_ERR_HIP, "set_genotypes_2bit: %s", hipGetErrorString(e)); }
+    }
+    stage.release();
+    p->have_geno = true;
+    p->glterms_valid = false;
+    return GARLIC_OK;
+}
+
 int garlic_panel_set_gl(garlic_panel *p, const double *gl, int64_t ld, int64_t locus_begin,
                         int64_t locus_count, int32_t where)
 {

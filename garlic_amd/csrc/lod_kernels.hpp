@@ -104,6 +104,34 @@ __global__ void pack_genotypes_kernel(const int16_t *__restrict__ geno, int64_t 
     *dst = word;
 }
 
+// The same from SNP-major 2-bit rows (4 genotypes per byte, code 3 = missing; genotype cache / bed-like
+// readers): rows[(l - locus_begin) * row_bytes + j / 4] >> 2 * (j % 4), j = ind_offset + shard-local
+// individual.  An eighth of the bytes of the int16 rows on the host and over PCIe.
+__global__ void pack_genotypes_2bit_kernel(const uint8_t *__restrict__ rows, int64_t row_bytes,
+                                           int64_t ind_offset, int64_t locus_begin, int64_t locus_count,
+                                           int32_t nind, int64_t nind_pad, int64_t nwordrows,
+                                           uint32_t *__restrict__ packed, int64_t word_lo, int64_t word_hi)
+{
+    int64_t ind = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t w = word_lo + blockIdx.y;
+    if (ind >= nind_pad || w >= word_hi) return;
+    uint32_t *dst = packed + packed_index(w, ind, nwordrows);
+    uint32_t word = *dst;
+    if (ind >= nind) { *dst = 0xFFFFFFFFu; return; }
+    const int64_t j = ind_offset + ind;
+    const int sh = 2 * (int)(j & 3);
+    int64_t g0 = w * 16 - GOFF;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        int64_t l = g0 + q - locus_begin;
+        if (l >= 0 && l < locus_count) {
+            const uint32_t code = (rows[l * row_bytes + (j >> 2)] >> sh) & 3u;
+            word = (word & ~(3u << (2 * q))) | (code << (2 * q));
+        }
+    }
+    *dst = word;
+}
+
 __global__ void fill_u32_kernel(uint32_t *p, int64_t n, uint32_t v)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

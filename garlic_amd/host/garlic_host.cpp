@@ -151,6 +151,7 @@ HapData *initHapData(unsigned int nind, unsigned int nloci, bool PHASED)
     d->nloci = nloci;
     d->data = new short *[nloci];
     d->firstCopy = PHASED ? new bool *[nloci] : nullptr;
+    d->packed = nullptr;
     for (unsigned l = 0; l < nloci; l++) {
         d->data[l] = new short[nind];
         std::fill(d->data[l], d->data[l] + nind, (short)MISSING);
@@ -165,11 +166,13 @@ void releaseHapData(HapData *d)
 {
     if (!d) return;
     for (int l = 0; l < d->nloci; l++) {
-        delete[] d->data[l];
+        if (d->data) delete[] d->data[l];
         if (d->firstCopy) delete[] d->firstCopy[l];
+        if (d->packed) delete[] d->packed[l];
     }
     delete[] d->data;
     delete[] d->firstCopy;
+    delete[] d->packed;
     delete d;
 }
 void releaseHapData(std::vector<HapData *> *v) { for (auto d : *v) releaseHapData(d); delete v; }
@@ -265,11 +268,13 @@ std::vector<GenoFreqData *> *calculateGenoFreq(std::vector<HapData *> *haps)
         g->homFreq = new double[h->nloci];
         for (int l = 0; l < h->nloci; l++) {
             double total = 0, hom = 0;
-            for (int i = 0; i < h->nind; i++)
-                if (h->data[l][i] != -9) {
-                    if (h->data[l][i] == 2 || h->data[l][i] == 0) hom++;
+            for (int i = 0; i < h->nind; i++) {
+                const short v = genotypeAt(h, l, i);
+                if (v != -9) {
+                    if (v == 2 || v == 0) hom++;
                     total++;
                 }
+            }
             hom /= total;
             g->homFreq[l] = hom;
         }
@@ -330,6 +335,7 @@ void flushChromosome(const std::string &chr, std::vector<short *> &hap, std::vec
     h->nloci = n;
     h->data = new short *[n];
     h->firstCopy = fc.empty() ? nullptr : new bool *[n];
+    h->packed = nullptr;
     FreqData *f = initFreqData(n);
     for (int l = 0; l < n; l++) {
         if (h->firstCopy) h->firstCopy[l] = fc[l];
@@ -530,26 +536,29 @@ void filterSites(size_t c, const std::vector<char> &keep, std::vector<MapData *>
     if (n < 1) fail("no sites left on " + m->chr + " after filtering");
     MapData *m2 = initMapData(n);
     m2->chr = m->chr;
-    HapData *h2 = new HapData{new short *[n], h->nind, n, h->firstCopy ? new bool *[n] : nullptr};
+    HapData *h2 = new HapData{h->data ? new short *[n] : nullptr, h->nind, n, h->firstCopy ? new bool *[n] : nullptr,
+                              h->packed ? new unsigned char *[n] : nullptr};
     FreqData *f2 = initFreqData(n);
     GenoLikeData *g2 = g ? new GenoLikeData{new double *[n], g->nind, n} : nullptr;
     int j = 0;
     for (int l = 0; l < m->nloci; l++) {
         if (!keep[l]) {
-            delete[] h->data[l];
+            if (h->data) delete[] h->data[l];
+            if (h->packed) delete[] h->packed[l];
             if (h->firstCopy) delete[] h->firstCopy[l];
             if (g) delete[] g->data[l];
             continue;
         }
         m2->physicalPos[j] = m->physicalPos[l]; m2->geneticPos[j] = m->geneticPos[l];
         m2->locusName[j] = m->locusName[l]; m2->allele[j] = m->allele[l];
-        h2->data[j] = h->data[l];
+        if (h->data) h2->data[j] = h->data[l];
+        if (h->packed) h2->packed[j] = h->packed[l];
         if (h->firstCopy) h2->firstCopy[j] = h->firstCopy[l];
         f2->freq[j] = f->freq[l];
         if (g) g2->data[j] = g->data[l];
         j++;
     }
-    delete[] h->data; delete[] h->firstCopy; delete h;
+    delete[] h->data; delete[] h->firstCopy; delete[] h->packed; delete h;
     if (g) { delete[] g->data; delete g; (*gls)[c] = g2; }
     releaseMapData(m); releaseFreqData(f);
     (*maps)[c] = m2; (*haps)[c] = h2; (*freqs)[c] = f2;
@@ -709,6 +718,7 @@ void writeGenotypeCache(const std::string &path, std::vector<HapData *> *haps, s
         o.put(freqs->at(c)->freq, sizeof(double) * m->nloci);
         for (int l = 0; l < m->nloci; l++) o.str(m->locusName[l]);
         for (int l = 0; l < m->nloci; l++) {
+            if (h->packed) { o.put(h->packed[l], row); continue; }
             std::fill(bits.begin(), bits.end(), 0);
             for (int i = 0; i < nind; i++) {
                 const short g = h->data[l][i];
@@ -728,7 +738,7 @@ void writeGenotypeCache(const std::string &path, std::vector<HapData *> *haps, s
 }
 
 void loadGenotypeCache(const std::string &path, int &numLoci, int &numInd, std::vector<HapData *> **haps,
-                       std::vector<MapData *> **maps, std::vector<FreqData *> **freqs)
+                       std::vector<MapData *> **maps, std::vector<FreqData *> **freqs, bool keepPacked)
 {
     CacheIn in(path);
     char magic[8];
@@ -765,9 +775,15 @@ void loadGenotypeCache(const std::string &path, int &numLoci, int &numInd, std::
             (*freqs)->push_back(f);
             in.get(f->freq, sizeof(double) * n);
             for (int l = 0; l < n; l++) m->locusName[l] = in.str();
-            HapData *h = new HapData{new short *[n](), nind, n, phased ? new bool *[n]() : nullptr};
+            HapData *h = new HapData{keepPacked ? nullptr : new short *[n](), nind, n, phased ? new bool *[n]() : nullptr,
+                                     keepPacked ? new unsigned char *[n]() : nullptr};
             (*haps)->push_back(h);
             for (int l = 0; l < n; l++) {
+                if (keepPacked) {   // the rows as stored: the engine uploads them 2-bit
+                    h->packed[l] = new unsigned char[row];
+                    in.get(h->packed[l], row);
+                    continue;
+                }
                 in.get(bits.data(), row);
                 short *d = h->data[l] = new short[nind];
                 for (int i = 0; i < nind; i++) d[i] = DECODE[(bits[i >> 2] >> (2 * (i & 3))) & 3];
@@ -868,6 +884,7 @@ void LodEngine::upload(std::vector<HapData *> *haps, std::vector<FreqData *> *fr
     // genotype rows are separate allocations in HapData: stage a slab of SNP rows at a time
     const int64_t slab = std::max<int64_t>(1, ((int64_t)64 << 20) / (2 * (int64_t)impl->nind));
     std::vector<int16_t> stage;
+    std::vector<uint8_t> stage2;
     std::vector<double> stage_gl;
     std::vector<uint8_t> stage_fc;
     impl->have_phase = true;
@@ -877,9 +894,15 @@ void LodEngine::upload(std::vector<HapData *> *haps, std::vector<FreqData *> *fr
         const HapData *h = haps->at(c);
         for (int l0 = 0; l0 < h->nloci; l0 += (int)slab) {
             const int rows = (int)std::min<int64_t>(slab, h->nloci - l0);
-            stage.resize((size_t)rows * impl->nind);
-            for (int r = 0; r < rows; r++)
-                memcpy(&stage[(size_t)r * impl->nind], h->data[l0 + r], sizeof(short) * impl->nind);
+            const size_t row_bytes = ((size_t)impl->nind + 3) / 4;
+            if (h->packed) {
+                stage2.resize((size_t)rows * row_bytes);
+                for (int r = 0; r < rows; r++) memcpy(&stage2[(size_t)r * row_bytes], h->packed[l0 + r], row_bytes);
+            } else {
+                stage.resize((size_t)rows * impl->nind);
+                for (int r = 0; r < rows; r++)
+                    memcpy(&stage[(size_t)r * impl->nind], h->data[l0 + r], sizeof(short) * impl->nind);
+            }
             if (USE_GL) {
                 stage_gl.resize((size_t)rows * impl->nind);
                 for (int r = 0; r < rows; r++)
@@ -892,8 +915,12 @@ void LodEngine::upload(std::vector<HapData *> *haps, std::vector<FreqData *> *fr
                         stage_fc[(size_t)r * impl->nind + i] = h->firstCopy[l0 + r][i];
             }
             for (auto &s : impl->shards) {
-                check(garlic_panel_set_genotypes(s.panel, stage.data() + s.ind_begin, impl->nind, o + l0, rows,
-                                                 GARLIC_HOST), "garlic_panel_set_genotypes");
+                if (h->packed)
+                    check(garlic_panel_set_genotypes_2bit(s.panel, stage2.data(), (int64_t)row_bytes, s.ind_begin, o + l0,
+                                                          rows, GARLIC_HOST), "garlic_panel_set_genotypes_2bit");
+                else
+                    check(garlic_panel_set_genotypes(s.panel, stage.data() + s.ind_begin, impl->nind, o + l0, rows,
+                                                     GARLIC_HOST), "garlic_panel_set_genotypes");
                 if (impl->have_phase)
                     check(garlic_panel_set_phase(s.panel, stage_fc.data() + s.ind_begin, impl->nind, o + l0, rows,
                                                  GARLIC_HOST), "garlic_panel_set_phase");

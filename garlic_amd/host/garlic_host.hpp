@@ -23,7 +23,17 @@ struct HapData {           // src/garlic-data.h:32-38
     int nind;
     int nloci;
     bool **firstCopy;      // --phased only (else NULL): the first allele of the pair is the counted one
+    // Extension: rows straight from the genotype cache, 4 genotypes per byte (0/1/2, 3 = missing),
+    // (nind + 3) / 4 bytes each; then `data` is NULL.  Everything in this adapter takes either form
+    // (genotypeAt reads one value); the engine uploads the packed rows as they are.
+    unsigned char **packed;
 };
+inline short genotypeAt(const HapData *h, int locus, int ind)
+{
+    if (h->data) return h->data[locus][ind];
+    const unsigned code = (h->packed[locus][ind >> 2] >> (2 * (ind & 3))) & 3u;
+    return code == 3u ? (short)-9 : (short)code;
+}
 struct MapData {           // src/garlic-data.h:51-60
     int *physicalPos;
     double *geneticPos;
@@ -151,7 +161,8 @@ void writeGenotypeCache(const std::string &path, std::vector<HapData *> *hapData
                         std::vector<MapData *> *mapDataByChr, std::vector<FreqData *> *freqDataByChr);
 void loadGenotypeCache(const std::string &path, int &numLoci, int &numInd,
                        std::vector<HapData *> **hapDataByChr, std::vector<MapData *> **mapDataByChr,
-                       std::vector<FreqData *> **freqDataByChr);
+                       std::vector<FreqData *> **freqDataByChr,
+                       bool keepPacked = false);   // keepPacked: HapData::packed instead of ::data
 
 // ---- the path (drop-in signatures)
 struct LodOptions {

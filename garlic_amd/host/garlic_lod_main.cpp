@@ -139,7 +139,7 @@ int main(int argc, char **argv)
         FILE *probe = a.cache == "none" ? nullptr : fopen(a.cache.c_str(), "rb");
         if (probe) {   // parsed before: load the 2-bit sidecar instead of the text
             fclose(probe);
-            loadGenotypeCache(a.cache, numLoci, numInd, &haps, &maps, &freqs);
+            loadGenotypeCache(a.cache, numLoci, numInd, &haps, &maps, &freqs, /*keepPacked=*/true);
             std::cerr << "Loaded genotype cache " << a.cache << "\n";
             if (a.phased && !haps->at(0)->firstCopy) {
                 std::cerr << "ERROR: --phased, but " << a.cache << " was written without phase; delete it to re-read the tped\n";

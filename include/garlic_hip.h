@@ -102,6 +102,15 @@ int garlic_panel_set_freq(garlic_panel *panel, const double *freq);
 int garlic_panel_set_genotypes(garlic_panel *panel, const int16_t *geno, int64_t ld,
                                int64_t locus_begin, int64_t locus_count, int32_t where);
 
+/* The same genotypes from SNP-major 2-bit rows -- what a genotype cache or a bed-like reader holds:
+ * 4 genotypes per byte, codes 0/1/2 = HapData::data values, 3 = missing (-9).  Row l - locus_begin
+ * starts at rows + (l - locus_begin) * row_bytes and holds the individuals of the WHOLE data set;
+ * this shard's individual i is number ind_offset + i of the row (byte / 4, bits 2 * (% 4)).
+ * An eighth of the host memory and PCIe traffic of the int16 rows; same device layout. */
+int garlic_panel_set_genotypes_2bit(garlic_panel *panel, const uint8_t *rows, int64_t row_bytes,
+                                    int64_t ind_offset, int64_t locus_begin, int64_t locus_count,
+                                    int32_t where);
+
 /* GenoLikeData::data (src/garlic-data.h:91): per-genotype error probabilities, already converted
  * as readTGLSData does (src/garlic-data.cpp:1557-1576); same addressing as genotypes. */
 int garlic_panel_set_gl(garlic_panel *panel, const double *gl, int64_t ld, int64_t locus_begin,

@@ -162,19 +162,20 @@ def test_sharded_run_equals_single_device(tmp_path):
 
 
 def test_genotype_cache_gives_identical_outputs(tmp_path):
-    """second run from the 2-bit sidecar (no TPED parse) writes byte-identical freq, raw-LOD and feed files"""
+    """runs from the 2-bit sidecar (no TPED parse; the rows go to the device as they are, 2 bits per
+    genotype, also when the individuals are sharded) write byte-identical freq, raw-LOD and feed files"""
     import filecmp
     cache = str(tmp_path / "tiny.g2b")
     outs = []
-    for k in range(2):
+    for k, devs in enumerate(("0", "0", "0,0,0")):
         d = tmp_path / f"c{k}"
         d.mkdir()
-        outs.append(run_tool(d, "--winsize", "30", "--raw-lod", "--genotype-cache", cache))
+        outs.append(run_tool(d, "--winsize", "30", "--raw-lod", "--genotype-cache", cache, "--devices", devs))
     names = sorted(os.path.basename(p)[len("mine"):] for p in glob.glob(outs[0] + "*"))
     assert len(names) >= 5
-    for n in names:
-        assert filecmp.cmp(outs[0] + n, outs[1] + n, shallow=False), n
-
+    for other in outs[1:]:
+        for n in names:
+            assert filecmp.cmp(outs[0] + n, other + n, shallow=False), n
 
 
 def test_genotype_cache_keeps_the_phase(tmp_path):

@@ -218,3 +218,37 @@ def test_random_configurations(gpu_ctx):
             bad = ol.count_mismatch(np.ascontiguousarray(out[c]), want)
             assert bad == 0, (trial, sizes, W, nind, i0, cnt, pa, c, bad)
         assert st["n_valid_windows"] + st["n_missing"] == sum(sizes)
+
+
+def pack2bit(geno):
+    """[nloci][nind] int16 (-9 missing) -> SNP-major 2-bit rows, 4 genotypes per byte"""
+    nloci, nind = geno.shape
+    code = np.where((geno >= 0) & (geno <= 2), geno, 3).astype(np.uint8)
+    pad = (-nind) % 4
+    code = np.concatenate([code, np.full((nloci, pad), 3, np.uint8)], axis=1).reshape(nloci, -1, 4)
+    return (code[:, :, 0] | (code[:, :, 1] << 2) | (code[:, :, 2] << 4) | (code[:, :, 3] << 6)).astype(np.uint8)
+
+
+@pytest.mark.parametrize("nind,lo", [(70, 0), (45, 13), (64, 64), (1, 6)])
+def test_genotypes_from_2bit_rows(gpu_ctx, nind, lo):
+    """garlic_panel_set_genotypes_2bit: a shard's individuals [lo, lo + nind) of 2-bit rows that hold
+    the whole data set, streamed in chunks -> the same scores as the int16 upload"""
+    rng = np.random.default_rng(100 * nind + lo)
+    total = lo + nind + 5
+    sizes = [700, 333]
+    W, mg = 25, 200000
+    chroms = [ol.random_panel(rng, n, total, max_gap=mg) for n in sizes]
+    geno = np.concatenate([c[0] for c in chroms], axis=0)
+    rows = pack2bit(geno)
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms])
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes_2bit(rows[:400], ind_offset=lo)
+        panel.set_genotypes_2bit(rows[400:], ind_offset=lo, locus_begin=400)
+        got = panel.lod_windows(W, 0.001, mg)
+        for c, (g, f, p, cs, ce) in enumerate(chroms):
+            want = ol.oracle_calc_lod(g[:, lo:lo + nind], f, p, cs, ce, W, 0.001, mg)
+            assert ol.bits_equal(got[c], want), c
+        with pytest.raises(abi.GarlicError):
+            panel.set_genotypes_2bit(rows[:, :(lo + nind + 3) // 4 - 1] if (lo + nind + 3) // 4 > 1 else rows[:, :0],
+                                     ind_offset=lo)
