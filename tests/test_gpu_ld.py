@@ -199,3 +199,15 @@ def test_phased_ld_sharded(gpu_ctx):
     for panel in parts:
         assert same(panel.ld_finish(W, loc, pair, phased=True), want)
         panel.close()
+
+
+@pytest.mark.parametrize("W", [63, 64, 65, 200, 256, 257])
+def test_ld_wide_windows_and_kernel_switch(gpu_ctx, W):
+    """the LDS-tiled ordered sums serve W <= 256 (one thread per column, 64 window starts per
+    workgroup: W around the wave size and the group size), the plain kernel everything wider"""
+    rng = np.random.default_rng(W)
+    nind = 24
+    sizes = [W + 70, W, W - 1, 2 * W + 3]
+    chroms = [ol.random_panel(rng, n, nind, max_gap=10 ** 9, gaps=0, miss=0.1) for n in sizes]
+    with make_panel(gpu_ctx, chroms, nind) as panel:
+        assert same(panel.compute_ld(W), oracle_ld(chroms, W))

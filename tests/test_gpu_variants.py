@@ -278,3 +278,22 @@ def test_lod_feed_thinned_write_out(gpu_ctx, W, step):
         got = panel.lod_windows(W, 0.001, mg)
         for c, (g, f, p, cs, ce) in enumerate(chroms):
             assert ol.bits_equal(got[c], ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg)), c
+
+
+@pytest.mark.parametrize("W,step,nind", [(2, 4, 64), (5, 31, 65), (33, 32, 1), (129, 5, 130), (1100, 64, 70)])
+def test_lod_feed_thinned_edge_shapes(gpu_ctx, W, step, nind):
+    """thinned write-out at the edges: windows narrower than a tile and than the step, a step of one
+    tile, a single individual, a window wider than the hand-scheduled loop's genotype ring (generic
+    tile path only)"""
+    rng = np.random.default_rng(7 * W + step)
+    mg = 200000
+    sizes = [3 * W + 700, 1, W + 40]
+    chroms = [ol.random_panel(rng, n, nind, max_gap=mg, gaps=2 if n > 500 else 0) for n in sizes]
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms])
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        feed, per_chr = panel.lod_feed(W, 0.001, mg, step)
+        want = [ol.oracle_flatten(ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg), step) for g, f, p, cs, ce in chroms]
+        assert [len(w) for w in want] == list(per_chr)
+        assert ol.bits_equal(feed, np.concatenate(want))
