@@ -111,63 +111,6 @@ ld_pair_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__
     pair[(i * W + d) * 2 + 1] = hab;
 }
 
-// The same counts with the planes of a tile of SNPs staged in LDS: ld_pair_kernel streams four plane
-// words per (pair, block) from L2 and is bound by that (30 % of the LD time at 10M SNPs x 1250).
-// One workgroup = LD_PAIR_T consecutive SNPs i and their W-1 partners each; the {M, H} words of the
-// SNPs i0 .. i0+T+W-2 are staged LD_PAIR_BLK blocks at a time, every thread keeps the counts of its
-// pairs (tid, tid + 256, ..) in registers across the chunks.
-constexpr int LD_PAIR_T = 64;
-constexpr int LD_PAIR_BLK = 8;
-constexpr int LD_PAIR_Q = 32;           // pairs per thread: T * (W - 1) <= 256 * Q  =>  W <= 129
-__global__ void __launch_bounds__(256)
-ld_pair_tiled_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__ planeH, int nblk,
-                     int64_t nloci, int64_t lo, int64_t hi, int W, int32_t *__restrict__ pair)
-{
-    extern __shared__ uint64_t ld_planes[];                    // [LD_PAIR_BLK][T + W - 1][2] = {M, H}
-    const int span = LD_PAIR_T + W - 1;
-    const int64_t i0 = lo + (int64_t)blockIdx.x * LD_PAIR_T;
-    const int ni = (int)min<int64_t>(LD_PAIR_T, hi - i0);      // SNPs i of this tile
-    const int nsnp = (int)min<int64_t>(span, hi - i0);         // staged SNPs that exist
-    const int npairs = ni * (W - 1);
-    int32_t tot[LD_PAIR_Q], hab[LD_PAIR_Q];
-#pragma unroll
-    for (int q = 0; q < LD_PAIR_Q; q++) { tot[q] = 0; hab[q] = 0; }
-    for (int b0 = 0; b0 < nblk; b0 += LD_PAIR_BLK) {
-        const int nb = min(LD_PAIR_BLK, nblk - b0);
-        __syncthreads();
-        for (int e = threadIdx.x; e < nb * nsnp; e += blockDim.x) {
-            const int b = e / nsnp, x = e - b * nsnp;
-            const int64_t g = (int64_t)(b0 + b) * nloci + i0 + x;
-            ld_planes[(b * span + x) * 2 + 0] = planeM[g];
-            ld_planes[(b * span + x) * 2 + 1] = planeH[g];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < LD_PAIR_Q; q++) {
-            const int p = threadIdx.x + q * 256;
-            if (p >= npairs) break;
-            const int il = p / (W - 1), jl = il + 1 + p % (W - 1);
-            if (jl >= nsnp) continue;                          // partner outside the chromosome: stays 0
-            int32_t t = 0, h = 0;
-            for (int b = 0; b < nb; b++) {
-                const uint64_t *a = ld_planes + (b * span + il) * 2, *c = ld_planes + (b * span + jl) * 2;
-                t += __popcll(a[0] & c[0]);
-                h += __popcll(a[1] & c[1]);
-            }
-            tot[q] += t;
-            hab[q] += h;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < LD_PAIR_Q; q++) {
-        const int p = threadIdx.x + q * 256;
-        if (p >= npairs) break;
-        const int il = p / (W - 1), d = 1 + p % (W - 1);
-        pair[((i0 + il) * W + d) * 2 + 0] = tot[q];
-        pair[((i0 + il) * W + d) * 2 + 1] = hab[q];
-    }
-}
-
 // --phased pair counts: pair = {2 * #(both non-missing), x11}  (r2, garlic-data.cpp:592-606)
 __global__ void __launch_bounds__(256)
 ld_pair_phased_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__ planeT,
