@@ -153,7 +153,9 @@ struct garlic_panel {
     DevBuf<double> d_tabgl;
     bool tabgl_valid = false;
     DevBuf<double> d_glterms;                      // TGLS term matrix [blk][GOFF+nloci+pad][64]
-    bool glterms_valid = false;
+    bool glterms_valid = false, glterms_scaled = false;   // scaled: holds (term * nomut) * norec of (glterms_M, glterms_mu)
+    int32_t glterms_M = 0;
+    double glterms_mu = 0.0;
 
     int tabgl_ncodes = 0;
     // wLOD
@@ -374,9 +376,12 @@ int ensure_gl_table(garlic_panel *p)
 // ---- TGLS pass 1: every (SNP, individual) term, once per panel (window-size independent).
 // Returns GARLIC_OK with glterms_valid unset when the matrix does not fit: the caller then keeps
 // the look-up-in-the-chain kernel.
-int ensure_gl_terms(garlic_panel *p)
+// TGLS term matrix; scaled = multiplied in place by the decay factors of (M, mu) for the weighted
+// tile kernel (ensure_decay_table first).  Switching between the two forms rebuilds / rescales.
+int ensure_gl_terms(garlic_panel *p, bool scaled = false, int32_t M = 0, double mu = 0.0)
 {
-    if (p->glterms_valid) return GARLIC_OK;
+    const bool same_scale = p->glterms_scaled && p->glterms_M == M && memcmp(&p->glterms_mu, &mu, sizeof mu) == 0;
+    if (p->glterms_valid && (scaled ? same_scale : !p->glterms_scaled)) return GARLIC_OK;
     if (getenv("GARLIC_GL_NO_TERMS")) return GARLIC_OK;
     const int64_t rows = GOFF + p->nloci + GPAD_BACK;
     const size_t n = (size_t)rows * p->nind_pad;
@@ -386,12 +391,24 @@ int ensure_gl_terms(garlic_panel *p)
     int rc;
     if ((rc = p->d_glterms.reserve(n))) return rc;
     hipStream_t s = p->ctx->stream;
-    HIP_TRY(hipMemsetAsync(p->d_glterms.p, 0, sizeof(double) * n, s));
-    VariantArgs a{p->d_packed.p, nullptr, p->d_tabgl.p, p->d_codes.p, nullptr, nullptr, nullptr, nullptr, nullptr,
-                  p->nind_pad, p->nwordrows, 0, 0, 0, (int32_t)p->gl_values.size(), 1};
-    hipLaunchKernelGGL(gl_terms_kernel, dim3((unsigned)((p->nloci + 63) / 64), (unsigned)(p->nind_pad / WAVE)),
-                       dim3(256), 0, s, a, p->nloci, rows, p->d_glterms.p);
-    HIP_TRY(hipGetLastError());
+    if (!p->glterms_valid || p->glterms_scaled) {   // (re)build the raw terms
+        p->glterms_valid = false;
+        HIP_TRY(hipMemsetAsync(p->d_glterms.p, 0, sizeof(double) * n, s));
+        VariantArgs a{p->d_packed.p, nullptr, p->d_tabgl.p, p->d_codes.p, nullptr, nullptr, nullptr, nullptr, nullptr,
+                      p->nind_pad, p->nwordrows, 0, 0, 0, (int32_t)p->gl_values.size(), 1};
+        hipLaunchKernelGGL(gl_terms_kernel, dim3((unsigned)((p->nloci + 63) / 64), (unsigned)(p->nind_pad / WAVE)),
+                           dim3(256), 0, s, a, p->nloci, rows, p->d_glterms.p);
+        HIP_TRY(hipGetLastError());
+        p->glterms_scaled = false;
+    }
+    if (scaled) {
+        hipLaunchKernelGGL(gl_scale_kernel, dim3(4096), dim3(256), 0, s, p->d_glterms.p, p->d_decay.p, rows,
+                           (int64_t)(p->nind_pad / WAVE));
+        HIP_TRY(hipGetLastError());
+        p->glterms_scaled = true;
+        p->glterms_M = M;
+        p->glterms_mu = mu;
+    }
     p->glterms_valid = true;
     return GARLIC_OK;
 }
@@ -489,8 +506,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // generic kernel
     const bool wlod_shape_ok = mode == MODE_WLOD && W >= WLOD_R && W + 64 <= GPAD_BACK &&
                                !getenv("GARLIC_WLOD_GENERIC");
-    if (wlod_shape_ok && use_gl && (rc = ensure_gl_terms(p))) return rc;
-    const bool wlod_gl = wlod_shape_ok && use_gl && p->glterms_valid;       // terms from the TGLS term matrix
+    if (wlod_shape_ok && use_gl && (rc = ensure_gl_terms(p, true, M, mu))) return rc;
+    const bool wlod_gl = wlod_shape_ok && use_gl && p->glterms_valid && p->glterms_scaled;   // scores from the term matrix
     bool wlod_fast = (wlod_shape_ok && !use_gl) || wlod_gl;                 // tile kernel, either variant
     if (wlod_fast && !wlod_gl && sizeof(double) * (size_t)(W + TILE) * 4 + 16 > 150 * 1024) wlod_fast = false;
     if (wlod_fast && !wlod_gl && (rc = ensure_score_rows(p, error, M, mu, W))) return rc;
@@ -609,7 +626,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         const int nquad = (nblk + WLOD_WAVES - 1) / WLOD_WAVES;
         WlodArgs a{p->d_valid.p, p->d_chrs.p, p->d_tiles.p, p->nwordrows, p->nchr, ind_begin, ind_count, W, nquad,
                    (uint32_t)((int64_t)p->plan.n_tiles * nquad), wlod_use_patch ? 1 : 0,
-                   (int64_t)(GOFF + p->nloci + GPAD_BACK), p->d_decay.p};
+                   (int64_t)(GOFF + p->nloci + GPAD_BACK)};
         const uint32_t *a_packed = p->d_packed.p;
         const double *a_wtab = wlod_gl ? p->d_glterms.p : p->d_wtab.p, *a_skew = p->d_skew.p + SKEW_FRONT;
         const unsigned wl_grid = (a.n_work + 7u) / 8u * 8u;
@@ -667,7 +684,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         VariantArgs a{p->d_packed.p, p->d_tab.p,  p->d_tabgl.p, p->d_codes.p, p->d_decay.p, p->d_rld.p,
                       p->d_items.p,  p->d_chrs.p, d_out,        p->nind_pad,  p->nwordrows, ind_begin,    ind_count,
                       W,             (int32_t)p->gl_values.size(), use_gl ? 1 : 0};
-        if (mode == MODE_LOD_GL && p->glterms_valid) {
+        if (mode == MODE_LOD_GL && p->glterms_valid && !p->glterms_scaled) {
             hipLaunchKernelGGL(lod_chain_terms_kernel, dim3((unsigned)n_items), dim3(2 * WAVE), 0, ctx->stream, a,
                                (int)n_items, (int64_t)(GOFF + p->nloci + GPAD_BACK), p->d_glterms.p);
         } else if (mode == MODE_LOD_GL) {

@@ -170,6 +170,19 @@ gl_terms_kernel(VariantArgs p, int64_t nloci, int64_t rows, double *__restrict__
     }
 }
 
+// wLOD with per-genotype likelihoods reads scores, (term * nomut) * norec (garlic-roh.cpp:249), from
+// the same matrix: scaled in place (and rebuilt by gl_terms_kernel when the unweighted TGLS chain
+// needs the raw terms again -- a session normally uses one of the two).  decay: [rows][2].
+__global__ void __launch_bounds__(256)
+gl_scale_kernel(double *__restrict__ terms, const double *__restrict__ decay, int64_t rows, int64_t nblk)
+{
+    const int64_t n = rows * nblk * WAVE;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t G = (i / WAVE) % rows;
+        terms[i] = (terms[i] * decay[2 * G]) * decay[2 * G + 1];
+    }
+}
+
 // The chain of lod_chain_gl_kernel with its 64 terms per tile read straight from the term matrix
 // (one round of coalesced 512-B loads per tile).  All work items are resident at once, so the
 // kernel lasts as long as the longest run needs for its tiles one after the other; that path is
@@ -344,7 +357,6 @@ struct WlodArgs {
     uint32_t n_work;           // tiles x nquad
     int32_t use_patch;         // transposed write-out through the LDS patch (allocated then)
     int64_t score_rows;        // FROM_SCORES: SNP rows per 64-individual block of the term matrix
-    const double *decay;       // FROM_SCORES: [GOFF + nloci + pad][2] = {nomut, norec}
 };
 
 // Ordered sums of windows s .. s+15 for this lane's individual: acc[r] = sum_j sc[s+r+j] * D[s+r+j][j],
@@ -386,20 +398,19 @@ __device__ __forceinline__ void wlod_group(const double *rows, const uint32_t *g
 typedef const __attribute__((address_space(4))) double *const_f64_ptr;
 
 template <int R>
-__device__ __forceinline__ void wlod_group_scores(const double *tcol, const double *decay, int64_t G,
-                                                  const double *Ds, int W, double (&acc)[R])
+__device__ __forceinline__ void wlod_group_scores(const double *tcol, int64_t G, const double *Ds, int W,
+                                                  double (&acc)[R])
 {
-    // weights and decay factors through the constant address space: they never change during the
-    // kernel, and only then does the compiler keep their wave-uniform loads on the scalar path
+    // weights through the constant address space: they never change during the kernel, and only
+    // then does the compiler keep their wave-uniform loads on the scalar path
     const const_f64_ptr Dg = (const_f64_ptr)(uintptr_t)Ds;
-    const const_f64_ptr dec = (const_f64_ptr)(uintptr_t)(decay + 2 * G);     // {nomut, norec} per SNP
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = 0.0;
     const double *tp = tcol + G * WAVE;
-    // score of SNP s+i: (lod * nomut) * norec, in that order (garlic-roh.cpp:249)
-    // (a separate score matrix is 0.9 ms faster at 200k x 1000 but doubles the 8 B per genotype
-    // of the term matrix; the two factors as vector loads were measured slower than as scalar loads)
-    auto score = [&](int i) -> double { return (tp[i * WAVE] * dec[2 * i]) * dec[2 * i + 1]; };
+    // score of SNP s+i = (lod * nomut) * norec (garlic-roh.cpp:249): the term matrix has been scaled
+    // in place by gl_scale_kernel (scaling on the fly from two scalar loads per SNP was 30 % slower,
+    // a second matrix of scores costs another 8 B per genotype)
+    auto score = [&](int i) -> double { return tp[i * WAVE]; };
     double up[R - 1];
 #pragma unroll
     for (int i = 0; i < R - 1; i++) up[i] = score(i);
@@ -489,7 +500,7 @@ wlod_tile_body(const uint32_t *__restrict__ packed,
         const uint32_t gm = (vm >> (grp * R)) & ((1u << R) - 1u);
         if (gm != 0) {
             if (FROM_SCORES)
-                wlod_group_scores<R>(wtab + ((col >> 6) * p.score_rows) * WAVE + (col & 63), p.decay, G0 + grp * R,
+                wlod_group_scores<R>(wtab + ((col >> 6) * p.score_rows) * WAVE + (col & 63), G0 + grp * R,
                                      D + (c.loc_base + s0 + grp * R) * (int64_t)W, W, acc);
             else
                 wlod_group<R>(rows + grp * R * 4, gcol, G0 + grp * R,

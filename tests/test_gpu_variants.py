@@ -158,6 +158,18 @@ def test_wlod_tile_kernel_shapes(gpu_ctx, W):
             out = panel.wlod_windows(W, 0.001, mg, 7, 1e-9, pitch_align=pa, ind_begin=i0, ind_count=cnt, use_gl=True)
             for c in range(len(sizes)):
                 assert ol.bits_equal(np.ascontiguousarray(out[c]), want[c][i0:i0 + cnt]), ("gl", pa, i0, c)
+        # the weighted kernel scaled the term matrix in place: the unweighted TGLS chain gets the raw
+        # terms back, other decay parameters rescale from them, and the first form comes back too
+        tg = panel.lod_windows(W, 0.001, mg, use_gl=True, pitch_align=32)
+        for c, (g, f, p, cs, ce) in enumerate(chroms):
+            assert ol.bits_equal(np.ascontiguousarray(tg[c]), ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg, gl=err[c])), c
+        out = panel.wlod_windows(W, 0.001, mg, 3, 2e-9, pitch_align=32, use_gl=True)
+        for c, (g, f, p, cs, ce) in enumerate(chroms):
+            w2 = ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, 0.001, mg, 2e-9, 3, gl=err[c])
+            assert ol.bits_equal(np.ascontiguousarray(out[c]), w2), ("gl, other decay", c)
+        out = panel.wlod_windows(W, 0.001, mg, 7, 1e-9, pitch_align=32, use_gl=True)
+        for c in range(len(sizes)):
+            assert ol.bits_equal(np.ascontiguousarray(out[c]), want[c]), ("gl again", c)
 
 
 def test_kde_feed_flatten_on_device(gpu_ctx):
