@@ -1210,13 +1210,12 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
         hipLaunchKernelGGL(ld_planes_kernel<false>, dim3((unsigned)p->nwordrows), dim3(256), 0, s, p->d_packed.p,
                            p->nwordrows, nblk, d_sub.p, p->nloci, d_m.p, d_h.p, (uint64_t *)nullptr, loc);
     for (int c = 0; c < p->nchr; c++) {
-        const unsigned pair_blocks = (unsigned)(((int64_t)p->chr_nloci[c] * (winsize - 1) + 255) / 256);
         if (phased)
-            hipLaunchKernelGGL(ld_pair_phased_kernel, dim3(pair_blocks), dim3(256), 0, s, d_m.p,
+            hipLaunchKernelGGL(ld_pair_phased_kernel, dim3((unsigned)p->chr_nloci[c]), dim3(256), 0, s, d_m.p,
                                d_h.p, d_o.p, p->d_phase.p, nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1],
                                winsize, pair);
         else
-            hipLaunchKernelGGL(ld_pair_kernel, dim3(pair_blocks), dim3(256), 0, s, d_m.p, d_h.p,
+            hipLaunchKernelGGL(ld_pair_kernel, dim3((unsigned)p->chr_nloci[c]), dim3(256), 0, s, d_m.p, d_h.p,
                                nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1], winsize, pair);
     }
     e = hipGetLastError();

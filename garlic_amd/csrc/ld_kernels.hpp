@@ -88,27 +88,26 @@ ld_planes_kernel(const uint32_t *__restrict__ packed, int64_t nwordrows, int nbl
 }
 
 // pair[(i * W + d) * 2 + {0,1}] = {total, HAB} of SNPs (i, i+d), d = 1 .. W-1, both inside the
-// chromosome [lo, hi); d = 0 and pairs leaving the chromosome stay 0.  One thread per pair, pairs of
-// one SNP i consecutive: its plane words are broadcast, those of i+d consecutive.
+// chromosome [lo, hi); d = 0 and pairs leaving the chromosome stay 0.  One workgroup per SNP i,
+// threads over d: plane words of i are broadcast, those of i+d consecutive.
 __global__ void __launch_bounds__(256)
 ld_pair_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__ planeH, int nblk,
                int64_t nloci, int64_t lo, int64_t hi, int W, int32_t *__restrict__ pair)
 {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t i = lo + p / (W - 1);
-    if (i >= hi) return;
-    const int d = 1 + (int)(p % (W - 1));
-    const int64_t j = i + d;
-    int32_t tot = 0, hab = 0;
-    if (j < hi) {
-        for (int blk = 0; blk < nblk; blk++) {
-            const int64_t base = (int64_t)blk * nloci;
-            tot += __popcll(planeM[base + i] & planeM[base + j]);
-            hab += __popcll(planeH[base + i] & planeH[base + j]);
+    const int64_t i = lo + blockIdx.x;
+    for (int d = 1 + threadIdx.x; d < W; d += blockDim.x) {
+        const int64_t j = i + d;
+        int32_t tot = 0, hab = 0;
+        if (j < hi) {
+            for (int blk = 0; blk < nblk; blk++) {
+                const int64_t base = (int64_t)blk * nloci;
+                tot += __popcll(planeM[base + i] & planeM[base + j]);
+                hab += __popcll(planeH[base + i] & planeH[base + j]);
+            }
         }
+        pair[(i * W + d) * 2 + 0] = tot;
+        pair[(i * W + d) * 2 + 1] = hab;
     }
-    pair[(i * W + d) * 2 + 0] = tot;
-    pair[(i * W + d) * 2 + 1] = hab;
 }
 
 // --phased pair counts: pair = {2 * #(both non-missing), x11}  (r2, garlic-data.cpp:592-606)
@@ -117,24 +116,23 @@ ld_pair_phased_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__res
                       const uint64_t *__restrict__ planeO, const uint64_t *__restrict__ planeF, int nblk,
                       int64_t nloci, int64_t lo, int64_t hi, int W, int32_t *__restrict__ pair)
 {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t i = lo + p / (W - 1);
-    if (i >= hi) return;
-    const int d = 1 + (int)(p % (W - 1));
-    const int64_t j = i + d;
-    int32_t tot = 0, x11 = 0;
-    if (j < hi) {
-        for (int blk = 0; blk < nblk; blk++) {
-            const int64_t base = (int64_t)blk * nloci;
-            const uint64_t ti = planeT[base + i], tj = planeT[base + j];
-            const uint64_t oi = planeO[base + i], oj = planeO[base + j];
-            tot += 2 * __popcll(planeM[base + i] & planeM[base + j]);
-            x11 += 2 * __popcll(ti & tj) + __popcll(oi & tj) + __popcll(ti & oj) +
-                   __popcll(oi & oj & ~(planeF[base + i] ^ planeF[base + j]));
+    const int64_t i = lo + blockIdx.x;
+    for (int d = 1 + threadIdx.x; d < W; d += blockDim.x) {
+        const int64_t j = i + d;
+        int32_t tot = 0, x11 = 0;
+        if (j < hi) {
+            for (int blk = 0; blk < nblk; blk++) {
+                const int64_t base = (int64_t)blk * nloci;
+                const uint64_t ti = planeT[base + i], tj = planeT[base + j];
+                const uint64_t oi = planeO[base + i], oj = planeO[base + j];
+                tot += 2 * __popcll(planeM[base + i] & planeM[base + j]);
+                x11 += 2 * __popcll(ti & tj) + __popcll(oi & tj) + __popcll(ti & oj) +
+                       __popcll(oi & oj & ~(planeF[base + i] ^ planeF[base + j]));
+            }
         }
+        pair[(i * W + d) * 2 + 0] = tot;
+        pair[(i * W + d) * 2 + 1] = x11;
     }
-    pair[(i * W + d) * 2 + 0] = tot;
-    pair[(i * W + d) * 2 + 1] = x11;
 }
 
 // HapData::firstCopy rows (uint8 [count][ld], loci [l0, l0 + count)) -> bit planes [blk][nloci];
