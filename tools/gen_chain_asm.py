@@ -101,7 +101,7 @@ TPITCH_B = 34 * 8
 LDS_TOTAL = TILE_BASE + NTILE * TILE_BUF
 
 # ---- fixed VGPRs (clobbered by the block; each wave has its own register file)
-# Every role is a different wave with its own register file, so the three roles reuse one compact
+# Every role is a different wave with its own register file, so the four roles reuse one compact
 # range v64..v185: the kernel's register count decides how many workgroups fit a CU.
 V_BUF = [64, 96]            # CHAIN: two term buffers, 8 x {t_out, t_in} each
 V_ADDR = 128                # CHAIN: 8 LDS byte offsets
