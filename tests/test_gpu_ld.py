@@ -211,3 +211,18 @@ def test_ld_wide_windows_and_kernel_switch(gpu_ctx, W):
     chroms = [ol.random_panel(rng, n, nind, max_gap=10 ** 9, gaps=0, miss=0.1) for n in sizes]
     with make_panel(gpu_ctx, chroms, nind) as panel:
         assert same(panel.compute_ld(W), oracle_ld(chroms, W))
+
+
+def test_phased_ld_golden_from_the_reference_build(gpu_ctx):
+    """tests/golden/phased_ld.npz holds calcR2LD's own output (tools/make_golden.py, real reference build)"""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "phased_ld.npz"))
+    n, nind = d["geno"].shape
+    with abi.Panel(gpu_ctx, [n], nind) as panel:
+        panel.set_map(np.arange(1, n + 1, dtype=np.int32) * 1000, [0], [0])
+        panel.set_freq(d["freq"])
+        panel.set_genotypes(d["geno"])
+        panel.set_phase(d["first_copy"])
+        for W in (10, 30):
+            assert same(panel.compute_ld(W, phased=True), d[f"ld_W{W}"]), W
+            assert same(panel.compute_ld(W, sub_idx=d["sub"], phased=True), d[f"ldsub_W{W}"]), W

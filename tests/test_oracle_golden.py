@@ -110,6 +110,16 @@ def test_wlod_and_ld():
             assert ol.bits_equal(got, d[f"win_W{W}"]), (W, threads)
 
 
+def test_phased_ld():
+    """--phased LD weights (calcR2LD / r2): oracle == what the reference build produced"""
+    d = load("phased_ld.npz")
+    for W in (10, 30):
+        for key, idx in ((f"ld_W{W}", None), (f"ldsub_W{W}", d["sub"])):
+            mine = ol.oracle_r2_ld(d["geno"], d["first_copy"], d["freq"], W, idx=idx)
+            nan = np.isnan(d[key])
+            assert np.array_equal(nan, np.isnan(mine)) and ol.bits_equal(d[key][~nan], mine[~nan]), key
+
+
 def test_flatten():
     d = load("flatten.npz")
     for step in (1, 30):

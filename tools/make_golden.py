@@ -142,6 +142,23 @@ def wlod():
     return n
 
 
+def phased_ld():
+    """--phased LD weights (calcR2LD / r2, garlic-data.cpp:426-535, 585-617) of the real reference,
+    all individuals and an --ld-subsample index"""
+    rng = np.random.default_rng(20260108)
+    g, f, p, cs, ce = ol.random_panel(rng, 500, 14, max_gap=MAX_GAP, gaps=0, mono=0.02, miss=0.06)
+    fc = rng.integers(0, 2, size=g.shape).astype(np.uint8)
+    sub = np.sort(rng.choice(14, size=6, replace=False)).astype(np.int32)
+    data = dict(geno=g, freq=f, first_copy=fc, sub=sub)
+    n = 0
+    for W in (10, 30):
+        data[f"ld_W{W}"] = ol.ref_r2_ld(g, fc, f, W, threads=2)
+        data[f"ldsub_W{W}"] = ol.ref_r2_ld(g, fc, f, W, idx=sub, threads=3)
+        n += 2 * data[f"ld_W{W}"].size
+    np.savez_compressed(os.path.join(OUT, "phased_ld.npz"), **data)
+    return n
+
+
 def flatten():
     d = np.load(os.path.join(OUT, "unweighted.npz"))
     win = d["win0_W30"].copy()
@@ -166,6 +183,7 @@ def main():
             "tgls_lod.npz": tgls_lod(),
             "wlod.npz": wlod(),
             "flatten.npz": flatten(),
+            "phased_ld.npz": phased_ld(),
         },
     }
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as fh:
