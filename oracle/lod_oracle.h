@@ -9,10 +9,12 @@
  * reference sources compiled into oracle/_ref/libgarlic_ref.so (tests/test_oracle_vs_ref.py,
  * build container only) and against fixtures generated from that build and committed
  * under tests/golden/ (tools/make_golden.py).
- * One exception: oracle_roh_coverage restates six lines in the middle of assembleROHWindows
- * (garlic-roh.cpp:446-454), which the reference does not expose as a function; it is integer
- * counting, cross-checked against a brute-force numpy loop (tests/test_oracle_golden.py), not
- * against the reference build -- parity UNPINNED for that one helper.
+ * oracle_roh_coverage restates six lines in the middle of assembleROHWindows (garlic-roh.cpp:446-454),
+ * which the reference does not expose as a function; it is pinned through what those counts feed:
+ * tests/test_oracle_vs_ref.py derives the ROH segments from them (second half of that function,
+ * restated in the test) and compares with the segments the real assembleROHWindows reports, for
+ * overlap thresholds from one SNP to the whole window; a brute-force numpy loop checks it everywhere
+ * else (tests/test_oracle_golden.py).
  *
  * All arrays are flat, row-major:
  *   genotypes  int16  [nloci][nind]   (reference HapData::data, garlic-data.h:35)

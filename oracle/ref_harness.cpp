@@ -16,6 +16,7 @@
 //   calcwLOD       garlic-roh.cpp:144   (+ parallelwLOD :204)
 //   calcHR2LD      garlic-data.cpp:377  (explicit individual index, no RNG)
 //   calcR2LD       garlic-data.cpp:426  (--phased; same)
+//   assembleROHWindows garlic-roh.cpp:409 (pins the coverage counts through the ROH segments they give)
 //   calculateGenoFreq garlic-data.cpp:656
 //   readTGLSData   garlic-data.cpp:1516 (GQ/GL/PL -> error probability)
 //   convertWinData2DoubleData garlic-data.cpp:2026
@@ -249,6 +250,42 @@ REF_API int ref_calcR2LD(int nloci, int nind, const short *genotypes, const unsi
         free_hap(hap);
     } catch (...) { return 1; }
     return 0;
+}
+
+// assembleROHWindows (garlic-roh.cpp:409-545) on one chromosome: win = WinData::data [nind][nloci].
+// Returns the number of ROH segments written (individual, start, stop; at most cap), or -1.
+REF_API int ref_assembleROH(int nloci, int nind, const double *win, const int *pos, int cStart, int cEnd,
+                            int centro_known, double cutoff, int winsize, int max_gap, double overlap_frac,
+                            int cap, int *seg_ind, double *seg_start, double *seg_stop)
+{
+    StderrSilencer quiet;
+    try {
+        MapData *map = make_map(nloci, pos, NULL);
+        centromere *c = make_centromere(cStart, cEnd, centro_known != 0);
+        WinData *w = initWinData((unsigned)nind, (unsigned)nloci);
+        for (int i = 0; i < nind; i++) memcpy(w->data[i], win + (size_t)i * nloci, sizeof(double) * nloci);
+        IndData ind;
+        ind.pop = "POP";
+        ind.nind = nind;
+        ind.indID = new string[nind];
+        for (int i = 0; i < nind; i++) ind.indID[i] = "i";
+        vector<WinData *> wins; wins.push_back(w);
+        vector<MapData *> maps; maps.push_back(map);
+        ROHLength *len = NULL;
+        vector<ROHData *> *roh = assembleROHWindows(&wins, &maps, &ind, c, cutoff, &len, winsize, max_gap,
+                                                    overlap_frac, false);
+        int n = 0;
+        for (int i = 0; i < nind; i++)
+            for (size_t k = 0; k < roh->at(i)->start.size(); k++, n++)
+                if (n < cap) { seg_ind[n] = i; seg_start[n] = roh->at(i)->start[k]; seg_stop[n] = roh->at(i)->stop[k]; }
+        releaseROHData(roh);
+        releaseROHLength(len);
+        delete [] ind.indID;
+        releaseWinData(w);
+        delete c;
+        free_map(map);
+        return n;
+    } catch (...) { return -1; }
 }
 
 // Runs the reference's TGLS reader on a text file we are given; returns error probabilities

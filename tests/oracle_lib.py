@@ -103,6 +103,9 @@ def ref():
                                      C.c_double, C.c_int, C.c_int, _dp]
         lib.ref_calcHR2LD.restype = C.c_int
         lib.ref_calcHR2LD.argtypes = [C.c_int, C.c_int, _sp, C.c_int, C.c_int, _ip, C.c_int, _dp, _dp]
+        lib.ref_assembleROH.restype = C.c_int
+        lib.ref_assembleROH.argtypes = [C.c_int, C.c_int, _dp, _ip, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                        C.c_int, C.c_double, C.c_int, _ip, _dp, _dp]
         lib.ref_calcR2LD.restype = C.c_int
         lib.ref_calcR2LD.argtypes = [C.c_int, C.c_int, _sp, _bp, _dp, C.c_int, C.c_int, _ip, C.c_int, _dp]
         lib.ref_readTGLS.restype = C.c_int
@@ -259,6 +262,21 @@ def ref_r2_ld(geno, first_copy, freq, W, idx=None, threads=1):
                             _p(idx, _ip), idx.shape[0], _p(ld, _dp))
     assert rc == 0
     return ld
+
+
+def ref_assemble_roh(win, pos, cS, cE, cutoff, W, max_gap, overlap_frac, centro_known=True):
+    """the reference's assembleROHWindows on one chromosome -> list of (individual, start, stop)"""
+    win = np.ascontiguousarray(win, dtype=np.float64)
+    pos = np.ascontiguousarray(pos, dtype=np.int32)
+    nind, nloci = win.shape
+    cap = nind * nloci
+    ind = np.empty(cap, dtype=np.int32)
+    a = np.empty(cap, dtype=np.float64)
+    b = np.empty(cap, dtype=np.float64)
+    n = ref().ref_assembleROH(nloci, nind, _p(win, _dp), _p(pos, _ip), cS, cE, int(centro_known), cutoff, W, max_gap,
+                              overlap_frac, cap, _p(ind, _ip), _p(a, _dp), _p(b, _dp))
+    assert 0 <= n <= cap
+    return [(int(ind[k]), float(a[k]), float(b[k])) for k in range(n)]
 
 
 def ref_flatten(win, step):

@@ -90,3 +90,54 @@ def test_phased_r2_ld():
         mine = ol.oracle_r2_ld(geno, fc, freq, W, idx=idx)
         nan = np.isnan(ld)
         assert np.array_equal(nan, np.isnan(mine)) and ol.bits_equal(ld[~nan], mine[~nan])
+
+
+def _segments_from_coverage(inwin, pos, cS, cE, W, max_gap, overlap_frac):
+    """second half of assembleROHWindows (garlic-roh.cpp:456-533), applied to coverage counts the
+    caller supplies -- only here, to pin those counts through the segments the reference reports"""
+    thr = overlap_frac * W
+    thr = thr if thr >= 1 else 1
+    thr = thr if thr <= W else W
+    out = []
+    n = len(pos)
+    start = start_idx = -1
+    for w in range(n):
+        hit = inwin[w] >= thr
+        if start < 0 and hit:
+            start, start_idx = int(pos[w]), w
+        elif hit and (int(pos[w]) - int(pos[w - 1]) > max_gap or ol.oracle().oracle_in_gap(int(pos[w - 1]), int(pos[w]), cS, cE)):
+            if (w - 1) - start_idx + 1 >= thr:
+                out.append((float(start), float(pos[w - 1])))
+            start, start_idx = int(pos[w]), w
+        elif start > 0 and not hit:
+            if (w - 1) - start_idx + 1 >= thr:
+                out.append((float(start), float(pos[w - 1])))
+            start = start_idx = -1
+        elif start > 0 and w + 1 >= n:
+            if w - start_idx + 1 >= thr:
+                out.append((float(start), float(pos[w])))
+            start = start_idx = -1
+    return out
+
+
+def test_roh_coverage_through_the_reference_segments():
+    """oracle_roh_coverage restates the inWin[] loop in the middle of assembleROHWindows
+    (garlic-roh.cpp:446-454), which the reference does not expose.  Pinned here through what it feeds:
+    coverage counts -> ROH segments (restated above) must equal the segments the real
+    assembleROHWindows reports, for thresholds from 1 SNP to the whole window."""
+    rng = np.random.default_rng(77)
+    checked = 0
+    for _ in range(12):
+        nloci, nind, W = int(rng.integers(60, 400)), int(rng.integers(1, 6)), int(rng.integers(2, 25))
+        geno, freq, pos, cS, cE = ol.random_panel(rng, nloci, nind)
+        mg = 200000
+        win = ol.oracle_calc_lod(geno, freq, pos, cS, cE, W, 0.001, mg)
+        cutoff = float(np.quantile(win[win != ol.MISSING], rng.uniform(0.3, 0.8))) if (win != ol.MISSING).any() else 0.0
+        cov = ol.oracle_roh_coverage(win, W, cutoff)
+        for frac in (1e-9, 0.25, 0.5, 0.77, 1.0):
+            ref = ol.ref_assemble_roh(win, pos, cS, cE, cutoff, W, mg, frac)
+            mine = [(i, a, b) for i in range(nind)
+                    for a, b in _segments_from_coverage(cov[i], pos, cS, cE, W, mg, frac)]
+            assert mine == ref, (nloci, nind, W, frac)
+            checked += len(ref)
+    assert checked > 200
