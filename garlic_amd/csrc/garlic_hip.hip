@@ -1028,40 +1028,74 @@ int garlic_panel_set_gl(garlic_panel *p, const double *gl, int64_t ld, int64_t l
         if ((rc = p->d_codes.reserve((size_t)(rows_total * p->nind_pad)))) return rc;
         HIP_TRY(hipMemsetAsync(p->d_codes.p, 0, (size_t)(rows_total * p->nind_pad), s));
     }
-    // distinct error probabilities -> one-byte codes (the term table needs the host libm)
-    std::vector<double> host;
-    const double *src = gl;
-    if (where == GARLIC_DEVICE) {
-        host.resize((size_t)(locus_count * ld));
-        HIP_TRY(hipMemcpyAsync(host.data(), gl, sizeof(double) * host.size(), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        src = host.data();
-    }
-    std::vector<uint8_t> codes((size_t)(locus_count * p->nind_pad), 0);
-    for (int64_t l = 0; l < locus_count; l++)
-        for (int i = 0; i < p->nind; i++) {
-            uint64_t bits;
-            memcpy(&bits, &src[l * ld + i], sizeof bits);
-            auto it = p->gl_code.find(bits);
-            int code;
-            if (it == p->gl_code.end()) {
-                code = (int)p->gl_values.size();
-                if (code > 255)
-                    return fail(GARLIC_ERR_INVALID,
-                                "more than 256 distinct genotype-likelihood values: the dictionary "
-                                "TGLS path of this build needs quantised inputs (GQ / PL integers)");
-                p->gl_code.emplace(bits, code);
-                p->gl_values.push_back(src[l * ld + i]);
-                p->tabgl_valid = false;
-            } else code = it->second;
-            codes[(size_t)(l * p->nind_pad + i)] = (uint8_t)code;
+    // distinct error probabilities -> one-byte codes (the term table needs the host libm).  Coded on
+    // the device against the dictionary so far; values it does not know come back, join the
+    // dictionary and the slab is coded again (a hash look-up per genotype on the host took minutes
+    // at 1e10 genotypes).
+    constexpr int UNK_CAP = 8192;
+    DevBuf<double> stage;
+    DevBuf<uint64_t> d_bits, d_unk;
+    DevBuf<uint8_t> d_dcode;
+    DevBuf<int32_t> d_nunk;
+    auto done = [&](int code) { stage.release(); d_bits.release(); d_unk.release(); d_dcode.release(); d_nunk.release(); return code; };
+    if ((rc = d_bits.reserve(GL_DICT_MAX)) || (rc = d_dcode.reserve(GL_DICT_MAX)) || (rc = d_unk.reserve(UNK_CAP)) ||
+        (rc = d_nunk.reserve(1)))
+        return done(rc);
+    const int64_t slab_rows = (where == GARLIC_HOST) ? std::max<int64_t>(16, ((int64_t)256 << 20) / (8 * ld)) : locus_count;
+    std::vector<uint64_t> unk(UNK_CAP);
+    for (int64_t at = 0; at < locus_count; at += slab_rows) {
+        const int64_t nrows = std::min(slab_rows, locus_count - at);
+        const double *src = gl + at * ld;
+        hipError_t e = hipSuccess;
+        if (where == GARLIC_HOST) {
+            if ((rc = stage.reserve((size_t)(nrows * ld)))) return done(rc);
+            e = hipMemcpyAsync(stage.p, src, sizeof(double) * nrows * ld, hipMemcpyHostToDevice, s);
+            src = stage.p;
         }
-    HIP_TRY(hipMemcpyAsync(p->d_codes.p + (GOFF + locus_begin) * p->nind_pad, codes.data(), codes.size(),
-                           hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
+        while (e == hipSuccess) {   // until the slab holds no value outside the dictionary
+            // dictionary, sorted by bit pattern
+            std::vector<std::pair<uint64_t, uint8_t>> dict;
+            for (auto &kv : p->gl_code) dict.emplace_back(kv.first, (uint8_t)kv.second);
+            std::sort(dict.begin(), dict.end());
+            std::vector<uint64_t> hb(dict.size());
+            std::vector<uint8_t> hc(dict.size());
+            for (size_t k = 0; k < dict.size(); k++) { hb[k] = dict[k].first; hc[k] = dict[k].second; }
+            if (!dict.empty()) {
+                e = hipMemcpyAsync(d_bits.p, hb.data(), sizeof(uint64_t) * hb.size(), hipMemcpyHostToDevice, s);
+                if (e == hipSuccess) e = hipMemcpyAsync(d_dcode.p, hc.data(), hc.size(), hipMemcpyHostToDevice, s);
+            }
+            if (e == hipSuccess) e = hipMemsetAsync(d_nunk.p, 0, sizeof(int32_t), s);
+            if (e != hipSuccess) break;
+            hipLaunchKernelGGL(gl_encode_kernel, dim3(2048), dim3(256), 0, s, src, ld, nrows, p->nind, p->nind_pad, d_bits.p,
+                               d_dcode.p, (int)dict.size(), p->d_codes.p + (GOFF + locus_begin + at) * p->nind_pad,
+                               d_unk.p, d_nunk.p, UNK_CAP);
+            int32_t nunk = 0;
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(&nunk, d_nunk.p, sizeof nunk, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);          // also: hb / hc / the staging slab are free again
+            if (e != hipSuccess || nunk == 0) break;
+            const int got = std::min<int32_t>(nunk, UNK_CAP);
+            e = hipMemcpy(unk.data(), d_unk.p, sizeof(uint64_t) * got, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) break;
+            for (int k = 0; k < got; k++) {
+                if (p->gl_code.count(unk[k])) continue;
+                const int code = (int)p->gl_values.size();
+                if (code >= GL_DICT_MAX)
+                    return done(fail(GARLIC_ERR_INVALID,
+                                     "more than 256 distinct genotype-likelihood values: the dictionary "
+                                     "TGLS path of this build needs quantised inputs (GQ / PL integers)"));
+                double v;
+                memcpy(&v, &unk[k], sizeof v);
+                p->gl_code.emplace(unk[k], code);
+                p->gl_values.push_back(v);
+                p->tabgl_valid = false;
+            }
+        }
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "set_gl: %s", hipGetErrorString(e)));
+    }
     p->have_gl = true;
     p->glterms_valid = false;
-    return GARLIC_OK;
+    return done(GARLIC_OK);
 }
 
 int garlic_panel_set_phase(garlic_panel *p, const uint8_t *first_copy, int64_t ld, int64_t locus_begin,

@@ -149,6 +149,39 @@ lod_chain_gl_kernel(VariantArgs p, int n_items)
 __device__ __forceinline__ void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); }
 __device__ __forceinline__ void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
+// ---- TGLS ingest: per-genotype error probabilities -> one-byte dictionary codes on the device.
+// dict_bits: the known values' bit patterns, sorted; dict_code: their codes.  A value that is not in
+// the dictionary is reported (up to cap of them) and the host extends the dictionary and runs the
+// rows again; after the first rows of a panel that practically never happens (GQ / PL integers).
+constexpr int GL_DICT_MAX = 256;
+__global__ void __launch_bounds__(256)
+gl_encode_kernel(const double *__restrict__ gl, int64_t ld, int64_t locus_count, int32_t nind, int64_t nind_pad,
+                 const uint64_t *__restrict__ dict_bits, const uint8_t *__restrict__ dict_code, int ndict,
+                 uint8_t *__restrict__ codes, uint64_t *__restrict__ unknown, int32_t *__restrict__ n_unknown, int cap)
+{
+    __shared__ uint64_t bits_s[GL_DICT_MAX];
+    __shared__ uint8_t code_s[GL_DICT_MAX];
+    for (int k = threadIdx.x; k < ndict; k += blockDim.x) { bits_s[k] = dict_bits[k]; code_s[k] = dict_code[k]; }
+    __syncthreads();
+    const int64_t n = locus_count * nind;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t l = e / nind;
+        const int i = (int)(e - l * nind);
+        const uint64_t b = reinterpret_cast<const uint64_t *>(gl)[l * ld + i];
+        int lo = 0, hi = ndict;                                 // first entry >= b
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (bits_s[mid] < b) lo = mid + 1; else hi = mid;
+        }
+        if (lo < ndict && bits_s[lo] == b) {
+            codes[l * nind_pad + i] = code_s[lo];
+        } else {
+            const int k = atomicAdd(n_unknown, 1);
+            if (k < cap) unknown[k] = b;
+        }
+    }
+}
+
 // ---- TGLS in two passes.  The term of (SNP, individual) does not depend on the window size, and
 // looking it up costs two dependent loads plus a gather that drags in 15 cache lines of the
 // ncodes x 32 B term row for 64 values.  Inside the sequential chain that latency is exposed three
