@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""One-off soak on the GPU box: many random panels through every variant of the path, each result
+against the CPU oracle bit for bit.  Not part of the test suite (minutes, not seconds):
+
+    python tools/soak.py [--trials 150] [--seed 1]
+
+Prints one line per failure and a summary; exit code 1 if anything differed."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def same(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    if a.shape != b.shape or not np.array_equal(np.isnan(a), np.isnan(b)):
+        return False
+    ok = ~np.isnan(a)
+    return np.array_equal(a[ok].view(np.uint64), b[ok].view(np.uint64))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    import oracle_lib as ol
+    from garlic_amd import abi
+
+    rng = np.random.default_rng(args.seed)
+    ctx = abi.Context(0)
+    fails, checks, t0 = 0, 0, time.time()
+    for trial in range(args.trials):
+        nchr = int(rng.integers(1, 4))
+        W = int(rng.choice([2, 5, 16, 17, 31, 32, 33, 64, 100, 130]))
+        sizes = [int(rng.choice([1, W - 1, W, W + 1, int(rng.integers(2 * W, 40 * W + 300))])) for _ in range(nchr)]
+        sizes = [max(1, n) for n in sizes]
+        nind = int(rng.choice([1, 63, 64, 65, int(rng.integers(2, 260))]))
+        mg = int(rng.choice([3000, 50000, 200000]))
+        chroms = [ol.random_panel(rng, n, nind, max_gap=mg, gaps=int(rng.integers(0, 5)) if n > 50 else 0,
+                                  miss=float(rng.choice([0.0, 0.03, 0.3]))) for n in sizes]
+        gpos = [np.cumsum(np.diff(c[2], prepend=0) * 1e-6 * rng.uniform(0.8, 1.2, size=c[2].shape[0])) for c in chroms]
+        err = float(rng.choice([1e-6, 0.001, 0.05]))
+        tag = (trial, sizes, W, nind, mg)
+        with abi.Panel(ctx, sizes, nind) as panel:
+            panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms],
+                          gpos=np.concatenate(gpos))
+            panel.set_freq(np.concatenate([c[1] for c in chroms]))
+            panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+            lod = [ol.oracle_calc_lod(g, f, p, cs, ce, W, err, mg) for g, f, p, cs, ce in chroms]
+            # full scores, aligned and dense layouts
+            for pa in (32, 1):
+                out = panel.lod_windows(W, err, mg, pitch_align=pa)
+                for c in range(nchr):
+                    checks += 1
+                    if not ol.bits_equal(np.ascontiguousarray(out[c]), lod[c]):
+                        fails += 1
+                        print("FAIL lod", pa, c, tag)
+            # thinned feed
+            step = int(rng.choice([1, 3, 4, W, 2 * W + 1, 32, 64]))
+            feed, per_chr = panel.lod_feed(W, err, mg, step)
+            want = [ol.oracle_flatten(x, step) for x in lod]
+            checks += 1
+            if [len(w) for w in want] != list(per_chr) or not ol.bits_equal(feed, np.concatenate(want) if want else feed):
+                fails += 1
+                print("FAIL feed", step, tag)
+            # LD weights, unphased and phased, with a subsample; wLOD from them
+            if W <= 64 and sum(sizes) <= 3000:
+                sub = None if rng.integers(0, 2) else np.sort(rng.choice(nind, size=int(rng.integers(1, nind + 1)), replace=False)).astype(np.int32)
+                ld = panel.compute_ld(W, sub_idx=sub)
+                want_ld = np.concatenate([ol.oracle_hr2_ld(c[0], W, idx=sub) for c in chroms], axis=0)
+                checks += 1
+                if not same(ld, want_ld):
+                    fails += 1
+                    print("FAIL hr2", tag)
+                phase = rng.integers(0, 2, size=(sum(sizes), nind)).astype(np.uint8)
+                panel.set_phase(phase)
+                r2 = panel.compute_ld(W, sub_idx=sub, phased=True)
+                o, parts = 0, []
+                for c in chroms:
+                    parts.append(ol.oracle_r2_ld(c[0], phase[o:o + c[0].shape[0]], c[1], W, idx=sub))
+                    o += c[0].shape[0]
+                checks += 1
+                if not same(r2, np.concatenate(parts, axis=0)):
+                    fails += 1
+                    print("FAIL r2", tag)
+            # wLOD (synthetic weights) and TGLS
+            lds = [rng.uniform(1.0, max(2.0, W / 4.0), size=(n, W)) for n in sizes]
+            panel.set_ld(W, np.concatenate(lds, axis=0))
+            out = panel.wlod_windows(W, err, mg, 7, 1e-9, pitch_align=32)
+            for c, (g, f, p, cs, ce) in enumerate(chroms):
+                checks += 1
+                if not ol.bits_equal(np.ascontiguousarray(out[c]), ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, err, mg, 1e-9, 7)):
+                    fails += 1
+                    print("FAIL wlod", c, tag)
+            gl = [rng.choice([1e-16, 1e-3, 0.01, 0.2, 1.0], size=c[0].shape) for c in chroms]
+            panel.set_gl(np.concatenate(gl, axis=0))
+            out = panel.lod_windows(W, err, mg, use_gl=True, pitch_align=32)
+            for c, (g, f, p, cs, ce) in enumerate(chroms):
+                checks += 1
+                if not ol.bits_equal(np.ascontiguousarray(out[c]), ol.oracle_calc_lod(g, f, p, cs, ce, W, err, mg, gl=gl[c])):
+                    fails += 1
+                    print("FAIL tgls", c, tag)
+            out = panel.wlod_windows(W, err, mg, 7, 1e-9, pitch_align=32, use_gl=True)
+            for c, (g, f, p, cs, ce) in enumerate(chroms):
+                checks += 1
+                if not ol.bits_equal(np.ascontiguousarray(out[c]), ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, err, mg, 1e-9, 7, gl=gl[c])):
+                    fails += 1
+                    print("FAIL wlod+gl", c, tag)
+        if trial % 10 == 9:
+            print(f"trial {trial + 1}: {checks} checks, {fails} failures, {time.time() - t0:.0f} s", flush=True)
+    print(f"soak: {args.trials} panels, {checks} checks, {fails} failures")
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
