@@ -21,7 +21,7 @@ SYMBOLS = [
     "garlic_hip_abi_version", "garlic_hip_last_error", "garlic_hip_device_count",
     "garlic_ctx_create", "garlic_ctx_destroy", "garlic_ctx_synchronize",
     "garlic_panel_create", "garlic_panel_destroy", "garlic_panel_set_map",
-    "garlic_panel_set_freq", "garlic_panel_set_genotypes", "garlic_panel_set_genotypes_2bit", "garlic_panel_set_gl",
+    "garlic_panel_set_freq", "garlic_panel_set_genotypes", "garlic_panel_set_genotypes_2bit", "garlic_panel_set_gl", "garlic_panel_set_gl_codes",
     "garlic_panel_set_phase",
     "garlic_panel_set_ld", "garlic_lod_out_layout", "garlic_lod_windows",
     "garlic_wlod_windows", "garlic_lod_flatten", "garlic_last_call_stats",
@@ -80,6 +80,7 @@ def lib():
     L.garlic_panel_set_genotypes.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
     L.garlic_panel_set_gl.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
     L.garlic_panel_release_scratch.argtypes = [_vp]
+    L.garlic_panel_set_gl_codes.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int32, C.c_int32]
     L.garlic_panel_set_genotypes_2bit.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
     L.garlic_panel_set_phase.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
     L.garlic_panel_set_ld.argtypes = [_vp, C.c_int32, _vp, C.c_int32]
@@ -215,6 +216,13 @@ class Panel:
         assert rows.ndim == 2
         check(lib().garlic_panel_set_genotypes_2bit(self.handle, _vp(rows.ctypes.data), rows.shape[1], ind_offset,
                                                     locus_begin, rows.shape[0], HOST))
+
+    def set_gl_codes(self, codes, values, locus_begin=0):
+        """codes: uint8 [nloci_chunk][nind] indexing values (float64, <= 256 error probabilities)"""
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        check(lib().garlic_panel_set_gl_codes(self.handle, _vp(codes.ctypes.data), codes.shape[1], locus_begin,
+                                              codes.shape[0], _vp(values.ctypes.data), values.shape[0], HOST))
 
     def release_scratch(self):
         """free the device scratch the panel keeps between calls (LD buffers, score / feed scratch)"""

@@ -1098,6 +1098,64 @@ int garlic_panel_set_gl(garlic_panel *p, const double *gl, int64_t ld, int64_t l
     return done(GARLIC_OK);
 }
 
+int garlic_panel_set_gl_codes(garlic_panel *p, const uint8_t *codes, int64_t ld, int64_t locus_begin,
+                              int64_t locus_count, const double *values, int32_t nvalues, int32_t where)
+{
+    if (!p || !codes || !values) return fail(GARLIC_ERR_INVALID, "panel, codes and values are required");
+    if (nvalues < 1 || nvalues > GL_DICT_MAX) return fail(GARLIC_ERR_INVALID, "nvalues must be 1..256 (got %d)", nvalues);
+    if (ld < p->nind) return fail(GARLIC_ERR_INVALID, "ld %lld < nind %d", (long long)ld, p->nind);
+    if (locus_begin < 0 || locus_count < 1 || locus_begin + locus_count > p->nloci)
+        return fail(GARLIC_ERR_INVALID, "locus range [%lld,+%lld) outside panel of %lld loci",
+                    (long long)locus_begin, (long long)locus_count, (long long)p->nloci);
+    int rc;
+    if ((rc = set_device(p->ctx))) return rc;
+    hipStream_t s = p->ctx->stream;
+    const int64_t rows_total = GOFF + p->nloci + GPAD_BACK;
+    if (!p->d_codes.p) {
+        if ((rc = p->d_codes.reserve((size_t)(rows_total * p->nind_pad)))) return rc;
+        HIP_TRY(hipMemsetAsync(p->d_codes.p, 0, (size_t)(rows_total * p->nind_pad), s));
+    }
+    // the caller's table joins the panel's dictionary; its codes are translated on the device
+    uint8_t remap[256] = {0};
+    for (int k = 0; k < nvalues; k++) {
+        uint64_t bits;
+        memcpy(&bits, &values[k], sizeof bits);
+        auto it = p->gl_code.find(bits);
+        if (it == p->gl_code.end()) {
+            const int code = (int)p->gl_values.size();
+            if (code >= GL_DICT_MAX)
+                return fail(GARLIC_ERR_INVALID, "more than 256 distinct genotype-likelihood values in one panel");
+            it = p->gl_code.emplace(bits, code).first;
+            p->gl_values.push_back(values[k]);
+            p->tabgl_valid = false;
+        }
+        remap[k] = (uint8_t)it->second;
+    }
+    DevBuf<uint8_t> stage, d_remap;
+    auto done = [&](int code) { stage.release(); d_remap.release(); return code; };
+    if ((rc = d_remap.reserve(256))) return done(rc);
+    hipError_t e = hipMemcpyAsync(d_remap.p, remap, 256, hipMemcpyHostToDevice, s);
+    const int64_t slab_rows = (where == GARLIC_HOST) ? std::max<int64_t>(16, ((int64_t)256 << 20) / ld) : locus_count;
+    for (int64_t at = 0; e == hipSuccess && at < locus_count; at += slab_rows) {
+        const int64_t nrows = std::min(slab_rows, locus_count - at);
+        const uint8_t *src = codes + at * ld;
+        if (where == GARLIC_HOST) {
+            if ((rc = stage.reserve((size_t)(nrows * ld)))) return done(rc);
+            e = hipMemcpyAsync(stage.p, src, (size_t)(nrows * ld), hipMemcpyHostToDevice, s);
+            src = stage.p;
+        }
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(gl_recode_kernel, dim3(2048), dim3(256), 0, s, src, ld, nrows, p->nind, p->nind_pad, d_remap.p,
+                           p->d_codes.p + (GOFF + locus_begin + at) * p->nind_pad);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s);                      // staging slab (and remap) free again
+    }
+    if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "set_gl_codes: %s", hipGetErrorString(e)));
+    p->have_gl = true;
+    p->glterms_valid = false;
+    return done(GARLIC_OK);
+}
+
 int garlic_panel_set_phase(garlic_panel *p, const uint8_t *first_copy, int64_t ld, int64_t locus_begin,
                            int64_t locus_count, int32_t where)
 {

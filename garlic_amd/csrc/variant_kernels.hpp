@@ -182,6 +182,23 @@ gl_encode_kernel(const double *__restrict__ gl, int64_t ld, int64_t locus_count,
     }
 }
 
+// Likelihoods that arrive dictionary-coded (garlic_panel_set_gl_codes): the caller's code -> the
+// panel's code.  rows: [locus_count][ld] bytes.
+__global__ void __launch_bounds__(256)
+gl_recode_kernel(const uint8_t *__restrict__ rows, int64_t ld, int64_t locus_count, int32_t nind, int64_t nind_pad,
+                 const uint8_t *__restrict__ remap, uint8_t *__restrict__ codes)
+{
+    __shared__ uint8_t map_s[256];
+    map_s[threadIdx.x] = remap[threadIdx.x];
+    __syncthreads();
+    const int64_t n = locus_count * nind;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t l = e / nind;
+        const int i = (int)(e - l * nind);
+        codes[l * nind_pad + i] = map_s[rows[l * ld + i]];
+    }
+}
+
 // ---- TGLS in two passes.  The term of (SNP, individual) does not depend on the window size, and
 // looking it up costs two dependent loads plus a gather that drags in 15 cache lines of the
 // ncodes x 32 B term row for 64 values.  Inside the sequential chain that latency is exposed three

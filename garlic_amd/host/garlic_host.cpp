@@ -217,6 +217,9 @@ GenoLikeData *initGLData(unsigned int nind, unsigned int nloci)
     d->nind = nind;
     d->nloci = nloci;
     d->data = new double *[nloci];
+    d->codes = nullptr;
+    d->values = nullptr;
+    d->nvalues = 0;
     for (unsigned l = 0; l < nloci; l++) {
         d->data[l] = new double[nind];
         std::fill(d->data[l], d->data[l] + nind, (double)MISSING);
@@ -226,8 +229,13 @@ GenoLikeData *initGLData(unsigned int nind, unsigned int nloci)
 void releaseGLData(GenoLikeData *d)
 {
     if (!d) return;
-    for (int l = 0; l < d->nloci; l++) delete[] d->data[l];
+    for (int l = 0; l < d->nloci; l++) {
+        if (d->data) delete[] d->data[l];
+        if (d->codes) delete[] d->codes[l];
+    }
     delete[] d->data;
+    delete[] d->codes;
+    delete[] d->values;
     delete d;
 }
 void releaseGLData(std::vector<GenoLikeData *> *v) { for (auto d : *v) releaseGLData(d); delete v; }
@@ -449,14 +457,19 @@ IndData *readIndData3(const std::string &filename, int numInd)
 }
 
 std::vector<GenoLikeData *> *readTGLSData(const std::string &filename, int /*expectedLoci*/, int expectedInd,
-                                          std::vector<MapData *> *maps, const std::string &GL_TYPE)
+                                          std::vector<MapData *> *maps, const std::string &GL_TYPE, bool compact)
 {
     if (GL_TYPE != "GQ" && GL_TYPE != "GL" && GL_TYPE != "PL") fail("Must choose GQ/GL/PL for genotype likelihood format");
     LineReader in(filename);
     auto *out = new std::vector<GenoLikeData *>;
     std::string line, junk;
     for (auto m : *maps) {
-        GenoLikeData *d = initGLData(expectedInd, m->nloci);
+        GenoLikeData *d;
+        if (compact) {   // one byte per genotype and a table of the distinct converted values
+            d = new GenoLikeData{nullptr, expectedInd, m->nloci, new unsigned char *[m->nloci](), new double[256], 0};
+        } else {
+            d = initGLData(expectedInd, m->nloci);
+        }
         out->push_back(d);
         for (int l = 0; l < m->nloci; l++) {
             if (!in.next(line)) fail("too few lines in " + filename);
@@ -473,7 +486,15 @@ std::vector<GenoLikeData *> *readTGLSData(const std::string &filename, int /*exp
                 else { gl /= (-10.0); gl = (gl > -10) ? gl : -10; gl = 1 - pow(10, gl); }
                 if (gl <= 0) gl = 0.0000000000000001;
                 if (gl > 1) gl = 1;
-                d->data[l][i] = gl;
+                if (!compact) { d->data[l][i] = gl; continue; }
+                if (i == 0) d->codes[l] = new unsigned char[expectedInd];
+                int code = 0;
+                while (code < d->nvalues && memcmp(&d->values[code], &gl, sizeof gl) != 0) code++;
+                if (code == d->nvalues) {
+                    if (code == 256) fail("more than 256 distinct genotype likelihood values on " + m->chr + " in " + filename);
+                    d->values[d->nvalues++] = gl;
+                }
+                d->codes[l][i] = (unsigned char)code;
             }
         }
     }
@@ -539,14 +560,20 @@ void filterSites(size_t c, const std::vector<char> &keep, std::vector<MapData *>
     HapData *h2 = new HapData{h->data ? new short *[n] : nullptr, h->nind, n, h->firstCopy ? new bool *[n] : nullptr,
                               h->packed ? new unsigned char *[n] : nullptr};
     FreqData *f2 = initFreqData(n);
-    GenoLikeData *g2 = g ? new GenoLikeData{new double *[n], g->nind, n} : nullptr;
+    GenoLikeData *g2 = nullptr;
+    if (g) {
+        g2 = new GenoLikeData{g->data ? new double *[n] : nullptr, g->nind, n, g->codes ? new unsigned char *[n] : nullptr,
+                              g->values, g->nvalues};
+        if (g->values) g->values = nullptr;   // the table moves on with the kept rows
+    }
     int j = 0;
     for (int l = 0; l < m->nloci; l++) {
         if (!keep[l]) {
             if (h->data) delete[] h->data[l];
             if (h->packed) delete[] h->packed[l];
             if (h->firstCopy) delete[] h->firstCopy[l];
-            if (g) delete[] g->data[l];
+            if (g && g->data) delete[] g->data[l];
+            if (g && g->codes) delete[] g->codes[l];
             continue;
         }
         m2->physicalPos[j] = m->physicalPos[l]; m2->geneticPos[j] = m->geneticPos[l];
@@ -555,11 +582,12 @@ void filterSites(size_t c, const std::vector<char> &keep, std::vector<MapData *>
         if (h->packed) h2->packed[j] = h->packed[l];
         if (h->firstCopy) h2->firstCopy[j] = h->firstCopy[l];
         f2->freq[j] = f->freq[l];
-        if (g) g2->data[j] = g->data[l];
+        if (g && g->data) g2->data[j] = g->data[l];
+        if (g && g->codes) g2->codes[j] = g->codes[l];
         j++;
     }
     delete[] h->data; delete[] h->firstCopy; delete[] h->packed; delete h;
-    if (g) { delete[] g->data; delete g; (*gls)[c] = g2; }
+    if (g) { delete[] g->data; delete[] g->codes; delete g; (*gls)[c] = g2; }
     releaseMapData(m); releaseFreqData(f);
     (*maps)[c] = m2; (*haps)[c] = h2; (*freqs)[c] = f2;
 }
@@ -884,7 +912,7 @@ void LodEngine::upload(std::vector<HapData *> *haps, std::vector<FreqData *> *fr
     // genotype rows are separate allocations in HapData: stage a slab of SNP rows at a time
     const int64_t slab = std::max<int64_t>(1, ((int64_t)64 << 20) / (2 * (int64_t)impl->nind));
     std::vector<int16_t> stage;
-    std::vector<uint8_t> stage2;
+    std::vector<uint8_t> stage2, stage_glc;
     std::vector<double> stage_gl;
     std::vector<uint8_t> stage_fc;
     impl->have_phase = true;
@@ -903,10 +931,14 @@ void LodEngine::upload(std::vector<HapData *> *haps, std::vector<FreqData *> *fr
                 for (int r = 0; r < rows; r++)
                     memcpy(&stage[(size_t)r * impl->nind], h->data[l0 + r], sizeof(short) * impl->nind);
             }
-            if (USE_GL) {
+            const GenoLikeData *gld = USE_GL ? gls->at(c) : nullptr;
+            if (gld && gld->codes) {
+                stage_glc.resize((size_t)rows * impl->nind);
+                for (int r = 0; r < rows; r++) memcpy(&stage_glc[(size_t)r * impl->nind], gld->codes[l0 + r], impl->nind);
+            } else if (gld) {
                 stage_gl.resize((size_t)rows * impl->nind);
                 for (int r = 0; r < rows; r++)
-                    memcpy(&stage_gl[(size_t)r * impl->nind], gls->at(c)->data[l0 + r], sizeof(double) * impl->nind);
+                    memcpy(&stage_gl[(size_t)r * impl->nind], gld->data[l0 + r], sizeof(double) * impl->nind);
             }
             if (impl->have_phase) {
                 stage_fc.resize((size_t)rows * impl->nind);
@@ -924,7 +956,10 @@ void LodEngine::upload(std::vector<HapData *> *haps, std::vector<FreqData *> *fr
                 if (impl->have_phase)
                     check(garlic_panel_set_phase(s.panel, stage_fc.data() + s.ind_begin, impl->nind, o + l0, rows,
                                                  GARLIC_HOST), "garlic_panel_set_phase");
-                if (USE_GL)
+                if (gld && gld->codes)
+                    check(garlic_panel_set_gl_codes(s.panel, stage_glc.data() + s.ind_begin, impl->nind, o + l0, rows,
+                                                    gld->values, gld->nvalues, GARLIC_HOST), "garlic_panel_set_gl_codes");
+                else if (gld)
                     check(garlic_panel_set_gl(s.panel, stage_gl.data() + s.ind_begin, impl->nind, o + l0, rows,
                                               GARLIC_HOST), "garlic_panel_set_gl");
             }

@@ -55,7 +55,17 @@ struct GenoLikeData {      // src/garlic-data.h:89-95
     double **data;         // [locus][ind]: per-genotype error probability
     int nind;
     int nloci;
+    // Extension (readTGLSData with compact = true): the same values dictionary-coded, one byte per
+    // genotype -- codes[locus][ind] indexes values[0 .. nvalues) -- and `data` NULL.  GQ / PL / GL
+    // files hold a few dozen distinct values; the engine uploads the codes as they are.
+    unsigned char **codes;
+    double *values;
+    int nvalues;
 };
+inline double likelihoodAt(const GenoLikeData *g, int locus, int ind)
+{
+    return g->data ? g->data[locus][ind] : g->values[g->codes[locus][ind]];
+}
 struct LDData {            // src/garlic-data.h:103-108
     double **LD;           // [locus][winsize]
     int nloci;
@@ -127,7 +137,8 @@ void scanIndData3(const std::string &filename, int &numInd, std::string &popName
 IndData *readIndData3(const std::string &filename, int numInd);                     // :1963
 std::vector<GenoLikeData *> *readTGLSData(const std::string &filename, int expectedLoci, int expectedInd,
                                           std::vector<MapData *> *mapDataByChr,
-                                          const std::string &GL_TYPE);             // :1516
+                                          const std::string &GL_TYPE,
+                                          bool compact = false);   // compact: ::codes instead of ::data             // :1516
 std::vector<FreqData *> *readFreqData(const std::string &freqfile,
                                       std::vector<MapData *> *mapDataByChr);        // :1345
 void writeFreqData(const std::string &freqOutfile, std::vector<FreqData *> *freqDataByChr,

@@ -160,7 +160,7 @@ int main(int argc, char **argv)
         std::cerr << "Loaded " << numLoci << " loci x " << numInd << " individuals (" << maps->size() << " chromosomes)\n";
 
         const bool USE_GL = a.tgls != "none";
-        if (USE_GL) gls = readTGLSData(a.tgls, numLoci, numInd, maps, a.gl_type); // rows in pre-filter TPED order
+        if (USE_GL) gls = readTGLSData(a.tgls, numLoci, numInd, maps, a.gl_type, /*compact=*/true); // rows in pre-filter TPED order
         if (a.freq_file != "none") { releaseFreqData(freqs); freqs = nullptr; freqs = readFreqData(a.freq_file, maps); }
         else writeFreqData(a.out + ".freq", freqs, maps);                        // garlic-main.cpp:245-253
         int kept;

@@ -116,6 +116,14 @@ int garlic_panel_set_genotypes_2bit(garlic_panel *panel, const uint8_t *rows, in
 int garlic_panel_set_gl(garlic_panel *panel, const double *gl, int64_t ld, int64_t locus_begin,
                         int64_t locus_count, int32_t where);
 
+/* The same likelihoods already dictionary-coded, as a reader that converts GQ / PL integers produces
+ * them anyway: codes[(l - locus_begin) * ld + i] indexes values[0 .. nvalues), nvalues <= 256, the
+ * error probabilities as readTGLSData converts them.  One byte per genotype on the host and over
+ * PCIe instead of eight.  Every call may bring its own table; a panel holds at most 256 distinct
+ * values in all. */
+int garlic_panel_set_gl_codes(garlic_panel *panel, const uint8_t *codes, int64_t ld, int64_t locus_begin,
+                              int64_t locus_count, const double *values, int32_t nvalues, int32_t where);
+
 /* HapData::firstCopy (src/garlic-data.h:36; filled by readTPED under --phased,
  * src/garlic-data.cpp:106,129: "the first allele of the pair is the counted allele"), one byte per
  * genotype, non-zero = true; same addressing as genotypes.  Only the phased LD weights read it. */

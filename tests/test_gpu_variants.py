@@ -309,3 +309,26 @@ def test_lod_feed_thinned_edge_shapes(gpu_ctx, W, step, nind):
         want = [ol.oracle_flatten(ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg), step) for g, f, p, cs, ce in chroms]
         assert [len(w) for w in want] == list(per_chr)
         assert ol.bits_equal(feed, np.concatenate(want))
+
+
+def test_tgls_from_dictionary_codes(gpu_ctx):
+    """garlic_panel_set_gl_codes: likelihoods that arrive as one-byte codes + a value table, a
+    different table per chunk (as per chromosome in the host adapter) -> the scores of the doubles"""
+    rng = np.random.default_rng(404)
+    mg, W, nind = 200000, 20, 90
+    sizes = [500, 260]
+    chroms = [ol.random_panel(rng, n, nind, max_gap=mg) for n in sizes]
+    tables = [np.array([1e-16, 1e-3, 0.01, 0.2]), np.array([0.5, 1e-3, 1.0, 0.2, 0.03])]   # overlapping, reordered
+    codes = [rng.integers(0, len(t), size=c[0].shape).astype(np.uint8) for t, c in zip(tables, chroms)]
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms])
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        panel.set_gl_codes(codes[0], tables[0])
+        panel.set_gl_codes(codes[1], tables[1], locus_begin=sizes[0])
+        out = panel.lod_windows(W, 0.5, mg, use_gl=True, pitch_align=32)
+        for c, (g, f, p, cs, ce) in enumerate(chroms):
+            want = ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.5, mg, gl=tables[c][codes[c]])
+            assert ol.bits_equal(np.ascontiguousarray(out[c]), want), c
+        with pytest.raises(abi.GarlicError):
+            panel.set_gl_codes(codes[0], np.linspace(0.1, 0.9, 257))
