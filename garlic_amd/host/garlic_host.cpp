@@ -381,9 +381,21 @@ void loadTPEDData(const std::string &tpedfile, int &numLoci, int &numInd, std::v
         if (line.empty()) continue;
         numLoci++;
         numInd = (countFields(line) - 4) / 2; // garlic-data.cpp:59-60
-        std::stringstream ss(line);
+        // the four leading fields through a stream (tiny), the allele columns by hand: at 10k
+        // individuals a line is 40 KB and formatted extraction of every character dominated the load
+        size_t at = 0;
+        for (int field = 0; field < 4; field++) {
+            while (at < line.size() && isspace((unsigned char)line[at])) at++;
+            while (at < line.size() && !isspace((unsigned char)line[at])) at++;
+        }
+        std::stringstream ss(line.substr(0, at));
         double g, p;
         ss >> chr >> name >> g >> p;
+        const char *cur = line.data() + at, *const end = line.data() + line.size();
+        auto next_allele = [&]() -> char {   // `ss >> char`: the next non-blank character, TPED_MISSING at the end
+            while (cur < end && isspace((unsigned char)*cur)) cur++;
+            return cur < end ? *cur++ : TPED_MISSING;
+        };
         if (numLoci == 1) prevChr = chr;
         if (chr != prevChr) { // new chromosome when the chr string changes (garlic-data.cpp:68-91)
             flushChromosome(prevChr, hap, fc, gpos, ppos, names, allele, freq, numInd, *hapDataByChr,
@@ -395,8 +407,7 @@ void loadTPEDData(const std::string &tpedfile, int &numLoci, int &numInd, std::v
         char one = TPED_MISSING; // the first non-missing allele on the line is the counted one
         int nalleles = 0, total = 0;
         for (int i = 0; i < numInd; i++) {
-            char a1 = TPED_MISSING, a2 = TPED_MISSING;
-            ss >> a1 >> a2; // alleles are single characters (garlic-data.cpp:47,111)
+            const char a1 = next_allele(), a2 = next_allele(); // alleles are single characters (garlic-data.cpp:47,111)
             if (one == TPED_MISSING && a1 != TPED_MISSING) one = a1;
             if (one == TPED_MISSING && a2 != TPED_MISSING) one = a2;
             int v = 0;
