@@ -23,7 +23,7 @@ SYMBOLS = [
     "garlic_panel_create", "garlic_panel_destroy", "garlic_panel_set_map",
     "garlic_panel_set_freq", "garlic_panel_set_genotypes", "garlic_panel_set_genotypes_2bit", "garlic_panel_set_gl", "garlic_panel_set_gl_codes",
     "garlic_panel_set_phase",
-    "garlic_panel_set_ld", "garlic_lod_out_layout", "garlic_lod_windows",
+    "garlic_panel_set_ld", "garlic_lod_out_layout", "garlic_lod_windows", "garlic_lod_windows_multi",
     "garlic_wlod_windows", "garlic_lod_flatten", "garlic_last_call_stats",
     "garlic_panel_compute_ld", "garlic_ld_counts", "garlic_ld_finish", "garlic_roh_coverage",
     "garlic_panel_release_scratch",
@@ -80,6 +80,8 @@ def lib():
     L.garlic_panel_set_genotypes.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
     L.garlic_panel_set_gl.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
     L.garlic_panel_release_scratch.argtypes = [_vp]
+    L.garlic_lod_windows_multi.argtypes = [_vp, _i32p, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_int32, _vp, C.c_int64, C.c_int32]
     L.garlic_panel_set_gl_codes.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_int32, C.c_int32]
     L.garlic_panel_set_genotypes_2bit.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
     L.garlic_panel_set_phase.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32]
@@ -337,6 +339,19 @@ class Panel:
             n = int(self.chr_nloci[c])
             blk = out[base[c]: base[c] + ind_count * pitch[c]].reshape(ind_count, pitch[c])
             res.append(blk[:, :n])
+        return res
+
+    def lod_windows_multi(self, winsizes, error, max_gap, pitch_align=1, use_gl=False):
+        """Host-output convenience for several window sizes: {W: [per-chromosome [nind][nloci_c] arrays]}."""
+        ws = np.ascontiguousarray(winsizes, dtype=np.int32)
+        base, pitch, total = self.out_layout(pitch_align, self.nind)
+        out = np.empty((len(ws), total), dtype=np.float64)
+        check(lib().garlic_lod_windows_multi(self.handle, _ptr(ws, _i32p), len(ws), error, max_gap, int(use_gl), 0,
+                                             self.nind, pitch_align, _vp(out.ctypes.data), total, HOST))
+        res = {}
+        for k, W in enumerate(ws):
+            res[int(W)] = [out[k, base[c]: base[c] + self.nind * pitch[c]].reshape(self.nind, pitch[c])[:, :int(self.chr_nloci[c])]
+                           for c in range(self.nchr)]
         return res
 
     def lod_windows_device(self, out_ptr, winsize, error, max_gap, ind_begin=0, ind_count=None,

@@ -1456,6 +1456,25 @@ int garlic_lod_windows(garlic_panel *p, int32_t winsize, double error, int32_t m
                       ind_count, pitch_align, out, where);
 }
 
+int garlic_lod_windows_multi(garlic_panel *p, const int32_t *winsizes, int32_t n_winsizes, double error,
+                             int32_t max_gap, int32_t use_gl, int32_t ind_begin, int32_t ind_count,
+                             int32_t pitch_align, double *out, int64_t out_stride, int32_t where)
+{
+    if (!p || !winsizes) return fail(GARLIC_ERR_INVALID, "panel and winsizes are required");
+    if (n_winsizes < 1) return fail(GARLIC_ERR_INVALID, "n_winsizes must be >= 1");
+    if (!out) return fail(GARLIC_ERR_INVALID, "out is NULL");
+    const Layout L = make_layout(p, pitch_align, ind_count);
+    if (out_stride < L.total)
+        return fail(GARLIC_ERR_INVALID, "out_stride %lld smaller than one window size's scores (%lld doubles)",
+                    (long long)out_stride, (long long)L.total);
+    for (int32_t k = 0; k < n_winsizes; k++) {   // the panel stays resident: only the work list changes
+        const int rc = launch_lod(p, use_gl ? MODE_LOD_GL : MODE_LOD, winsizes[k], error, max_gap, 0, 0.0, ind_begin,
+                                  ind_count, pitch_align, out + (int64_t)k * out_stride, where);
+        if (rc) return rc;
+    }
+    return GARLIC_OK;
+}
+
 int garlic_wlod_windows(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
                         int32_t M, double mu, int32_t ind_begin, int32_t ind_count, int32_t pitch_align,
                         double *out, int32_t where)

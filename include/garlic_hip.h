@@ -186,6 +186,13 @@ int garlic_lod_windows(garlic_panel *panel, int32_t winsize, double error, int32
                        int32_t use_gl, int32_t ind_begin, int32_t ind_count, int32_t pitch_align,
                        double *out, int32_t where);
 
+/* The same for several window sizes (--winsize-multi; exploreWinsizes, src/garlic-roh.cpp:726-751):
+ * the scores of winsizes[k] go to out + k * out_stride (out_stride >= the layout's total).  The
+ * panel stays resident, the kernels run one window size after the other. */
+int garlic_lod_windows_multi(garlic_panel *panel, const int32_t *winsizes, int32_t n_winsizes, double error,
+                             int32_t max_gap, int32_t use_gl, int32_t ind_begin, int32_t ind_count,
+                             int32_t pitch_align, double *out, int64_t out_stride, int32_t where);
+
 /* calcwLODWindows (src/garlic-roh.cpp:311): gap-weighted wLOD; needs gpos and LD for winsize
  * (garlic_panel_set_ld or garlic_panel_compute_ld).  winsize up to 4096 (above that:
  * GARLIC_ERR_INVALID; the reference has no limit but no use for such windows either). */

@@ -252,3 +252,23 @@ def test_genotypes_from_2bit_rows(gpu_ctx, nind, lo):
         with pytest.raises(abi.GarlicError):
             panel.set_genotypes_2bit(rows[:, :(lo + nind + 3) // 4 - 1] if (lo + nind + 3) // 4 > 1 else rows[:, :0],
                                      ind_offset=lo)
+
+
+def test_several_window_sizes_in_one_call(gpu_ctx):
+    """garlic_lod_windows_multi (--winsize-multi): one resident panel, one score block per window size"""
+    rng = np.random.default_rng(55)
+    sizes, nind, mg = [900, 300], 70, 200000
+    data = make_multichr(rng, sizes, nind, mg, gaps=2, miss=0.03)
+    genos, freqs, poss, css, ces = data
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate(poss), css, ces)
+        panel.set_freq(np.concatenate(freqs))
+        panel.set_genotypes(np.concatenate(genos, axis=0))
+        for pa in (1, 32):
+            got = panel.lod_windows_multi([50, 10, 300, 33], 0.001, mg, pitch_align=pa)
+            for W, blocks in got.items():
+                for c, g in enumerate(genos):
+                    want = ol.oracle_calc_lod(g, freqs[c], poss[c], css[c], ces[c], W, 0.001, mg)
+                    assert ol.bits_equal(np.ascontiguousarray(blocks[c]), want), (pa, W, c)
+        with pytest.raises(abi.GarlicError):
+            panel.lod_windows_multi([50, 1], 0.001, mg)
