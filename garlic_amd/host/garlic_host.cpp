@@ -12,6 +12,7 @@
 #include <iostream>
 #include <sstream>
 #include <random>
+#include <mutex>
 #include <thread>
 #include <ctime>
 
@@ -1058,32 +1059,53 @@ std::vector<LDData *> *LodEngine::ldWeights(int winsize, const std::vector<int> 
     for (int n : impl->chr_nloci) nloci += n;
     // every shard counts over its own individuals; the counts are integers, so their sum over
     // shards is exact whatever the order (with one process per GPU this is an RCCL all-reduce)
-    std::vector<int32_t> loc((size_t)nloci * 2, 0), pair((size_t)nloci * winsize * 2, 0), l1, p1;
-    for (auto &s : impl->shards) {
+    std::vector<int32_t> loc((size_t)nloci * 2, 0), pair((size_t)nloci * winsize * 2, 0);
+    const size_t ns = impl->shards.size();
+    std::vector<std::string> errors(ns);
+    std::mutex sum_lock;
+    auto count_shard = [&](size_t k) {   // one host thread per GPU, as for the scores
+        auto &s = impl->shards[k];
         std::vector<int32_t> sub;
         for (int g : subsample)
             if (g >= s.ind_begin && g < s.ind_begin + s.nind) sub.push_back(g - s.ind_begin);
-        const bool single = impl->shards.size() == 1;
-        std::vector<int32_t> &lo = single ? loc : l1, &pa = single ? pair : p1;
+        std::vector<int32_t> l1, p1;
+        std::vector<int32_t> &lo = ns == 1 ? loc : l1, &pa = ns == 1 ? pair : p1;
         lo.resize(loc.size()); pa.resize(pair.size());
-        if (!subsample.empty() && sub.empty()) {   // none of the subsample lives here: only homFreq counts
-            // (an empty list would mean "all": count everything, then drop the pair counts)
-            check(garlic_ld_counts(s.panel, winsize, ph, nullptr, 0, lo.data(), pa.data(), GARLIC_HOST), "garlic_ld_counts");
-            std::fill(pa.begin(), pa.end(), 0);
-        } else {
-            check(garlic_ld_counts(s.panel, winsize, ph, sub.empty() ? nullptr : sub.data(), (int32_t)sub.size(),
-                                   lo.data(), pa.data(), GARLIC_HOST), "garlic_ld_counts");
+        // none of the subsample lives here: only the homFreq counts (an empty list would mean "all":
+        // count everything, then drop the pair counts)
+        const bool none = !subsample.empty() && sub.empty();
+        if (garlic_ld_counts(s.panel, winsize, ph, (none || sub.empty()) ? nullptr : sub.data(),
+                             none ? 0 : (int32_t)sub.size(), lo.data(), pa.data(), GARLIC_HOST) != GARLIC_OK) {
+            errors[k] = garlic_hip_last_error();
+            return;
         }
-        if (!single) {
-            for (size_t i = 0; i < loc.size(); i++) loc[i] += lo[i];
+        if (ns == 1) return;
+        std::lock_guard<std::mutex> hold(sum_lock);
+        for (size_t i = 0; i < loc.size(); i++) loc[i] += lo[i];
+        if (!none)
             for (size_t i = 0; i < pair.size(); i++) pair[i] += pa[i];
-        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < ns; k++) th.emplace_back(count_shard, k);
+        for (auto &t : th) t.join();
     }
+    for (auto &e : errors)
+        if (!e.empty()) fail("garlic_ld_counts: " + e);
     std::vector<double> flat;
     if (want_host) flat.resize((size_t)nloci * winsize);
-    for (size_t k = 0; k < impl->shards.size(); k++)
-        check(garlic_ld_finish(impl->shards[k].panel, winsize, ph, loc.data(), pair.data(),
-                               (want_host && k == 0) ? flat.data() : nullptr, GARLIC_HOST), "garlic_ld_finish");
+    {
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < ns; k++)
+            th.emplace_back([&, k] {
+                if (garlic_ld_finish(impl->shards[k].panel, winsize, ph, loc.data(), pair.data(),
+                                     (want_host && k == 0) ? flat.data() : nullptr, GARLIC_HOST) != GARLIC_OK)
+                    errors[k] = garlic_hip_last_error();
+            });
+        for (auto &t : th) t.join();
+    }
+    for (auto &e : errors)
+        if (!e.empty()) fail("garlic_ld_finish: " + e);
     if (!want_host) return nullptr;
     std::vector<LDData *> *out = new std::vector<LDData *>;
     int64_t o = 0;
