@@ -362,6 +362,58 @@ void flushChromosome(const std::string &chr, std::vector<short *> &hap, std::vec
 }
 } // namespace
 
+namespace {
+struct TpedLine {          // one parsed TPED line (garlic-data.cpp:56-141)
+    std::string chr, name;
+    double g = 0, p = 0;
+    int numInd = 0;
+    short *data = nullptr;
+    bool *first = nullptr;
+    char one = 0;
+    double freq = 0;
+};
+
+TpedLine parseTpedLine(const std::string &line, char TPED_MISSING, bool PHASED)
+{
+    TpedLine r;
+    r.numInd = (countFields(line) - 4) / 2; // garlic-data.cpp:59-60
+    // the four leading fields through a stream (tiny), the allele columns by hand: at 10k
+    // individuals a line is 40 KB and formatted extraction of every character dominated the load
+    size_t at = 0;
+    for (int field = 0; field < 4; field++) {
+        while (at < line.size() && isspace((unsigned char)line[at])) at++;
+        while (at < line.size() && !isspace((unsigned char)line[at])) at++;
+    }
+    std::stringstream ss(line.substr(0, at));
+    ss >> r.chr >> r.name >> r.g >> r.p;
+    const char *cur = line.data() + at, *const end = line.data() + line.size();
+    auto next_allele = [&]() -> char {   // `ss >> char`: the next non-blank character, TPED_MISSING at the end
+        while (cur < end && (*cur == ' ' || *cur == '\t' || *cur == '\r')) cur++;
+        return cur < end ? *cur++ : TPED_MISSING;
+    };
+    const int n = std::max(r.numInd, 0);
+    r.data = new short[n > 0 ? n : 1];
+    r.first = PHASED ? new bool[n > 0 ? n : 1] : nullptr;
+    char one = TPED_MISSING; // the first non-missing allele on the line is the counted one
+    int nalleles = 0, total = 0;
+    for (int i = 0; i < n; i++) {
+        const char a1 = next_allele(), a2 = next_allele(); // alleles are single characters (garlic-data.cpp:47,111)
+        if (one == TPED_MISSING && a1 != TPED_MISSING) one = a1;
+        if (one == TPED_MISSING && a2 != TPED_MISSING) one = a2;
+        int v = 0;
+        for (char a : {a1, a2}) {
+            if (a == TPED_MISSING) v += -9;
+            else { total++; if (a == one) { v += 1; nalleles++; } }
+        }
+        r.data[i] = (short)(v < 0 ? -9 : v);
+        if (r.first) r.first[i] = (a1 == one);   // garlic-data.cpp:129
+    }
+    r.one = one;
+    r.freq = total == 0 ? 0.0 : double(nalleles) / double(total); // garlic-data.cpp:140-141
+    return r;
+}
+} // namespace
+
 void loadTPEDData(const std::string &tpedfile, int &numLoci, int &numInd, std::vector<HapData *> **hapDataByChr,
                   std::vector<MapData *> **mapDataByChr, std::vector<FreqData *> **freqDataByChr,
                   char TPED_MISSING, bool PHASED)
@@ -375,57 +427,46 @@ void loadTPEDData(const std::string &tpedfile, int &numLoci, int &numInd, std::v
     std::vector<double> gpos, ppos, freq;
     std::vector<std::string> names;
     std::vector<char> allele;
-    std::string line, chr, prevChr, name;
+    std::string chr, prevChr;
     numLoci = 0;
     numInd = 0;
-    while (in.next(line)) {
-        if (line.empty()) continue;
-        numLoci++;
-        numInd = (countFields(line) - 4) / 2; // garlic-data.cpp:59-60
-        // the four leading fields through a stream (tiny), the allele columns by hand: at 10k
-        // individuals a line is 40 KB and formatted extraction of every character dominated the load
-        size_t at = 0;
-        for (int field = 0; field < 4; field++) {
-            while (at < line.size() && isspace((unsigned char)line[at])) at++;
-            while (at < line.size() && !isspace((unsigned char)line[at])) at++;
-        }
-        std::stringstream ss(line.substr(0, at));
-        double g, p;
-        ss >> chr >> name >> g >> p;
-        const char *cur = line.data() + at, *const end = line.data() + line.size();
-        auto next_allele = [&]() -> char {   // `ss >> char`: the next non-blank character, TPED_MISSING at the end
-            while (cur < end && isspace((unsigned char)*cur)) cur++;
-            return cur < end ? *cur++ : TPED_MISSING;
-        };
-        if (numLoci == 1) prevChr = chr;
-        if (chr != prevChr) { // new chromosome when the chr string changes (garlic-data.cpp:68-91)
-            flushChromosome(prevChr, hap, fc, gpos, ppos, names, allele, freq, numInd, *hapDataByChr,
-                            *mapDataByChr, *freqDataByChr);
-            prevChr = chr;
-        }
-        short *data = new short[numInd];
-        bool *first = PHASED ? new bool[numInd] : nullptr;
-        char one = TPED_MISSING; // the first non-missing allele on the line is the counted one
-        int nalleles = 0, total = 0;
-        for (int i = 0; i < numInd; i++) {
-            const char a1 = next_allele(), a2 = next_allele(); // alleles are single characters (garlic-data.cpp:47,111)
-            if (one == TPED_MISSING && a1 != TPED_MISSING) one = a1;
-            if (one == TPED_MISSING && a2 != TPED_MISSING) one = a2;
-            int v = 0;
-            for (char a : {a1, a2}) {
-                if (a == TPED_MISSING) v += -9;
-                else { total++; if (a == one) { v += 1; nalleles++; } }
+    // Lines are independent: one thread reads (and inflates), batches of lines are parsed on all
+    // cores, the results join the chromosomes in file order.
+    const unsigned nthreads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const size_t batch_lines = 64 * nthreads;
+    std::vector<std::string> lines;
+    std::vector<TpedLine> parsed;
+    bool more = true;
+    while (more) {
+        lines.clear();
+        std::string line;
+        while (lines.size() < batch_lines && (more = in.next(line)))
+            if (!line.empty()) lines.push_back(std::move(line));
+        parsed.assign(lines.size(), TpedLine());
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nthreads && t < lines.size(); t++)
+            th.emplace_back([&, t] {
+                for (size_t k = t; k < lines.size(); k += nthreads) parsed[k] = parseTpedLine(lines[k], TPED_MISSING, PHASED);
+            });
+        for (auto &t : th) t.join();
+        for (TpedLine &r : parsed) {
+            numLoci++;
+            numInd = r.numInd;
+            chr = r.chr;
+            if (numLoci == 1) prevChr = chr;
+            if (chr != prevChr) { // new chromosome when the chr string changes (garlic-data.cpp:68-91)
+                flushChromosome(prevChr, hap, fc, gpos, ppos, names, allele, freq, numInd, *hapDataByChr,
+                                *mapDataByChr, *freqDataByChr);
+                prevChr = chr;
             }
-            data[i] = (short)(v < 0 ? -9 : v);
-            if (first) first[i] = (a1 == one);   // garlic-data.cpp:129
+            hap.push_back(r.data);
+            if (r.first) fc.push_back(r.first);
+            gpos.push_back(r.g);
+            ppos.push_back(r.p);
+            names.push_back(r.name);
+            allele.push_back(r.one);
+            freq.push_back(r.freq);
         }
-        hap.push_back(data);
-        if (first) fc.push_back(first);
-        gpos.push_back(g);
-        ppos.push_back(p);
-        names.push_back(name);
-        allele.push_back(one);
-        freq.push_back(total == 0 ? 0.0 : double(nalleles) / double(total)); // garlic-data.cpp:140-141
     }
     if (numLoci == 0) fail("no loci in " + tpedfile);
     flushChromosome(chr, hap, fc, gpos, ppos, names, allele, freq, numInd, *hapDataByChr, *mapDataByChr,
