@@ -368,15 +368,21 @@ class Panel:
                                        _vp(feed_ptr) if feed_ptr else None, feed_capacity, C.byref(n)))
         return n.value
 
-    def lod_feed(self, winsize, error, max_gap, step, use_gl=False, weighted=False, M=7, mu=1e-9):
-        """scores + thinning on the device: returns (feed float64 [count], per-chromosome counts)"""
+    def lod_feed(self, winsize, error, max_gap, step, use_gl=False, weighted=False, M=7, mu=1e-9, copy=True):
+        """scores + thinning on the device: returns (feed float64 [count], per-chromosome counts).
+        copy=False: the feed is a view of a buffer the panel object reuses for the next call."""
         cap = int(sum((int(n) + step - 1) // step for n in self.chr_nloci)) * self.nind
-        feed = np.empty(max(cap, 1), dtype=np.float64)
+        if copy:
+            feed = np.empty(max(cap, 1), dtype=np.float64)
+        else:
+            if getattr(self, "_feed_buf", None) is None or self._feed_buf.shape[0] < max(cap, 1):
+                self._feed_buf = np.empty(max(cap, 1), dtype=np.float64)
+            feed = self._feed_buf
         n = C.c_int64()
         per_chr = np.zeros(self.nchr, dtype=np.int64)
         check(lib().garlic_lod_feed(self.handle, winsize, error, max_gap, int(use_gl), int(weighted), M, mu,
                                     step, _vp(feed.ctypes.data), cap, C.byref(n), _ptr(per_chr, _i64p)))
-        return feed[: n.value].copy(), per_chr
+        return (feed[: n.value].copy() if copy else feed[: n.value]), per_chr
 
     def roh_coverage(self, scores_ptr, winsize, cutoff, pitch_align=32, nind_out=None):
         """assembleROHWindows' coverage counts of device-resident scores: list of per-chromosome int16

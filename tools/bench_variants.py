@@ -83,11 +83,11 @@ def main():
         # the compaction.  chain_kernel_ms = the chain kernel alone; call_ms = wall clock incl. the D2H
         # of the feed.  GARLIC_FEED_FULL=1 in the environment gives the full-scores-then-sample path.
         import time
-        panel.lod_feed(W, error, max_gap, W)
+        panel.lod_feed(W, error, max_gap, W, copy=False)
         ms, wall = [], []
         for _ in range(args.steps):
             t0 = time.perf_counter()
-            feed, _ = panel.lod_feed(W, error, max_gap, W)
+            feed, _ = panel.lod_feed(W, error, max_gap, W, copy=False)
             wall.append(time.perf_counter() - t0)
             ms.append(panel.stats()["chain_kernel_ms"])
         k = float(np.mean(ms))
