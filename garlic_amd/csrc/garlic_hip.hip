@@ -103,7 +103,7 @@ struct garlic_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev_begin = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_end = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool async_device = false;   // garlic_ctx_set_async
     // the dominant kernel of the last HIST calls, one event pair each (asynchronous passes are
     // timed without being waited for one by one): garlic_recent_kernel_ms
@@ -192,6 +192,7 @@ struct garlic_panel {
     DevBuf<double> d_out, d_feed;
     garlic_call_stats stats{};
     bool stats_pending = false;                    // event times of the last call not read yet
+    int stats_slot = 0;                            // the context's event pair that brackets its dominant kernel
     // work list of the last call, still on the device: repeated calls with the same arguments
     // (bench steps, window-size sweeps coming back to a size) skip planning and uploads
     struct {
@@ -562,7 +563,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         if ((rc = p->d_chrs.reserve(chrs.size()))) return rc;
         if ((rc = p->d_items.reserve(std::max<size_t>(n_items, 1)))) return rc;
         if ((rc = p->d_fill.reserve(std::max<size_t>(n_fill, 1)))) return rc;
-        if ((rc = p->d_counter.reserve(1))) return rc;
+        if ((rc = p->d_counter.reserve(2))) return rc;
         p->plan.valid = false;
     }
     std::vector<uint8_t> valid;
@@ -619,9 +620,11 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         hipLaunchKernelGGL(fill_missing_kernel, grid, dim3(256), 0, ctx->stream, p->d_fill.p,
                            p->d_chrs.p, ind_count, d_out);
     }
-    if (n_items) HIP_TRY(hipMemsetAsync(p->d_counter.p, 0, sizeof(int32_t), ctx->stream));
-    HIP_TRY(hipEventRecord(ctx->ev_k0, ctx->stream));
-    HIP_TRY(hipEventRecord(ctx->hist0[ctx->n_calls % garlic_ctx::HIST], ctx->stream));
+    // queue head and exit count of the persistent chain kernel: its last workgroup leaves both at
+    // zero, so only a new plan (or a first call) clears them
+    if (n_items && (!reuse || mode != MODE_LOD)) HIP_TRY(hipMemsetAsync(p->d_counter.p, 0, 2 * sizeof(int32_t), ctx->stream));
+    p->stats_slot = (int)(ctx->n_calls % garlic_ctx::HIST);
+    HIP_TRY(hipEventRecord(ctx->hist0[p->stats_slot], ctx->stream));
     if (wlod_fast) {
         const int nquad = (nblk + WLOD_WAVES - 1) / WLOD_WAVES;
         WlodArgs a{p->d_valid.p, p->d_chrs.p, p->d_tiles.p, p->nwordrows, p->nchr, ind_begin, ind_count, W, nquad,
@@ -701,7 +704,6 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                                ring);
         }
     }
-    HIP_TRY(hipEventRecord(ctx->ev_k1, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->hist1[ctx->n_calls % garlic_ctx::HIST], ctx->stream));
     ctx->n_calls++;
     HIP_TRY(hipGetLastError());
@@ -786,7 +788,7 @@ int garlic_ctx_create(int32_t device, void *hip_stream, garlic_ctx **out)
         }
         ctx->own_stream = true;
     }
-    hipEvent_t *evs[4] = {&ctx->ev_begin, &ctx->ev_k0, &ctx->ev_k1, &ctx->ev_end};
+    hipEvent_t *evs[2] = {&ctx->ev_begin, &ctx->ev_end};
     for (auto ev : evs) {
         hipError_t ee = hipEventCreate(ev);
         if (ee != hipSuccess) {
@@ -808,7 +810,7 @@ int garlic_ctx_destroy(garlic_ctx *ctx)
     if (!ctx) return GARLIC_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (hipEvent_t ev : {ctx->ev_begin, ctx->ev_k0, ctx->ev_k1, ctx->ev_end})
+    for (hipEvent_t ev : {ctx->ev_begin, ctx->ev_end})
         if (ev) (void)hipEventDestroy(ev);
     for (int i = 0; i < garlic_ctx::HIST; i++) {
         if (ctx->hist0[i]) (void)hipEventDestroy(ctx->hist0[i]);
@@ -1629,7 +1631,7 @@ int garlic_last_call_stats(garlic_panel *p, garlic_call_stats *stats)
         int rc;
         if ((rc = set_device(p->ctx))) return rc;
         HIP_TRY(hipEventSynchronize(p->ctx->ev_end));
-        (void)hipEventElapsedTime(&p->stats.chain_kernel_ms, p->ctx->ev_k0, p->ctx->ev_k1);
+        (void)hipEventElapsedTime(&p->stats.chain_kernel_ms, p->ctx->hist0[p->stats_slot], p->ctx->hist1[p->stats_slot]);
         (void)hipEventElapsedTime(&p->stats.total_ms, p->ctx->ev_begin, p->ctx->ev_end);
         p->stats_pending = false;
     }

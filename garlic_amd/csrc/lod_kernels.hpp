@@ -280,7 +280,8 @@ struct ChainArgs {
     int32_t n_items;          // work-list length
     int32_t thin_step;        // THIN kernels: only windows at chromosome-local loci 0, step, 2*step, .. are
                               // stored, as out[chr.out_base + ind * chr.out_pitch + locus / step]
-    int32_t *next_item;       // device counter (zeroed per launch): the persistent waves' queue head
+    int32_t *next_item;       // [0] the persistent workgroups' queue head, [1] workgroups that have left; both zero
+                              // at launch (the last workgroup to leave resets them)
     int64_t *trace;           // optional (GARLIC_TRACE): per item {worker, t_begin, t_asm, t_end} in 100 MHz ticks
 };
 
@@ -455,7 +456,18 @@ lod_chain_kernel(ChainArgs p)
     const int item_idx =
         __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(smem + LDS_ITEM));   // (barriers on both sides)
     __syncthreads();
-    if (item_idx >= p.n_items) return;
+    if (item_idx >= p.n_items) {
+        // the last workgroup to leave puts the queue head (and this exit count) back to zero for
+        // the next launch: one operation less between two passes
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(p.next_item + 1, 1) == (int)gridDim.x - 1) {
+                p.next_item[0] = 0;
+                p.next_item[1] = 0;
+            }
+        }
+        return;
+    }
     if (p.trace && threadIdx.x == 0) {
         p.trace[4 * item_idx + 0] = blockIdx.x;
         p.trace[4 * item_idx + 1] = wall_clock64();
