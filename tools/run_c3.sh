@@ -1,4 +1,5 @@
 #!/bin/bash
+# as run_var.sh at the C3-sized workload (5M x 5k)
 cp garlic_amd/libgarlic_hip.so /tmp/orig.so
 for f in build/var/*.so; do
   cp $f garlic_amd/libgarlic_hip.so

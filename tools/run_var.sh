@@ -1,4 +1,5 @@
 #!/bin/bash
+# time every library in build/var/ on the C2 bench (same box, same call): box-to-box variance is larger than most effects
 cp garlic_amd/libgarlic_hip.so /tmp/orig.so
 for f in build/var/*.so; do
   cp $f garlic_amd/libgarlic_hip.so
