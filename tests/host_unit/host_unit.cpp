@@ -1,0 +1,95 @@
+// CPU unit checks of the host adapter's compact containers (no GPU needed): the packed genotype rows of
+// the cache and the dictionary-coded likelihoods must describe exactly what the reference-shaped
+// containers hold, before and after the site filter.
+#include "../../garlic_amd/host/garlic_host.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+
+using namespace garlic_host;
+
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        if (!(cond)) { std::cerr << "FAILED " << __LINE__ << ": " #cond "\n"; return 1; } \
+    } while (0)
+
+static bool same_genotypes(std::vector<HapData *> *a, std::vector<HapData *> *b)
+{
+    if (a->size() != b->size()) return false;
+    for (size_t c = 0; c < a->size(); c++) {
+        if (a->at(c)->nloci != b->at(c)->nloci || a->at(c)->nind != b->at(c)->nind) return false;
+        for (int l = 0; l < a->at(c)->nloci; l++)
+            for (int i = 0; i < a->at(c)->nind; i++)
+                if (genotypeAt(a->at(c), l, i) != genotypeAt(b->at(c), l, i)) return false;
+    }
+    return true;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 5) { std::cerr << "usage: host_unit tped tgls gl_type tmpdir\n"; return 2; }
+    const std::string tped = argv[1], tgls = argv[2], gl_type = argv[3], tmp = argv[4];
+    try {
+        int nl = 0, ni = 0, nl2 = 0, ni2 = 0, nl3 = 0, ni3 = 0;
+        std::vector<HapData *> *h, *hp, *hs;
+        std::vector<MapData *> *m, *mp, *ms;
+        std::vector<FreqData *> *f, *fp, *fs;
+        loadTPEDData(tped, nl, ni, &h, &m, &f, '0', /*PHASED=*/true);
+        CHECK(h->at(0)->data && h->at(0)->firstCopy && !h->at(0)->packed);
+        const std::string cache = tmp + "/unit.g2b";
+        writeGenotypeCache(cache, h, m, f);
+        loadGenotypeCache(cache, nl2, ni2, &hp, &mp, &fp, /*keepPacked=*/true);
+        loadGenotypeCache(cache, nl3, ni3, &hs, &ms, &fs, /*keepPacked=*/false);
+        CHECK(nl2 == nl && ni2 == ni && nl3 == nl && ni3 == ni);
+        CHECK(hp->at(0)->packed && !hp->at(0)->data && hs->at(0)->data && !hs->at(0)->packed);
+        CHECK(same_genotypes(h, hp) && same_genotypes(h, hs));
+        for (size_t c = 0; c < h->size(); c++)           // phase bits and frequencies survive the cache
+            for (int l = 0; l < h->at(c)->nloci; l++) {
+                CHECK(memcmp(&f->at(c)->freq[l], &fp->at(c)->freq[l], sizeof(double)) == 0);
+                for (int i = 0; i < ni; i++) CHECK(h->at(c)->firstCopy[l][i] == hp->at(c)->firstCopy[l][i]);
+            }
+        // a cache written from packed rows is byte-identical
+        const std::string cache2 = tmp + "/unit2.g2b";
+        writeGenotypeCache(cache2, hp, mp, fp);
+        {
+            FILE *a = fopen(cache.c_str(), "rb"), *b = fopen(cache2.c_str(), "rb");
+            CHECK(a && b);
+            int ca, cb;
+            do { ca = fgetc(a); cb = fgetc(b); CHECK(ca == cb); } while (ca != EOF);
+            fclose(a); fclose(b);
+        }
+        // likelihoods: dictionary codes describe the same doubles
+        std::vector<GenoLikeData *> *g = readTGLSData(tgls, nl, ni, m, gl_type, false);
+        std::vector<GenoLikeData *> *gc = readTGLSData(tgls, nl, ni, mp, gl_type, true);
+        for (size_t c = 0; c < g->size(); c++) {
+            CHECK(g->at(c)->data && !g->at(c)->codes && gc->at(c)->codes && !gc->at(c)->data);
+            CHECK(gc->at(c)->nvalues >= 1 && gc->at(c)->nvalues <= 256);
+            for (int l = 0; l < g->at(c)->nloci; l++)
+                for (int i = 0; i < ni; i++) {
+                    const double x = likelihoodAt(g->at(c), l, i), y = likelihoodAt(gc->at(c), l, i);
+                    CHECK(memcmp(&x, &y, sizeof x) == 0);
+                }
+        }
+        // the site filter keeps the same sites and rows in both forms
+        const int k1 = filterMonomorphicSites(&m, &h, &f, &g, true);
+        const int k2 = filterMonomorphicSites(&mp, &hp, &fp, &gc, true);
+        CHECK(k1 == k2 && k1 < nl);
+        CHECK(same_genotypes(h, hp));
+        for (size_t c = 0; c < g->size(); c++)
+            for (int l = 0; l < g->at(c)->nloci; l++)
+                for (int i = 0; i < ni; i++) {
+                    const double x = likelihoodAt(g->at(c), l, i), y = likelihoodAt(gc->at(c), l, i);
+                    CHECK(memcmp(&x, &y, sizeof x) == 0);
+                }
+        releaseGLData(g); releaseGLData(gc);
+        releaseHapData(h); releaseHapData(hp); releaseHapData(hs);
+        releaseMapData(m); releaseMapData(mp); releaseMapData(ms);
+        releaseFreqData(f); releaseFreqData(fp); releaseFreqData(fs);
+    } catch (...) {
+        std::cerr << "FAILED: exception\n";
+        return 1;
+    }
+    std::cout << "host_unit ok\n";
+    return 0;
+}

@@ -55,3 +55,19 @@ def test_genotype_cache_round_trip_without_gpu(tmp_path):
         f.truncate(os.path.getsize(cache) // 2)
     r3 = run(*args)
     assert r3.returncode != 0 and "truncated" in r3.stderr
+
+
+def test_compact_host_containers(tmp_path):
+    """tests/host_unit/host_unit.cpp (compiled here, ASan + UBSan): the packed genotype rows of the cache and
+    the dictionary-coded likelihoods hold exactly what the reference-shaped containers hold, before and
+    after the monomorphic-site filter; a cache rewritten from packed rows is byte-identical"""
+    exe = str(tmp_path / "host_unit")
+    src = os.path.join(ROOT, "tests", "host_unit", "host_unit.cpp")
+    libdir = os.path.join(ROOT, "garlic_amd")
+    cc = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined",
+                         "-fno-omit-frame-pointer", "-o", exe, src, os.path.join(libdir, "host", "garlic_host.cpp"),
+                         "-L" + libdir, "-lgarlic_hip", "-lz", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-3000:]
+    r = subprocess.run([exe, os.path.join(E2E, "tiny.tped.gz"), os.path.join(E2E, "tiny.tgls.gz"), "GQ", str(tmp_path)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "host_unit ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
