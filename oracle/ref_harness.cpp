@@ -288,6 +288,26 @@ REF_API int ref_assembleROH(int nloci, int nind, const double *win, const int *p
     } catch (...) { return -1; }
 }
 
+// loadMapScaffold + interpolateGeneticmap (garlic-data.cpp:702-757, 759-...) for ONE chromosome of a map
+// file: the genetic positions the reference assigns to physical positions pos[0..n) (all inside the
+// scaffold's span).  Returns the number of interpolated sites, -1 on error.
+REF_API int ref_interpolate(const char *mapfile, int cStart, int cEnd, int centro_known, int nloci, const int *pos,
+                            double *gpos_out)
+{
+    StderrSilencer quiet;
+    try {
+        centromere *c = make_centromere(cStart, cEnd, centro_known != 0);
+        vector<GenMapScaffold *> *sc = loadMapScaffold(mapfile, c);
+        MapData *map = make_map(nloci, pos, NULL);
+        int n = interpolateGeneticmap(map, sc->at(0));
+        memcpy(gpos_out, map->geneticPos, sizeof(double) * nloci);
+        free_map(map);
+        releaseGenMapScaffold(sc);
+        delete c;
+        return n;
+    } catch (...) { return -1; }
+}
+
 // Runs the reference's TGLS reader on a text file we are given; returns error probabilities
 // double[nloci][nind].  gl_type is "GQ", "GL" or "PL".
 REF_API int ref_readTGLS(const char *path, int nloci, int nind, const char *gl_type, double *out)

@@ -141,3 +141,32 @@ def test_roh_coverage_through_the_reference_segments():
             assert mine == ref, (nloci, nind, W, frac)
             checked += len(ref)
     assert checked > 200
+
+
+def test_genetic_map_interpolation_of_the_host_adapter(tmp_path):
+    """garlic_amd/host's loadMapScaffold + interpolateGeneticmap (what --weighted feeds wLOD with) against
+    the reference's own functions (garlic-data.cpp:702-757 through oracle/_ref): every genetic position
+    bit for bit -- exact scaffold hits, interpolated sites, the scaffold's first and last site"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "map_unit")
+    libdir = os.path.join(root, "garlic_amd")
+    cc = subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-o", exe, os.path.join(root, "tests", "host_unit", "map_unit.cpp"),
+                         "-L" + libdir, "-lgarlic_host", "-lgarlic_hip", "-lz", "-ldl", "-Wl,-rpath," + libdir],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-3000:]
+    rng = np.random.default_rng(8)
+    for trial in range(5):
+        n = int(rng.integers(2, 400))
+        pp = np.cumsum(rng.integers(1, 5000, size=n)).astype(np.int64) + 1000
+        gp = np.cumsum(rng.uniform(0.0, 0.01, size=n))
+        mapfile = str(tmp_path / f"m{trial}.map")
+        with open(mapfile, "w") as f:
+            for a, b in zip(pp, gp):
+                f.write(f"chrT rs{a} {b:.10f} {a}\n")
+        q = np.unique(np.concatenate([rng.integers(pp[0], pp[-1] + 1, size=300), pp[rng.integers(0, n, size=20)],
+                                      [pp[0], pp[-1]]]))
+        r = subprocess.run([exe, os.path.join(root, "oracle", "_ref", "libgarlic_ref.so"), mapfile, "chrT"] + [str(int(x)) for x in q],
+                           capture_output=True, text=True)
+        assert r.returncode == 0 and "map_unit ok" in r.stdout, (trial, (r.stdout + r.stderr)[-2000:])
