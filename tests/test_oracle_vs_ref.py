@@ -170,3 +170,33 @@ def test_genetic_map_interpolation_of_the_host_adapter(tmp_path):
         r = subprocess.run([exe, os.path.join(root, "oracle", "_ref", "libgarlic_ref.so"), mapfile, "chrT"] + [str(int(x)) for x in q],
                            capture_output=True, text=True)
         assert r.returncode == 0 and "map_unit ok" in r.stdout, (trial, (r.stdout + r.stderr)[-2000:])
+
+
+@pytest.mark.parametrize("gl_type", ["GQ", "GL", "PL"])
+def test_tgls_reader_of_the_host_adapter(tmp_path, gl_type):
+    """garlic_amd/host's readTGLSData, as doubles and as dictionary codes, against the reference's reader:
+    the conversions of garlic-data.cpp:1557-1576 incl. the clamps at 1e-16 and 1, bit for bit"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "tgls_unit")
+    libdir = os.path.join(root, "garlic_amd")
+    cc = subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-o", exe, os.path.join(root, "tests", "host_unit", "tgls_unit.cpp"),
+                         "-L" + libdir, "-lgarlic_host", "-lgarlic_hip", "-lz", "-ldl", "-Wl,-rpath," + libdir],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-3000:]
+    rng = np.random.default_rng({"GQ": 1, "GL": 2, "PL": 3}[gl_type])
+    nloci, nind = 300, 17
+    if gl_type == "GQ":
+        vals = rng.choice(np.concatenate([np.arange(0, 100), [150, 1000]]), size=(nloci, nind)).astype(float)
+    elif gl_type == "GL":
+        vals = rng.choice([-0.0004, -0.004, -0.3, -1.0, -3.0, -12.0, 0.0, 0.1], size=(nloci, nind))
+    else:
+        vals = rng.choice([0.004, 0.04, 3.0, 10.0, 30.0, 120.0, 0.0, -1.0], size=(nloci, nind))
+    path = str(tmp_path / "x.tgls")
+    with open(path, "w") as f:
+        for l in range(nloci):
+            f.write(f"1 rs{l} 0 {l + 1} " + " ".join(repr(float(v)) if gl_type != "GQ" else str(int(v)) for v in vals[l]) + "\n")
+    r = subprocess.run([exe, os.path.join(root, "oracle", "_ref", "libgarlic_ref.so"), path, gl_type, str(nloci), str(nind)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "tgls_unit ok" in r.stdout, (r.stdout + r.stderr)[-2000:]
