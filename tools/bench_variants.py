@@ -104,10 +104,24 @@ def main():
             ms.append(panel.stats()["chain_kernel_ms"])
         k = float(np.mean(ms))
         win = nloci * nind
-        print(json.dumps({"mode": mode, "snps": nloci, "inds": nind, "winsize": W, "kernel_ms": k,
-                          "sliding_windows_per_s": win / (k * 1e-3),
-                          "lod_windows_per_s": win / W / (k * 1e-3),
-                          "out_GBps": win * 8 / (k * 1e-3) / 1e9}))
+        line = {"mode": mode, "snps": nloci, "inds": nind, "winsize": W, "kernel_ms": k,
+                "sliding_windows_per_s": win / (k * 1e-3),
+                "lod_windows_per_s": win / W / (k * 1e-3),
+                "out_GBps": win * 8 / (k * 1e-3) / 1e9}
+        # what bounds the kernel: HBM bytes per sliding window for the chains,
+        # separately rounded FP64 multiply + add pairs for the weighted sums
+        if mode in ("lod", "tgls"):
+            per_win = 8.25 if mode == "lod" else 16.25
+            a = win * per_win / (k * 1e-3) / 1e9
+            line["roofline"] = {"bound": "hbm", "achieved": a, "peak": 8000.0, "unit": "GB/s", "frac": a / 8000.0,
+                                "algorithmic_bytes_per_window": per_win}
+        else:
+            pairs = win * W / (k * 1e-3)
+            line["roofline"] = {"bound": "fp64 valu (v_mul_f64 + v_add_f64 per term, no FMA)",
+                                "achieved": 2 * pairs / 1e12, "peak": 78.6 / 2, "unit": "TFLOP/s",
+                                "frac": 2 * pairs / 1e12 / (78.6 / 2),
+                                "measured_ceiling_TFLOPs": 35.8, "frac_of_measured_ceiling": 2 * pairs / 1e12 / 35.8}
+        print(json.dumps(line))
 
 
 if __name__ == "__main__":
