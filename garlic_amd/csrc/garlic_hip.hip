@@ -516,7 +516,12 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     const size_t wlod_rows = wlod_gl ? 0 : sizeof(double) * (size_t)(W + TILE) * 4;
     const size_t wlod_patch = sizeof(double) * (size_t)WAVE * WT_PITCH;
     const bool wlod_use_patch = wlod_rows + 16 + wlod_patch <= 160 * 1024 / 8;
-    const size_t wlod_lds = wlod_rows + 16 + (wlod_use_patch ? wlod_patch : 0);   // 16: the patch lock
+    // term-matrix variant: the hand-scheduled loop stages the block's term rows through one LDS ring
+    // per wave; it needs a block-aligned shard (a wave's 64 lanes = one block of the matrix)
+    const bool wlod_gl_ring = wlod_gl && (ind_begin & (WAVE - 1)) == 0 && !getenv("GARLIC_WLOD_GL_NO_RING");
+    const bool ring_patch = !getenv("GARLIC_WLOD_GL_NO_PATCH");
+    const size_t wlod_lds = wlod_gl_ring ? WLOD_GL_RING_OFF + (size_t)WLOD_WAVES * GARLIC_WLOD_GL_RING_ROWS * WAVE * 8
+                                         : wlod_rows + 16 + (wlod_use_patch ? wlod_patch : 0);   // 16: the patch lock
 
     // Host output: the device always computes into the padded layout the tuned kernels need; the
     // rows are copied out into the caller's (possibly dense) layout by strided D2H copies.
@@ -628,8 +633,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     if (wlod_fast) {
         const int nquad = (nblk + WLOD_WAVES - 1) / WLOD_WAVES;
         WlodArgs a{p->d_valid.p, p->d_chrs.p, p->d_tiles.p, p->nwordrows, p->nchr, ind_begin, ind_count, W, nquad,
-                   (uint32_t)((int64_t)p->plan.n_tiles * nquad), wlod_use_patch ? 1 : 0,
-                   (int64_t)(GOFF + p->nloci + GPAD_BACK)};
+                   (uint32_t)((int64_t)p->plan.n_tiles * nquad), (wlod_gl_ring ? ring_patch : wlod_use_patch) ? 1 : 0,
+                   (int64_t)(GOFF + p->nloci + GPAD_BACK), wlod_gl_ring ? 1 : 0};
         const uint32_t *a_packed = p->d_packed.p;
         const double *a_wtab = wlod_gl ? p->d_glterms.p : p->d_wtab.p, *a_skew = p->d_skew.p + SKEW_FRONT;
         const unsigned wl_grid = (a.n_work + 7u) / 8u * 8u;
@@ -641,7 +646,13 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                                                   : (const void *)wlod_tile_kernel<WLOD_R, false>);
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlod_lds));
         }
-        if (wlod_gl && aligned16)
+        if (wlod_gl_ring && aligned16)
+            hipLaunchKernelGGL((wlod_tile_glring_kernel<WLOD_R, true>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
+                               a_packed, a_wtab, a_skew, d_out, a);
+        else if (wlod_gl_ring)
+            hipLaunchKernelGGL((wlod_tile_glring_kernel<WLOD_R, false>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
+                               a_packed, a_wtab, a_skew, d_out, a);
+        else if (wlod_gl && aligned16)
             hipLaunchKernelGGL((wlod_tile_gl_kernel<WLOD_R, true>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
                                a_packed, a_wtab, a_skew, d_out, a);
         else if (wlod_gl)

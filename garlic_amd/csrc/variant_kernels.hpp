@@ -407,7 +407,11 @@ struct WlodArgs {
     uint32_t n_work;           // tiles x nquad
     int32_t use_patch;         // transposed write-out through the LDS patch (allocated then)
     int64_t score_rows;        // FROM_SCORES: SNP rows per 64-individual block of the term matrix
+    int32_t gl_ring;           // FROM_SCORES: hand-scheduled loop with per-wave LDS rings of term rows (allocated then)
 };
+// dynamic LDS of the term-matrix variant: patch lock (16 B) + patch [64][WT_PITCH] doubles, then, 1-KB
+// aligned, one ring of GARLIC_WLOD_GL_RING_ROWS x 512 B per wave
+constexpr uint32_t WLOD_GL_RING_OFF = (16u + 64u * 18u * 8u + 1023u) & ~1023u;
 
 // Ordered sums of windows s .. s+15 for this lane's individual: acc[r] = sum_j sc[s+r+j] * D[s+r+j][j],
 // j ascending from +0.0 (garlic-roh.cpp:255-272).  The whole loop is the hand-scheduled block of
@@ -437,6 +441,34 @@ __device__ __forceinline__ void wlod_group(const double *rows, const uint32_t *g
                    [word] "=&v"(word), [nextw] "=&v"(nextw), [gaddr] "+v"(gaddr), [bit] "+s"(bit),
                    [row] "+s"(row), [n] "+s"(n)
                  : [dp] "s"(dp), [stride] "s"(stride), [rowbytes] "s"((uint64_t)(WAVE * 4))
+                 : GARLIC_WLOD_LOOP_CLOBBERS);
+}
+
+// The same loop for per-genotype likelihoods (GARLIC_WLOD_GL_LOOP_ASM): the score of (SNP, lane) is the
+// lane's entry of the scaled TGLS term matrix.  The wave stages the block's 512-B rows through its
+// own LDS ring (LDS-DMA, two rows per request, GARLIC_WLOD_GL_RING_ROWS - 2 rows ahead) and reads
+// them with ds_read_b64 at row + lane * 8 where the plain loop looks a genotype up.
+//   ring_lds  LDS byte address of this wave's ring (1-KB aligned)
+//   trow      the block's row of SNP s in the term matrix (wave-uniform; 64 doubles per row)
+template <int R>
+__device__ __forceinline__ void wlod_group_gl(uint32_t ring_lds, const double *trow, int lane, const double *Ds, int W,
+                                              double (&acc)[R])
+{
+    static_assert(R == 16, "the hand-scheduled loop keeps 16 weights per step in SGPRs");
+    double sc, scn, t0, t1;
+    uint32_t vt, voff16 = (uint32_t)lane * 16u, rd = 0, wr = 0;
+    uint32_t n = (uint32_t)(W - (R - 1));
+    const uint32_t lane8b = ring_lds + (uint32_t)lane * 8u;
+    const double *dp = Ds - (R - 1);
+    const uint32_t stride = (uint32_t)(W + 1) * 8u;
+    asm volatile(GARLIC_WLOD_GL_LOOP_ASM
+                 : [a0] "=&v"(acc[0]), [a1] "=&v"(acc[1]), [a2] "=&v"(acc[2]), [a3] "=&v"(acc[3]),
+                   [a4] "=&v"(acc[4]), [a5] "=&v"(acc[5]), [a6] "=&v"(acc[6]), [a7] "=&v"(acc[7]),
+                   [a8] "=&v"(acc[8]), [a9] "=&v"(acc[9]), [a10] "=&v"(acc[10]), [a11] "=&v"(acc[11]),
+                   [a12] "=&v"(acc[12]), [a13] "=&v"(acc[13]), [a14] "=&v"(acc[14]), [a15] "=&v"(acc[15]),
+                   [sc] "=&v"(sc), [scn] "=&v"(scn), [t0] "=&v"(t0), [t1] "=&v"(t1), [vt] "=&v"(vt),
+                   [voff16] "+v"(voff16), [rd] "+s"(rd), [wr] "+s"(wr), [n] "+s"(n)
+                 : [dp] "s"(dp), [stride] "s"(stride), [lane8b] "v"(lane8b), [trow] "s"(trow), [rbase] "s"(ring_lds)
                  : GARLIC_WLOD_LOOP_CLOBBERS);
 }
 
@@ -499,7 +531,7 @@ __device__ __forceinline__ void wlod_group_scores(const double *tcol, int64_t G,
     }
 }
 
-template <int R, bool ALIGNED16, bool FROM_SCORES>
+template <int R, bool ALIGNED16, bool FROM_SCORES, bool GL_RING = false>
 __device__ __forceinline__ void
 wlod_tile_body(const uint32_t *__restrict__ packed,
                const double *__restrict__ wtab,   // [GOFF + nloci + pad][4]; FROM_SCORES: term matrix [blk][rows][64]
@@ -549,7 +581,14 @@ wlod_tile_body(const uint32_t *__restrict__ packed,
         double acc[R];
         const uint32_t gm = (vm >> (grp * R)) & ((1u << R) - 1u);
         if (gm != 0) {
-            if (FROM_SCORES)
+            if (GL_RING) {
+                // block-aligned shard (host-checked): the wave's 64 lanes are one block of the matrix
+                const int64_t blk = ((int64_t)p.ind_begin + ind0) >> 6;
+                const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)dyn +
+                                      WLOD_GL_RING_OFF + (uint32_t)wave * (GARLIC_WLOD_GL_RING_ROWS * WAVE * 8u);
+                wlod_group_gl<R>(ring, wtab + (blk * p.score_rows + (G0 + grp * R)) * WAVE, lane,
+                                 D + (c.loc_base + s0 + grp * R) * (int64_t)W, W, acc);
+            } else if (FROM_SCORES)
                 wlod_group_scores<R>(wtab + ((col >> 6) * p.score_rows) * WAVE + (col & 63), G0 + grp * R,
                                      D + (c.loc_base + s0 + grp * R) * (int64_t)W, W, acc);
             else
@@ -618,6 +657,15 @@ wlod_tile_kernel(const uint32_t *__restrict__ packed, const double *__restrict__
                  const double *__restrict__ D, double *__restrict__ out, WlodArgs p)
 {
     wlod_tile_body<R, ALIGNED16, false>(packed, wtab, D, out, p);
+}
+
+// ... and the hand-scheduled term-matrix variant (per-wave LDS rings): 64 VGPRs again
+template <int R, bool ALIGNED16>
+__global__ void __launch_bounds__(WLOD_WAVES * WAVE) __attribute__((amdgpu_num_vgpr(64)))
+wlod_tile_glring_kernel(const uint32_t *__restrict__ packed, const double *__restrict__ terms,
+                        const double *__restrict__ D, double *__restrict__ out, WlodArgs p)
+{
+    wlod_tile_body<R, ALIGNED16, true, true>(packed, terms, D, out, p);
 }
 
 template <int R, bool ALIGNED16>

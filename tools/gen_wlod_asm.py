@@ -51,10 +51,43 @@ def regs_of(parity):
     return ("A", "B", "sc", "scn") if parity == 0 else ("B", "A", "scn", "sc")
 
 
+# GL variant (per-genotype likelihoods): the score of (SNP, lane) is not a look-up by genotype but the
+# lane's own entry of the scaled TGLS term matrix, 512 B per SNP and 64-individual block.  The wave
+# keeps a ring of GL_RING rows in LDS, filled by LDS-DMA two rows (1 KB) per request GL_AHEAD rows
+# ahead of the step that reads them; LDS-DMA requests retire in order, so the waits are exact
+# vmcnt counts.  Operands instead of the genotype ones: [lane8b] = ring base + lane * 8 (VGPR),
+# [voff16] = lane * 16 (VGPR, advanced by 1 KB per request), [trow] = address of the block's row of SNP s (SGPR pair),
+# [rd] / [wr] = ring byte offsets of the next row to read / to fill (SGPRs), [rbase] = ring base.
+GL_RING = 8            # rows; the request for rows i+GL_AHEAD, +1 overwrites rows i-2, i-1
+GL_AHEAD = GL_RING - 2
+GL_MASK = GL_RING * 512 - 1
+
+
 class Gen:
-    def __init__(self):
+    def __init__(self, gl=False):
         self.out = []
         self.uid = 0
+        self.gl = gl
+
+    def gl_request(self):
+        """LDS-DMA of the next two term rows into the ring"""
+        e = self.e
+        e("s_add_u32 m0, %[rbase], %[wr]")
+        e("s_add_u32 %[wr], %[wr], 1024")
+        e(f"s_and_b32 %[wr], %[wr], {GL_MASK}")              # (also the wait state M0 needs before the DMA)
+        e("global_load_lds_dwordx4 %[voff16], %[trow]")
+        e("v_add_u32_e32 %[voff16], 0x400, %[voff16]")
+
+    def gl_read(self, dst, parity):
+        """score of the next step (row index of that step has the opposite parity of `parity`)"""
+        e = self.e
+        # requests issued after the one that brought the row: GL_AHEAD/2 when this step has just
+        # issued one (even steps), one less otherwise
+        e(f"s_waitcnt vmcnt({GL_AHEAD // 2 if parity == 0 else GL_AHEAD // 2 - 1})")
+        e("v_add_u32_e32 %[vt], %[rd], %[lane8b]")
+        e(f"ds_read_b64 %[{dst}], %[vt]")
+        e("s_add_u32 %[rd], %[rd], 512")
+        e(f"s_and_b32 %[rd], %[rd], {GL_MASK}")
 
     def e(self, s):
         self.out.append(s)
@@ -73,6 +106,11 @@ class Gen:
             e(f"s_addc_u32 s{S_DP + 1}, s{S_DP + 1}, 0")
             e(f"s_load_dwordx16 {tup(nxt, 0)}, s[{S_DP}:{S_DP + 1}], 0x0")
             e(f"s_load_dwordx16 {tup(nxt, 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
+        if prefetch and self.gl:
+            if parity == 0:
+                self.gl_request()
+            self.gl_read(scn, parity)
+        elif prefetch:
             e("v_bfe_u32 %[vt], %[word], %[bit], 2")
             e("v_lshl_add_u32 %[vt], %[vt], 3, %[row]")
             e(f"ds_read_b64 %[{scn}], %[vt]")
@@ -97,33 +135,45 @@ class Gen:
             e("s_waitcnt lgkmcnt(0)")
 
 
-def main():
-    g = Gen()
+def build(gl):
+    g = Gen(gl)
     e = g.e
     # ---- pipeline fill: weights and score of step 0
-    # (the lane's first two genotype words are requested here too, so that their latency overlaps
-    # with the first weights')
-    e("global_load_dword %[word], %[gaddr], off")
-    e("global_load_dword %[nextw], %[gaddr], off offset:256")
-    e(f"s_mov_b64 s[{S_DP}:{S_DP + 1}], %[dp]")
-    e(f"s_load_dwordx16 {tup('A', 0)}, s[{S_DP}:{S_DP + 1}], 0x0")
-    e(f"s_load_dwordx16 {tup('A', 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
-    e("v_lshl_add_u64 %[gaddr], %[gaddr], 0, %[rowbytes]")
-    e("v_lshl_add_u64 %[gaddr], %[gaddr], 0, %[rowbytes]")
-    e("s_waitcnt vmcnt(0)")
-    e("v_bfe_u32 %[vt], %[word], %[bit], 2")
-    e("v_lshl_add_u32 %[vt], %[vt], 3, %[row]")
-    e("ds_read_b64 %[sc], %[vt]")
-    e("s_add_u32 %[row], %[row], 32")
-    e("s_add_u32 %[bit], %[bit], 2")
-    e("s_cmp_eq_u32 %[bit], 32")
-    e("s_cbranch_scc0 WL_SAMEWORD_0_%=")
-    e("s_mov_b32 %[bit], 0")
-    g.switch_wait()
-    e("v_mov_b32_e32 %[word], %[nextw]")
-    e("global_load_dword %[nextw], %[gaddr], off")
-    e("v_lshl_add_u64 %[gaddr], %[gaddr], 0, %[rowbytes]")
-    e("WL_SAMEWORD_0_%=:")
+    if gl:
+        e(f"s_mov_b64 s[{S_DP}:{S_DP + 1}], %[dp]")
+        e(f"s_load_dwordx16 {tup('A', 0)}, s[{S_DP}:{S_DP + 1}], 0x0")
+        e(f"s_load_dwordx16 {tup('A', 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
+        for _ in range(GL_AHEAD // 2):                   # rows 0 .. GL_AHEAD-1
+            g.gl_request()
+        e(f"s_waitcnt vmcnt({GL_AHEAD // 2 - 1})")       # rows 0, 1 have landed
+        e("v_add_u32_e32 %[vt], %[rd], %[lane8b]")
+        e("ds_read_b64 %[sc], %[vt]")
+        e("s_add_u32 %[rd], %[rd], 512")
+        e(f"s_and_b32 %[rd], %[rd], {GL_MASK}")
+    else:
+        # (the lane's first two genotype words are requested here too, so that their latency overlaps
+        # with the first weights')
+        e("global_load_dword %[word], %[gaddr], off")
+        e("global_load_dword %[nextw], %[gaddr], off offset:256")
+        e(f"s_mov_b64 s[{S_DP}:{S_DP + 1}], %[dp]")
+        e(f"s_load_dwordx16 {tup('A', 0)}, s[{S_DP}:{S_DP + 1}], 0x0")
+        e(f"s_load_dwordx16 {tup('A', 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
+        e("v_lshl_add_u64 %[gaddr], %[gaddr], 0, %[rowbytes]")
+        e("v_lshl_add_u64 %[gaddr], %[gaddr], 0, %[rowbytes]")
+        e("s_waitcnt vmcnt(0)")
+        e("v_bfe_u32 %[vt], %[word], %[bit], 2")
+        e("v_lshl_add_u32 %[vt], %[vt], 3, %[row]")
+        e("ds_read_b64 %[sc], %[vt]")
+        e("s_add_u32 %[row], %[row], 32")
+        e("s_add_u32 %[bit], %[bit], 2")
+        e("s_cmp_eq_u32 %[bit], 32")
+        e("s_cbranch_scc0 WL_SAMEWORD_0_%=")
+        e("s_mov_b32 %[bit], 0")
+        g.switch_wait()
+        e("v_mov_b32_e32 %[word], %[nextw]")
+        e("global_load_dword %[nextw], %[gaddr], off")
+        e("v_lshl_add_u64 %[gaddr], %[gaddr], 0, %[rowbytes]")
+        e("WL_SAMEWORD_0_%=:")
     for r in range(R):
         e(f"v_mov_b64_e32 %[a{r}], 0")
     e("s_waitcnt lgkmcnt(0)")
@@ -149,25 +199,33 @@ def main():
         if first == 1:
             e("s_branch WL_DONE_%=")
     e("WL_DONE_%=:")
-    # the look-ahead genotype word requested at the last switch is never consumed: let it land
-    # before the compiler reuses its register (everything older retired long ago)
+    # whatever was requested ahead and never consumed (the look-ahead genotype word; the last term
+    # rows) lands before the compiler reuses its register / the ring
     e("s_waitcnt vmcnt(0)")
+    return g.out
 
+
+def main():
     here = os.path.dirname(os.path.abspath(__file__))
     path = os.path.join(here, "..", "garlic_amd", "csrc", "wlod_loop_gfx950.inc")
+    total = 0
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_wlod_asm.py -- do not edit; see that file for the schedule.\n")
         f.write("// wlod_group<16>: the ordered sums of 16 consecutive windows x 64 individuals, one SNP\n")
         f.write("// per step, the next step's weights and score requested before this step's FP64 work.\n")
-        f.write("#define GARLIC_WLOD_LOOP_ASM \\\n")
-        for ln in g.out:
-            f.write('    "%s\\n\\t" \\\n' % ln)
-        f.write('    ""\n')
+        f.write("// _GL: the score is the lane's entry of the scaled TGLS term matrix, through an LDS ring.\n")
+        f.write(f"#define GARLIC_WLOD_GL_RING_ROWS {GL_RING}\n")
+        for name, gl in (("GARLIC_WLOD_LOOP_ASM", False), ("GARLIC_WLOD_GL_LOOP_ASM", True)):
+            lines = build(gl)
+            total += sum(1 for x in lines if not x.endswith(":"))
+            f.write(f"#define {name} \\\n")
+            for ln in lines:
+                f.write('    "%s\\n\\t" \\\n' % ln)
+            f.write('    ""\n')
         regs = ['"s%d"' % r for r in range(S_DP, 100)] + ['"scc"', '"vcc"']
         f.write("#define GARLIC_WLOD_LOOP_CLOBBERS \\\n    ")
         f.write(", \\\n    ".join(", ".join(regs[i:i + 12]) for i in range(0, len(regs), 12)) + "\n")
-    n = sum(1 for x in g.out if not x.endswith(":"))
-    print(f"wrote {os.path.normpath(path)}: {n} instructions")
+    print(f"wrote {os.path.normpath(path)}: {total} instructions in two variants")
 
 
 if __name__ == "__main__":
