@@ -1,0 +1,31 @@
+"""CPU: the bench line committed under profiles/ (printed by bench.py under rocprofv3 on an MI355X) carries
+every field of the driver's contract, and its roofline object agrees with the rocprofv3 summary next to it."""
+import csv
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+
+
+def test_committed_bench_line_and_profile_agree():
+    line = json.load(open(os.path.join(PROF, "r01_bench_under_rocprof.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["vs_baseline"] is None and line["dtype"] == "f64" and line["data"] == "synthetic"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    # achieved = algorithmic bytes per launch / the kernel's HIP-event time
+    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["kernel_ms"] * 1e-3) / 1e9) < 1e-3 * roof["achieved"]
+    # ... and the rocprofv3 kernel-trace average of the same run agrees with that time
+    rows = list(csv.DictReader(open(os.path.join(PROF, "r01_kernel_stats.csv"))))
+    chain = [r for r in rows if "lod_chain_kernel" in r["Name"]][0]
+    assert abs(float(chain["AverageNs"]) * 1e-6 - roof["kernel_ms"]) < 0.03 * roof["kernel_ms"]
+    pmc = json.load(open(os.path.join(PROF, "r01_pmc_traffic.json")))
+    assert abs(pmc["hbm_bytes_per_launch"] - roof["algorithmic_bytes_per_launch"]) < 0.05 * roof["algorithmic_bytes_per_launch"]
