@@ -128,3 +128,27 @@ def test_variants_200k_by_1000_sampled_parity(gpu_ctx):
                 else:
                     want = ol.oracle_calc_lod(g, *args, *cen, W, 0.001, mg, gl=np.ascontiguousarray(gl_s[lo:hi]))
                 assert ol.bits_equal(blk[sample].cpu().numpy(), want), (name, c)
+
+
+@pytest.mark.parametrize("W,step", [(100, 100), (50, 50), (100, 7)])
+def test_c2_thinned_feed_equals_feed_of_full_scores(c2_panel, W, step):
+    """at C2 size (1M SNPs x 1000 individuals): the feed the chain kernel thins itself
+    (garlic_lod_feed) == convertWinData2DoubleData of the full scores (garlic_lod_flatten on the
+    device), value for value -- two independent write-out paths of the same chain"""
+    import torch
+    spec, panel, sample, geno_s = c2_panel
+    nind = 1000
+    base, pitch, total = panel.out_layout(32, nind)
+    dev = torch.device("cuda", 0)
+    out = torch.empty((total,), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    panel.lod_windows_device(out.data_ptr(), W, 0.001, 200000, pitch_align=32)
+    cap = int(sum((int(n) + step - 1) // step for n in spec.chr_nloci)) * nind
+    feed_dev = torch.empty((cap,), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    n = panel.flatten_device(out.data_ptr(), step, feed_dev.data_ptr(), cap)
+    torch.cuda.synchronize()
+    want = feed_dev[:n].cpu().numpy()
+    got, per_chr = panel.lod_feed(W, 0.001, 200000, step, copy=False)
+    assert got.shape[0] == n == int(per_chr.sum())
+    assert ol.bits_equal(got, want)
