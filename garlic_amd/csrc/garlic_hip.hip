@@ -1319,7 +1319,12 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
             hipLaunchKernelGGL(ld_pair_phased_kernel, dim3((unsigned)p->chr_nloci[c]), dim3(256), 0, s, d_m.p,
                                d_h.p, d_o.p, p->d_phase.p, nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1],
                                winsize, pair);
-        else
+        else if (winsize - 1 <= 256 && !getenv("GARLIC_LD_PAIR_L2")) {
+            const int threads = (winsize - 1 + WAVE - 1) / WAVE * WAVE;
+            hipLaunchKernelGGL(ld_pair_tiled_kernel, dim3((unsigned)((p->chr_nloci[c] + LD_PAIR_T - 1) / LD_PAIR_T)),
+                               dim3(threads), sizeof(uint64_t) * 2 * LD_PAIR_BLK * (LD_PAIR_T + winsize - 1), s, d_m.p,
+                               d_h.p, nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1], winsize, pair);
+        } else
             hipLaunchKernelGGL(ld_pair_kernel, dim3((unsigned)p->chr_nloci[c]), dim3(256), 0, s, d_m.p, d_h.p,
                                nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1], winsize, pair);
     }

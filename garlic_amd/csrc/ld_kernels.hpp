@@ -110,6 +110,63 @@ ld_pair_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__
     }
 }
 
+// The same counts from LDS: ld_pair_kernel streams four plane words per (pair, block) from L2 and is
+// bound by that (30 % of the LD time at 10M SNPs x 1250).  Here one workgroup owns LD_PAIR_T
+// consecutive SNPs i and thread d-1 their partners i + d: the {M, H} words of the SNPs
+// i0 .. i0+T+W-2 are staged LD_PAIR_BLK blocks at a time, the counts of the thread's T pairs stay in
+// registers across the chunks.  Partner words: consecutive threads, consecutive 16-B entries; the
+// SNP's own words: one broadcast.
+constexpr int LD_PAIR_T = 32;
+constexpr int LD_PAIR_BLK = 8;
+__global__ void __launch_bounds__(256)
+ld_pair_tiled_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__ planeH, int nblk,
+                     int64_t nloci, int64_t lo, int64_t hi, int W, int32_t *__restrict__ pair)
+{
+    extern __shared__ uint64_t ld_planes[];                    // [LD_PAIR_BLK][T + W - 1][2] = {M, H}
+    const int span = LD_PAIR_T + W - 1;
+    const int64_t i0 = lo + (int64_t)blockIdx.x * LD_PAIR_T;
+    const int ni = (int)min<int64_t>(LD_PAIR_T, hi - i0);      // SNPs i of this tile
+    const int nsnp = (int)min<int64_t>(span, hi - i0);         // staged SNPs that exist
+    const int d = 1 + (int)threadIdx.x;                        // blockDim.x >= W - 1
+    int32_t tot[LD_PAIR_T], hab[LD_PAIR_T];
+#pragma unroll
+    for (int q = 0; q < LD_PAIR_T; q++) { tot[q] = 0; hab[q] = 0; }
+    for (int b0 = 0; b0 < nblk; b0 += LD_PAIR_BLK) {
+        const int nb = min(LD_PAIR_BLK, nblk - b0);
+        __syncthreads();
+        for (int b = 0; b < nb; b++)
+            for (int x = threadIdx.x; x < nsnp; x += blockDim.x) {
+                const int64_t g = (int64_t)(b0 + b) * nloci + i0 + x;
+                ld_planes[(b * span + x) * 2 + 0] = planeM[g];
+                ld_planes[(b * span + x) * 2 + 1] = planeH[g];
+            }
+        __syncthreads();
+        if (d < W) {
+#pragma unroll
+            for (int q = 0; q < LD_PAIR_T; q++) {
+                if (q + d >= nsnp) continue;                   // partner outside the chromosome: stays 0
+                int32_t t = 0, h = 0;
+                for (int b = 0; b < nb; b++) {
+                    const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(ld_planes + (b * span + q) * 2);
+                    const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(ld_planes + (b * span + q + d) * 2);
+                    t += __popcll(a.x & c.x);
+                    h += __popcll(a.y & c.y);
+                }
+                tot[q] += t;
+                hab[q] += h;
+            }
+        }
+    }
+    if (d < W) {
+#pragma unroll
+        for (int q = 0; q < LD_PAIR_T; q++) {
+            if (q >= ni) continue;
+            pair[((i0 + q) * W + d) * 2 + 0] = tot[q];           // pairs leaving the chromosome stay 0
+            pair[((i0 + q) * W + d) * 2 + 1] = hab[q];
+        }
+    }
+}
+
 // --phased pair counts: pair = {2 * #(both non-missing), x11}  (r2, garlic-data.cpp:592-606)
 __global__ void __launch_bounds__(256)
 ld_pair_phased_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__ planeT,
