@@ -1314,17 +1314,29 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
     else
         hipLaunchKernelGGL(ld_planes_kernel<false>, dim3((unsigned)p->nwordrows), dim3(256), 0, s, p->d_packed.p,
                            p->nwordrows, nblk, d_sub.p, p->nloci, d_m.p, d_h.p, (uint64_t *)nullptr, loc);
+    // pair counts: LDS-tiled (thread = distance, W - 1 <= 256) or streamed from L2
+    const bool pair_tiled = winsize - 1 <= 256 && !getenv("GARLIC_LD_PAIR_L2");
+    const int pair_threads = (winsize - 1 + WAVE - 1) / WAVE * WAVE;
+    const size_t pair_lds = sizeof(uint64_t) * (phased ? 4 : 2) * LD_PAIR_BLK * (LD_PAIR_T + winsize - 1);
+    if (pair_tiled && pair_lds > 48 * 1024) {
+        const void *fn = phased ? (const void *)ld_pair_tiled_kernel<true> : (const void *)ld_pair_tiled_kernel<false>;
+        hipError_t ae = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds);
+        if (ae != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(ae)));
+    }
     for (int c = 0; c < p->nchr; c++) {
-        if (phased)
+        const unsigned tiles = (unsigned)((p->chr_nloci[c] + LD_PAIR_T - 1) / LD_PAIR_T);
+        if (pair_tiled && phased)
+            hipLaunchKernelGGL(ld_pair_tiled_kernel<true>, dim3(tiles), dim3(pair_threads), pair_lds, s, d_m.p, d_h.p,
+                               d_o.p, p->d_phase.p, nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1], winsize, pair);
+        else if (pair_tiled)
+            hipLaunchKernelGGL(ld_pair_tiled_kernel<false>, dim3(tiles), dim3(pair_threads), pair_lds, s, d_m.p, d_h.p,
+                               (const uint64_t *)nullptr, (const uint64_t *)nullptr, nblk, p->nloci, p->chr_off[c],
+                               p->chr_off[c + 1], winsize, pair);
+        else if (phased)
             hipLaunchKernelGGL(ld_pair_phased_kernel, dim3((unsigned)p->chr_nloci[c]), dim3(256), 0, s, d_m.p,
                                d_h.p, d_o.p, p->d_phase.p, nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1],
                                winsize, pair);
-        else if (winsize - 1 <= 256 && !getenv("GARLIC_LD_PAIR_L2")) {
-            const int threads = (winsize - 1 + WAVE - 1) / WAVE * WAVE;
-            hipLaunchKernelGGL(ld_pair_tiled_kernel, dim3((unsigned)((p->chr_nloci[c] + LD_PAIR_T - 1) / LD_PAIR_T)),
-                               dim3(threads), sizeof(uint64_t) * 2 * LD_PAIR_BLK * (LD_PAIR_T + winsize - 1), s, d_m.p,
-                               d_h.p, nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1], winsize, pair);
-        } else
+        else
             hipLaunchKernelGGL(ld_pair_kernel, dim3((unsigned)p->chr_nloci[c]), dim3(256), 0, s, d_m.p, d_h.p,
                                nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1], winsize, pair);
     }

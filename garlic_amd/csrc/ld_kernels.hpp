@@ -118,11 +118,16 @@ ld_pair_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__
 // SNP's own words: one broadcast.
 constexpr int LD_PAIR_T = 32;
 constexpr int LD_PAIR_BLK = 8;
+// PHASED: four planes per SNP -- {M, T ("genotype 2"), O ("genotype 1"), F (firstCopy)} -- and the
+// counts {2 * #(both non-missing), x11} of r2 (garlic-data.cpp:592-606)
+template <bool PHASED>
 __global__ void __launch_bounds__(256)
-ld_pair_tiled_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__ planeH, int nblk,
+ld_pair_tiled_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__ planeH,
+                     const uint64_t *__restrict__ planeO, const uint64_t *__restrict__ planeF, int nblk,
                      int64_t nloci, int64_t lo, int64_t hi, int W, int32_t *__restrict__ pair)
 {
-    extern __shared__ uint64_t ld_planes[];                    // [LD_PAIR_BLK][T + W - 1][2] = {M, H}
+    constexpr int NP = PHASED ? 4 : 2;
+    extern __shared__ uint64_t ld_planes[];                    // [LD_PAIR_BLK][T + W - 1][NP]
     const int span = LD_PAIR_T + W - 1;
     const int64_t i0 = lo + (int64_t)blockIdx.x * LD_PAIR_T;
     const int ni = (int)min<int64_t>(LD_PAIR_T, hi - i0);      // SNPs i of this tile
@@ -137,8 +142,10 @@ ld_pair_tiled_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__rest
         for (int b = 0; b < nb; b++)
             for (int x = threadIdx.x; x < nsnp; x += blockDim.x) {
                 const int64_t g = (int64_t)(b0 + b) * nloci + i0 + x;
-                ld_planes[(b * span + x) * 2 + 0] = planeM[g];
-                ld_planes[(b * span + x) * 2 + 1] = planeH[g];
+                uint64_t *e = ld_planes + (size_t)(b * span + x) * NP;
+                e[0] = planeM[g];
+                e[1] = planeH[g];
+                if (PHASED) { e[2] = planeO[g]; e[3] = planeF[g]; }
             }
         __syncthreads();
         if (d < W) {
@@ -147,10 +154,19 @@ ld_pair_tiled_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__rest
                 if (q + d >= nsnp) continue;                   // partner outside the chromosome: stays 0
                 int32_t t = 0, h = 0;
                 for (int b = 0; b < nb; b++) {
-                    const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(ld_planes + (b * span + q) * 2);
-                    const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(ld_planes + (b * span + q + d) * 2);
-                    t += __popcll(a.x & c.x);
-                    h += __popcll(a.y & c.y);
+                    const uint64_t *a = ld_planes + (size_t)(b * span + q) * NP, *c = a + (size_t)d * NP;
+                    const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(a);
+                    const ulonglong2 c0 = *reinterpret_cast<const ulonglong2 *>(c);
+                    if (PHASED) {
+                        const ulonglong2 a1 = *reinterpret_cast<const ulonglong2 *>(a + 2);
+                        const ulonglong2 c1 = *reinterpret_cast<const ulonglong2 *>(c + 2);
+                        t += 2 * __popcll(a0.x & c0.x);
+                        h += 2 * __popcll(a0.y & c0.y) + __popcll(a1.x & c0.y) + __popcll(a0.y & c1.x) +
+                             __popcll(a1.x & c1.x & ~(a1.y ^ c1.y));
+                    } else {
+                        t += __popcll(a0.x & c0.x);
+                        h += __popcll(a0.y & c0.y);
+                    }
                 }
                 tot[q] += t;
                 hab[q] += h;
