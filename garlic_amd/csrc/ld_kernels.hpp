@@ -49,29 +49,39 @@ ld_planes_kernel(const uint32_t *__restrict__ packed, int64_t nwordrows, int nbl
     const int64_t w = blockIdx.x;
     const int64_t l0 = w * 16 - GOFF;           // unpadded global index of the word's first SNP
     int32_t hom = 0, tot = 0;                    // lane q < 16 owns SNP l0 + q
-    for (int blk = wave; blk < nblk; blk += 4) {
-        const uint32_t word = packed[(blk * nwordrows + w) * WAVE + lane];
-        const uint64_t sub = submask[blk];
+    // the wave's blocks eight at a time, their words requested together (one trip to memory per
+    // eight blocks instead of one per block)
+    for (int blk0 = wave; blk0 < nblk; blk0 += 32) {
+        uint32_t words[8];
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const uint32_t code = (word >> (2 * q)) & 3u;
-            const uint64_t m = __ballot(code != 3u);
-            const uint64_t h = __ballot(code == 0u || code == 2u);
-            if (lane == q) {
-                hom += __popcll(h);
-                tot += __popcll(m);
+        for (int u = 0; u < 8; u++)
+            words[u] = packed[((int64_t)min(blk0 + 4 * u, nblk - 1) * nwordrows + w) * WAVE + lane];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int blk = blk0 + 4 * u;
+            if (blk >= nblk) break;
+            const uint32_t word = words[u];
+            const uint64_t sub = submask[blk];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const uint32_t code = (word >> (2 * q)) & 3u;
+                const uint64_t m = __ballot(code != 3u);
+                const uint64_t h = __ballot(code == 0u || code == 2u);
                 const int64_t l = l0 + q;
-                if (l >= 0 && l < nloci) {
-                    planeM[(int64_t)blk * nloci + l] = m & sub;
-                    if (!PHASED) planeH[(int64_t)blk * nloci + l] = h & sub;
+                if (lane == q) {
+                    hom += __popcll(h);
+                    tot += __popcll(m);
+                    if (l >= 0 && l < nloci) {
+                        planeM[(int64_t)blk * nloci + l] = m & sub;
+                        if (!PHASED) planeH[(int64_t)blk * nloci + l] = h & sub;
+                    }
                 }
-            }
-            if (PHASED) {
-                const uint64_t two = __ballot(code == 2u), one = __ballot(code == 1u);
-                const int64_t l = l0 + q;
-                if (lane == q && l >= 0 && l < nloci) {
-                    planeH[(int64_t)blk * nloci + l] = two & sub;
-                    planeO[(int64_t)blk * nloci + l] = one & sub;
+                if (PHASED) {
+                    const uint64_t two = __ballot(code == 2u), one = __ballot(code == 1u);
+                    if (lane == q && l >= 0 && l < nloci) {
+                        planeH[(int64_t)blk * nloci + l] = two & sub;
+                        planeO[(int64_t)blk * nloci + l] = one & sub;
+                    }
                 }
             }
         }
