@@ -171,10 +171,11 @@ struct garlic_panel {
         DevBuf<int32_t> loc, pair;
         DevBuf<double> hf, fwd, bwd, ld;
         DevBuf<LdSumChr> sum_chrs;
+        DevBuf<LdPairChr> pair_chrs;
         void release()
         {
             sub.release(); m.release(); h.release(); o.release(); loc.release(); pair.release();
-            hf.release(); fwd.release(); bwd.release(); ld.release(); sum_chrs.release();
+            hf.release(); fwd.release(); bwd.release(); ld.release(); sum_chrs.release(); pair_chrs.release();
         }
     } lds;
     // tuned wLOD path: skewed reciprocal weights, per-SNP score rows, window mask, tile index
@@ -1323,16 +1324,30 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
         hipError_t ae = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds);
         if (ae != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(ae)));
     }
-    for (int c = 0; c < p->nchr; c++) {
-        const unsigned tiles = (unsigned)((p->chr_nloci[c] + LD_PAIR_T - 1) / LD_PAIR_T);
-        if (pair_tiled && phased)
-            hipLaunchKernelGGL(ld_pair_tiled_kernel<true>, dim3(tiles), dim3(pair_threads), pair_lds, s, d_m.p, d_h.p,
-                               d_o.p, p->d_phase.p, nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1], winsize, pair);
-        else if (pair_tiled)
-            hipLaunchKernelGGL(ld_pair_tiled_kernel<false>, dim3(tiles), dim3(pair_threads), pair_lds, s, d_m.p, d_h.p,
-                               (const uint64_t *)nullptr, (const uint64_t *)nullptr, nblk, p->nloci, p->chr_off[c],
-                               p->chr_off[c + 1], winsize, pair);
-        else if (phased)
+    if (pair_tiled) {   // all chromosomes in one grid
+        std::vector<LdPairChr> pc;
+        int64_t blocks = 0;
+        for (int c = 0; c < p->nchr; c++) {
+            pc.push_back(LdPairChr{p->chr_off[c], p->chr_off[c + 1], blocks});
+            blocks += (p->chr_nloci[c] + LD_PAIR_T - 1) / LD_PAIR_T;
+        }
+        DevBuf<LdPairChr> &d_pc = p->lds.pair_chrs;
+        if ((rc = d_pc.reserve(pc.size()))) return done(rc);
+        e = hipMemcpyAsync(d_pc.p, pc.data(), sizeof(LdPairChr) * pc.size(), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
+        if (phased)
+            hipLaunchKernelGGL(ld_pair_tiled_kernel<true>, dim3((unsigned)blocks), dim3(pair_threads), pair_lds, s, d_m.p,
+                               d_h.p, d_o.p, p->d_phase.p, nblk, p->nloci, d_pc.p, p->nchr, winsize, pair);
+        else
+            hipLaunchKernelGGL(ld_pair_tiled_kernel<false>, dim3((unsigned)blocks), dim3(pair_threads), pair_lds, s, d_m.p,
+                               d_h.p, (const uint64_t *)nullptr, (const uint64_t *)nullptr, nblk, p->nloci, d_pc.p,
+                               p->nchr, winsize, pair);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s);   // pc (host) is read by the copy above
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
+    }
+    for (int c = 0; !pair_tiled && c < p->nchr; c++) {
+        if (phased)
             hipLaunchKernelGGL(ld_pair_phased_kernel, dim3((unsigned)p->chr_nloci[c]), dim3(256), 0, s, d_m.p,
                                d_h.p, d_o.p, p->d_phase.p, nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1],
                                winsize, pair);

@@ -130,16 +130,23 @@ constexpr int LD_PAIR_T = 32;
 constexpr int LD_PAIR_BLK = 8;
 // PHASED: four planes per SNP -- {M, T ("genotype 2"), O ("genotype 1"), F (firstCopy)} -- and the
 // counts {2 * #(both non-missing), x11} of r2 (garlic-data.cpp:592-606)
+struct LdPairChr {       // one chromosome's share of the grid (all chromosomes in one launch)
+    int64_t lo, hi;      // its SNPs
+    int64_t block0;      // its first workgroup
+};
 template <bool PHASED>
 __global__ void __launch_bounds__(256)
 ld_pair_tiled_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__ planeH,
                      const uint64_t *__restrict__ planeO, const uint64_t *__restrict__ planeF, int nblk,
-                     int64_t nloci, int64_t lo, int64_t hi, int W, int32_t *__restrict__ pair)
+                     int64_t nloci, const LdPairChr *__restrict__ chrs, int nchr, int W, int32_t *__restrict__ pair)
 {
     constexpr int NP = PHASED ? 4 : 2;
     extern __shared__ uint64_t ld_planes[];                    // [LD_PAIR_BLK][T + W - 1][NP]
     const int span = LD_PAIR_T + W - 1;
-    const int64_t i0 = lo + (int64_t)blockIdx.x * LD_PAIR_T;
+    int c = 0;
+    while (c + 1 < nchr && (int64_t)blockIdx.x >= chrs[c + 1].block0) c++;
+    const int64_t lo = chrs[c].lo, hi = chrs[c].hi;
+    const int64_t i0 = lo + ((int64_t)blockIdx.x - chrs[c].block0) * LD_PAIR_T;
     const int ni = (int)min<int64_t>(LD_PAIR_T, hi - i0);      // SNPs i of this tile
     const int nsnp = (int)min<int64_t>(span, hi - i0);         // staged SNPs that exist
     const int d = 1 + (int)threadIdx.x;                        // blockDim.x >= W - 1
