@@ -389,7 +389,14 @@ int ensure_gl_terms(garlic_panel *p, bool scaled = false, int32_t M = 0, double 
     const size_t n = (size_t)rows * p->nind_pad;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GARLIC_OK;
-    if (p->d_glterms.cap < n && n * sizeof(double) + ((size_t)8 << 30) > free_b) return GARLIC_OK;
+    if (p->d_glterms.cap < n && n * sizeof(double) + ((size_t)8 << 30) > free_b) {
+        // not enough room: the LD scratch the panel keeps for the next window size is worth less
+        // than the term matrix (the look-up-in-the-chain kernel is 10x slower)
+        HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+        p->lds.release();
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GARLIC_OK;
+        if (n * sizeof(double) + ((size_t)8 << 30) > free_b) return GARLIC_OK;
+    }
     int rc;
     if ((rc = p->d_glterms.reserve(n))) return rc;
     hipStream_t s = p->ctx->stream;
