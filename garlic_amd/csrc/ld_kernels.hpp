@@ -308,9 +308,9 @@ ld_sum_kernel(const double *__restrict__ fwd, const double *__restrict__ bwd, in
 // condition on q -- adds C_i[(s0+q+k) - i + W-1]: consecutive lanes read consecutive doubles.  The
 // terms of one accumulator arrive in the order i = s .. s+W-1, from 0.0, as in ldHR2
 // (garlic-data.cpp:521-527).
-constexpr int LD_SUM_B = 64;
+constexpr int LD_SUM_B = 32;   // 64 keeps the ramps shorter but costs occupancy (128 registers of accumulators): 19.4 vs 17.2 ms
 constexpr int LD_SUM_AHEAD = 4;
-constexpr int LD_SUM_MAX_W = 256;                              // one thread per column; 64 accumulators need the registers
+constexpr int LD_SUM_MAX_W = 256;                              // one thread per column
 struct LdSumChr {        // one chromosome's share of the grid
     int64_t lo;          // global index of its first SNP
     int64_t nstarts;     // window starts with a full window (>= 1)
