@@ -28,7 +28,7 @@ SYMBOLS = [
     "garlic_panel_compute_ld", "garlic_ld_counts", "garlic_ld_finish", "garlic_roh_coverage",
     "garlic_panel_release_scratch",
     "garlic_lod_feed", "garlic_ctx_set_async",
-    "garlic_recent_kernel_ms",
+    "garlic_recent_kernel_ms", "garlic_panel_tgls_mode", "garlic_lod_feed_subset",
 ]
 
 
@@ -51,7 +51,7 @@ _i64p = C.POINTER(C.c_int64)
 _f64p = C.POINTER(C.c_double)
 
 
-ABI_VERSION = 2   # GARLIC_HIP_ABI_VERSION of include/garlic_hip.h these bindings were written against
+ABI_VERSION = 3   # GARLIC_HIP_ABI_VERSION of include/garlic_hip.h these bindings were written against
 
 
 def lib():
@@ -100,6 +100,9 @@ def lib():
                                   C.c_double, C.c_int32, _vp, C.c_int64, _i64p, _i64p]
     L.garlic_roh_coverage.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, _vp, C.c_int32,
                                       C.c_int32]
+    L.garlic_lod_feed_subset.argtypes = [_vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_double, C.c_int32, _i32p, C.c_int32, _vp, C.c_int64, _i64p, _i64p]
+    L.garlic_panel_tgls_mode.argtypes = [_vp, _i32p, _i32p]
     for name in SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int and name not in ("garlic_hip_abi_version",):
@@ -260,10 +263,15 @@ class Panel:
 
     @staticmethod
     def _sub(sub_idx):
+        """None = every individual; an array = exactly those, an EMPTY array = none of them (a shard
+        that holds no member of a panel-wide subsample): the pointer must then still be non-NULL"""
         if sub_idx is None:
             return None, 0
         sub = np.ascontiguousarray(sub_idx, dtype=np.int32)
-        return sub, int(sub.shape[0])
+        n = int(sub.shape[0])
+        if n == 0:
+            sub = np.zeros(1, dtype=np.int32)
+        return sub, n
 
     def compute_ld(self, winsize, sub_idx=None, want_output=True, phased=False):
         """calcHR2LD (phased: calcR2LD) on the device (sub_idx: the --ld-subsample individuals,
@@ -368,10 +376,14 @@ class Panel:
                                        _vp(feed_ptr) if feed_ptr else None, feed_capacity, C.byref(n)))
         return n.value
 
-    def lod_feed(self, winsize, error, max_gap, step, use_gl=False, weighted=False, M=7, mu=1e-9, copy=True):
+    def lod_feed(self, winsize, error, max_gap, step, use_gl=False, weighted=False, M=7, mu=1e-9, copy=True,
+                 ind_idx=None):
         """scores + thinning on the device: returns (feed float64 [count], per-chromosome counts).
-        copy=False: the feed is a view of a buffer the panel object reuses for the next call."""
-        cap = int(sum((int(n) + step - 1) // step for n in self.chr_nloci)) * self.nind
+        copy=False: the feed is a view of a buffer the panel object reuses for the next call.
+        ind_idx: only these individuals, in this order (convertSubsetWinData2DoubleData, --kde-subsample)"""
+        idx = None if ind_idx is None else np.ascontiguousarray(ind_idx, dtype=np.int32)
+        n_rows = self.nind if idx is None else int(idx.shape[0])
+        cap = int(sum((int(n) + step - 1) // step for n in self.chr_nloci)) * n_rows
         if copy:
             feed = np.empty(max(cap, 1), dtype=np.float64)
         else:
@@ -380,9 +392,17 @@ class Panel:
             feed = self._feed_buf
         n = C.c_int64()
         per_chr = np.zeros(self.nchr, dtype=np.int64)
-        check(lib().garlic_lod_feed(self.handle, winsize, error, max_gap, int(use_gl), int(weighted), M, mu,
-                                    step, _vp(feed.ctypes.data), cap, C.byref(n), _ptr(per_chr, _i64p)))
+        check(lib().garlic_lod_feed_subset(self.handle, winsize, error, max_gap, int(use_gl), int(weighted), M, mu,
+                                           step, _ptr(idx, _i32p), 0 if idx is None else n_rows,
+                                           _vp(feed.ctypes.data), cap, C.byref(n), _ptr(per_chr, _i64p)))
         return (feed[: n.value].copy() if copy else feed[: n.value]), per_chr
+
+    def tgls_mode(self):
+        """(mode, terms_by): mode 0 none / 1 dictionary codes / 2 continuous values; terms_by 0 tabulated or
+        nothing yet / 1 device log10 / 2 host libm"""
+        mode, by = C.c_int32(), C.c_int32()
+        check(lib().garlic_panel_tgls_mode(self.handle, C.byref(mode), C.byref(by)))
+        return mode.value, by.value
 
     def roh_coverage(self, scores_ptr, winsize, cutoff, pitch_align=32, nind_out=None):
         """assembleROHWindows' coverage counts of device-resident scores: list of per-chromosome int16

@@ -110,6 +110,10 @@ struct garlic_ctx {
     static constexpr int HIST = 32;
     hipEvent_t hist0[HIST] = {}, hist1[HIST] = {};
     int64_t n_calls = 0;
+    // glibc's log table on the device (tgls_math.hpp) and the verdict of the start-up comparison of
+    // the device's log10 with the host's: 0 not run yet, 1 identical on every probe, -1 differs
+    DevBuf<double> d_logtab;
+    int log10_state = 0;
 };
 
 struct garlic_panel {
@@ -158,6 +162,16 @@ struct garlic_panel {
     double glterms_mu = 0.0;
 
     int tabgl_ncodes = 0;
+    // TGLS, continuous likelihoods (more distinct values than the dictionary holds): the error
+    // probabilities themselves, in the term matrix's layout, and lod() on the device
+    bool gl_cont = false;
+    DevBuf<double> d_glval;                        // [blk][GOFF+nloci+pad][64]; empty once converted in place
+    bool gl_vals_dropped = false;                  // d_glterms owns what was d_glval: terms cannot be rebuilt
+    bool gl_cover_required = false;                // after a restart of the upload: every locus must come again
+    std::vector<uint8_t> gl_cover;                 // loci uploaded since then
+    DevBuf<double> d_freq;                         // [GOFF+nloci+pad], pad rows 0
+    bool dfreq_valid = false;
+    int gl_terms_by = 0;                           // who built the current terms: 1 device log10, 2 host libm
     // wLOD
     bool have_ld = false, wlod_use_gl = false;
     int32_t ld_winsize = 0;
@@ -203,6 +217,7 @@ struct garlic_panel {
         size_t n_items = 0, n_fill = 0;
         bool wlod_fast = false;
         int32_t thin_step = 0;
+        uint64_t blocks_hash = 0;                  // 0: every 64-individual block; else a hash of the block subset
         int32_t n_tiles = 0;
         int64_t n_runs = 0, n_valid = 0;
     } plan;
@@ -375,40 +390,263 @@ int ensure_gl_table(garlic_panel *p)
     return GARLIC_OK;
 }
 
+// ---- TGLS with continuous likelihoods: glibc's log table on the device, checked against the host
+// Probes: both binades __ieee754_log10 hands to log (random mantissas), a dense band around 1 (the
+// polynomial branch and its borders), every table cell's ends, random exponents, subnormals and the
+// special values.  One kernel, ~2e5 values; the verdict is kept with the context.
+int ensure_log10(garlic_ctx *ctx)
+{
+    if (ctx->log10_state != 0) return GARLIC_OK;
+    static const double tab[256] = GLIBC_LOG_TAB;
+    int rc;
+    if ((rc = ctx->d_logtab.reserve(256))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->d_logtab.p, tab, sizeof tab, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<double> in;
+    uint64_t st = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    auto bits = [](uint64_t u) { double d; memcpy(&d, &u, sizeof d); return d; };
+    for (double x : {0.0, -0.0, 1.0, -1.0, (double)INFINITY, -(double)INFINITY, (double)NAN, 5e-324, 2.2250738585072014e-308,
+                     1.7976931348623157e308, 0.5, 2.0, 10.0, 1e-16})
+        in.push_back(x);
+    in.push_back(bits(0xFFF8000000000000ull));
+    in.push_back(bits(0x7FF0000000000001ull));
+    for (uint64_t c : {0x3FEE000000000000ull, 0x3FF1090000000000ull, 0x3FF0000000000000ull, 0x3FE6000000000000ull,
+                       0x3FF6000000000000ull, 0x0010000000000000ull})
+        for (int d = -16; d <= 16; d++) in.push_back(bits(c + (uint64_t)(int64_t)d));
+    for (int cell = 0; cell < 128; cell++)
+        for (uint64_t top : {0x3FE0000000000000ull, 0x3FF0000000000000ull})
+            for (int d = -2; d <= 2; d++) in.push_back(bits(top + ((uint64_t)cell << 45) + (uint64_t)(int64_t)d));
+    for (int k = 0; k < 40000; k++) {
+        const uint64_t m = next() & 0x000FFFFFFFFFFFFFull;
+        in.push_back(bits(0x3FE0000000000000ull | m));
+        in.push_back(bits(0x3FF0000000000000ull | m));
+        in.push_back(bits((0x3FF0000000000000ull - (1ull << 49)) + (next() % (3ull << 49))));
+        in.push_back(bits(((next() % 2046 + 1) << 52) | m));
+        if ((k & 63) == 0) in.push_back(bits(m));
+    }
+    const int64_t n = (int64_t)in.size();
+    DevBuf<double> d_in, d_out;
+    auto done = [&](int code) { d_in.release(); d_out.release(); return code; };
+    if ((rc = d_in.reserve((size_t)n)) || (rc = d_out.reserve((size_t)n))) return done(rc);
+    std::vector<double> out((size_t)n);
+    hipError_t e = hipMemcpyAsync(d_in.p, in.data(), sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(log10_probe_kernel, dim3(256), dim3(256), 0, ctx->stream, d_in.p, ctx->d_logtab.p, n, d_out.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out.p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "log10 probe: %s", hipGetErrorString(e)));
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const double want = log10(in[(size_t)i]);
+        if (memcmp(&want, &out[(size_t)i], sizeof want) != 0) bad++;
+    }
+    ctx->log10_state = bad == 0 ? 1 : -1;
+    if (bad)
+        fprintf(stderr, "libgarlic_hip: the host's log10 is not the glibc 2.35 FMA variant the device restates "
+                        "(%lld of %lld probes differ); continuous TGLS terms will be computed on the host\n",
+                (long long)bad, (long long)n);
+    return done(GARLIC_OK);
+}
+
+// allele frequencies on the device, in padded row order (pad rows 0 -> term +0.0)
+int ensure_dfreq(garlic_panel *p)
+{
+    if (p->dfreq_valid) return GARLIC_OK;
+    const int64_t rows = GOFF + p->nloci + GPAD_BACK;
+    std::vector<double> f((size_t)rows, 0.0);
+    memcpy(f.data() + GOFF, p->freq.data(), sizeof(double) * (size_t)p->nloci);
+    int rc;
+    if ((rc = p->d_freq.reserve((size_t)rows))) return rc;
+    HIP_TRY(hipMemcpyAsync(p->d_freq.p, f.data(), sizeof(double) * rows, hipMemcpyHostToDevice, p->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    p->dfreq_valid = true;
+    return GARLIC_OK;
+}
+
+// The dictionary is full (or the caller's values are continuous from the start): from here on the
+// panel keeps the error probabilities themselves.  What has been coded so far is decoded.
+int switch_to_continuous(garlic_panel *p)
+{
+    if (p->gl_cont) return GARLIC_OK;
+    const int64_t rows = GOFF + p->nloci + GPAD_BACK;
+    const size_t n = (size_t)rows * p->nind_pad;
+    hipStream_t s = p->ctx->stream;
+    int rc;
+    if ((rc = p->d_glval.reserve(n))) return rc;
+    if (p->d_codes.p && !p->gl_values.empty()) {
+        std::vector<double> dict(GL_DICT_MAX, 0.0);
+        std::copy(p->gl_values.begin(), p->gl_values.end(), dict.begin());
+        DevBuf<double> d_dict;
+        if ((rc = d_dict.reserve(GL_DICT_MAX))) return rc;
+        hipError_t e = hipMemcpyAsync(d_dict.p, dict.data(), sizeof(double) * GL_DICT_MAX, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(gl_decode_kernel, dim3(4096), dim3(256), 0, s, p->d_codes.p, d_dict.p, p->nind_pad, rows,
+                               p->d_glval.p);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        d_dict.release();
+        if (e != hipSuccess) return fail(GARLIC_ERR_HIP, "set_gl: %s", hipGetErrorString(e));
+    } else {
+        HIP_TRY(hipMemsetAsync(p->d_glval.p, 0, sizeof(double) * n, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    p->d_codes.release();
+    p->d_tabgl.release();
+    p->gl_code.clear();
+    p->gl_values.clear();
+    p->tabgl_valid = false;
+    p->gl_cont = true;
+    p->gl_vals_dropped = false;
+    p->glterms_valid = false;
+    return GARLIC_OK;
+}
+
+// A new upload after the values were converted in place: the matrix goes back to holding values, all
+// zero, and every locus has to come again before the next computation.
+int restart_continuous_upload(garlic_panel *p)
+{
+    if (!p->gl_cont || !p->gl_vals_dropped) return GARLIC_OK;
+    const int64_t rows = GOFF + p->nloci + GPAD_BACK;
+    const size_t n = (size_t)rows * p->nind_pad;
+    HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+    std::swap(p->d_glval.p, p->d_glterms.p);
+    std::swap(p->d_glval.cap, p->d_glterms.cap);
+    HIP_TRY(hipMemsetAsync(p->d_glval.p, 0, sizeof(double) * n, p->ctx->stream));
+    p->gl_vals_dropped = false;
+    p->glterms_valid = false;
+    p->gl_cover_required = true;
+    p->gl_cover.assign((size_t)p->nloci, 0);
+    return GARLIC_OK;
+}
+
+// terms from values on the host, with the host's own log10: the fallback when the device's restatement
+// of glibc's log10 does not reproduce this host's libm (ensure_log10), or GARLIC_TGLS_HOST_TERMS is set
+int build_terms_on_host(garlic_panel *p, const double *vals, double *terms)
+{
+    const int64_t rows = GOFF + p->nloci + GPAD_BACK;
+    const int nblk = (int)(p->nind_pad / WAVE);
+    const int64_t chunk = std::max<int64_t>(16, (((int64_t)128 << 20) / (8 * WAVE * nblk)) & ~(int64_t)15);
+    std::vector<double> hv((size_t)chunk * WAVE * nblk);
+    std::vector<uint32_t> hw((size_t)(chunk / 16 + 2) * WAVE * nblk);
+    hipStream_t s = p->ctx->stream;
+    const double *freq = p->freq.data();
+    for (int64_t G0 = GOFF; G0 < GOFF + p->nloci; G0 += chunk) {
+        const int64_t G1 = std::min<int64_t>(GOFF + p->nloci, G0 + chunk), nr = G1 - G0;
+        const int64_t w0 = G0 >> 4, nw = ((G1 - 1) >> 4) - w0 + 1;
+        for (int b = 0; b < nblk; b++) {
+            HIP_TRY(hipMemcpyAsync(hv.data() + (size_t)b * chunk * WAVE, vals + ((int64_t)b * rows + G0) * WAVE,
+                                   sizeof(double) * nr * WAVE, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(hw.data() + (size_t)b * (chunk / 16 + 2) * WAVE,
+                                   p->d_packed.p + ((int64_t)b * p->nwordrows + w0) * WAVE, sizeof(uint32_t) * nw * WAVE,
+                                   hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        double *hvp = hv.data();
+        const uint32_t *hwp = hw.data();
+        parallel_for(nr * nblk, 256, [=](int64_t lo, int64_t hi) {
+            for (int64_t k = lo; k < hi; k++) {
+                const int64_t b = k / nr, r = k % nr, G = G0 + r;
+                double *v = hvp + ((size_t)b * chunk + r) * WAVE;
+                const uint32_t *w = hwp + ((size_t)b * (chunk / 16 + 2) + ((G >> 4) - w0)) * WAVE;
+                const double f = freq[G - GOFF];
+                for (int lane = 0; lane < WAVE; lane++) {
+                    const uint32_t code = (w[lane] >> (2 * (int)(G & 15))) & 3u;
+                    v[lane] = host_lod(code == 3u ? -9 : (int)code, f, v[lane]);
+                }
+            }
+        });
+        for (int b = 0; b < nblk; b++)
+            HIP_TRY(hipMemcpyAsync(terms + ((int64_t)b * rows + G0) * WAVE, hv.data() + (size_t)b * chunk * WAVE,
+                                   sizeof(double) * nr * WAVE, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return GARLIC_OK;
+}
+
 // ---- TGLS pass 1: every (SNP, individual) term, once per panel (window-size independent).
-// Returns GARLIC_OK with glterms_valid unset when the matrix does not fit: the caller then keeps
-// the look-up-in-the-chain kernel.
-// TGLS term matrix; scaled = multiplied in place by the decay factors of (M, mu) for the weighted
-// tile kernel (ensure_decay_table first).  Switching between the two forms rebuilds / rescales.
+// Dictionary-coded likelihoods: returns GARLIC_OK with glterms_valid unset when the matrix does not
+// fit -- the caller then keeps the look-up-in-the-chain kernel.  Continuous likelihoods always end
+// with a valid matrix (converted in place when a second buffer does not fit) or an error.
+// scaled = multiplied in place by the decay factors of (M, mu) for the weighted tile kernel
+// (ensure_decay_table first).  Switching between the two forms rebuilds / rescales.
 int ensure_gl_terms(garlic_panel *p, bool scaled = false, int32_t M = 0, double mu = 0.0)
 {
     const bool same_scale = p->glterms_scaled && p->glterms_M == M && memcmp(&p->glterms_mu, &mu, sizeof mu) == 0;
     if (p->glterms_valid && (scaled ? same_scale : !p->glterms_scaled)) return GARLIC_OK;
-    if (getenv("GARLIC_GL_NO_TERMS")) return GARLIC_OK;
+    if (!p->gl_cont && getenv("GARLIC_GL_NO_TERMS")) return GARLIC_OK;
     const int64_t rows = GOFF + p->nloci + GPAD_BACK;
     const size_t n = (size_t)rows * p->nind_pad;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GARLIC_OK;
-    if (p->d_glterms.cap < n && n * sizeof(double) + ((size_t)8 << 30) > free_b) {
-        // not enough room: the LD scratch the panel keeps for the next window size is worth less
-        // than the term matrix (the look-up-in-the-chain kernel is 10x slower)
-        HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-        p->lds.release();
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GARLIC_OK;
-        if (n * sizeof(double) + ((size_t)8 << 30) > free_b) return GARLIC_OK;
-    }
-    int rc;
-    if ((rc = p->d_glterms.reserve(n))) return rc;
     hipStream_t s = p->ctx->stream;
-    if (!p->glterms_valid || p->glterms_scaled) {   // (re)build the raw terms
+    int rc;
+    const bool rebuild = !p->glterms_valid || p->glterms_scaled;   // the raw terms have to be made (again)
+    if (p->gl_cont && rebuild) {
+        if (p->gl_vals_dropped)
+            return fail(GARLIC_ERR_STATE, "the likelihoods of this panel were converted to terms in place (no room for "
+                                          "both); after changing genotypes, frequencies or the weighting they "
+                                          "have to be uploaded again (garlic_panel_set_gl over all loci)");
+        if (p->gl_cover_required) {
+            for (int64_t l = 0; l < p->nloci; l++)
+                if (!p->gl_cover[(size_t)l])
+                    return fail(GARLIC_ERR_STATE, "likelihood upload restarted: locus %lld has not been uploaded again",
+                                (long long)l);
+            p->gl_cover_required = false;
+        }
+        if ((rc = ensure_log10(p->ctx)) || (rc = ensure_dfreq(p))) return rc;
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        // a second matrix only while it leaves plenty of room for the scores (it is what lets the panel
+        // switch between raw and weighted terms later); otherwise the values become the terms
+        bool separate = p->d_glterms.cap >= n ||
+                        (free_b >= n * sizeof(double) && free_b - n * sizeof(double) >= (size_t)(0.45 * (double)total_b));
+        if (const char *e = getenv("GARLIC_TGLS_INPLACE")) separate = atoi(e) == 0;
+        if (separate && (rc = p->d_glterms.reserve(n))) return rc;
+        double *dst = separate ? p->d_glterms.p : p->d_glval.p;
+        p->glterms_valid = false;
+        const bool on_host = p->ctx->log10_state < 0 || getenv("GARLIC_TGLS_HOST_TERMS");
+        if (separate)   // pad rows of the term matrix: +0.0
+            HIP_TRY(hipMemsetAsync(dst, 0, sizeof(double) * n, s));
+        if (on_host) {
+            if ((rc = build_terms_on_host(p, p->d_glval.p, dst))) return rc;
+        } else {
+            // all rows, pad rows included: their frequency is 0 and their genotypes code 3 -> +0.0
+            hipLaunchKernelGGL(gl_terms_cont_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)(p->nind_pad / WAVE)),
+                               dim3(256), 0, s, p->d_packed.p, p->nwordrows, p->d_freq.p, p->ctx->d_logtab.p, p->d_glval.p,
+                               (int64_t)0, rows, rows, dst);
+            HIP_TRY(hipGetLastError());
+        }
+        if (!separate) {   // the term matrix takes the buffer over
+            HIP_TRY(hipStreamSynchronize(s));
+            p->d_glterms.release();
+            std::swap(p->d_glterms.p, p->d_glval.p);
+            std::swap(p->d_glterms.cap, p->d_glval.cap);
+            p->gl_vals_dropped = true;
+        }
+        p->gl_terms_by = on_host ? 2 : 1;
+        p->glterms_scaled = false;
+    } else if (rebuild) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GARLIC_OK;
+        if (p->d_glterms.cap < n && n * sizeof(double) + ((size_t)8 << 30) > free_b) {
+            // not enough room: the LD scratch the panel keeps for the next window size is worth less
+            // than the term matrix (the look-up-in-the-chain kernel is 10x slower)
+            HIP_TRY(hipStreamSynchronize(s));
+            p->lds.release();
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GARLIC_OK;
+            if (n * sizeof(double) + ((size_t)8 << 30) > free_b) return GARLIC_OK;
+        }
+        if ((rc = p->d_glterms.reserve(n))) return rc;
         p->glterms_valid = false;
         HIP_TRY(hipMemsetAsync(p->d_glterms.p, 0, sizeof(double) * n, s));
         VariantArgs a{p->d_packed.p, nullptr, p->d_tabgl.p, p->d_codes.p, nullptr, nullptr, nullptr, nullptr, nullptr,
-                      p->nind_pad, p->nwordrows, 0, 0, 0, (int32_t)p->gl_values.size(), 1};
+                      p->nind_pad, p->nwordrows, 0, 0, 0, (int32_t)p->gl_values.size(), 1, nullptr, 0};
         hipLaunchKernelGGL(gl_terms_kernel, dim3((unsigned)((p->nloci + 63) / 64), (unsigned)(p->nind_pad / WAVE)),
                            dim3(256), 0, s, a, p->nloci, rows, p->d_glterms.p);
         HIP_TRY(hipGetLastError());
         p->glterms_scaled = false;
+        p->gl_terms_by = 0;
     }
     if (scaled) {
         hipLaunchKernelGGL(gl_scale_kernel, dim3(4096), dim3(256), 0, s, p->d_glterms.p, p->d_decay.p, rows,
@@ -482,8 +720,9 @@ int ensure_score_rows(garlic_panel *p, double error, int32_t M, double mu, int32
 // 0, thin_step, 2 * thin_step, .. of each chromosome, everything else of that matrix is MISSING.
 int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_gap, int32_t M, double mu,
                int32_t ind_begin, int32_t ind_count, int32_t pitch_align, double *out, int32_t where,
-               int32_t thin_step = 0)
-{
+               int32_t thin_step = 0, const std::vector<uint8_t> *blocks = nullptr)
+{   // blocks (chain kernels only): per 64-individual block of the call, 1 = score it; rows of the other
+    // blocks are left unwritten (the subset feed never reads them)
     garlic_ctx *ctx = p->ctx;
     int rc;
     if ((rc = set_device(ctx))) return rc;
@@ -502,7 +741,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     if ((rc = ensure_segments(p, max_gap))) return rc;
     if (use_gl) {
         if (!p->have_gl) return fail(GARLIC_ERR_STATE, "use_gl set but no genotype likelihoods were given");
-        if ((rc = ensure_gl_table(p))) return rc;
+        if (!p->gl_cont && (rc = ensure_gl_table(p))) return rc;
         if (mode == MODE_LOD_GL && (rc = ensure_gl_terms(p))) return rc;
     } else if ((rc = ensure_term_table(p, error))) return rc;
     if (mode == MODE_WLOD) {
@@ -520,6 +759,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     bool wlod_fast = (wlod_shape_ok && !use_gl) || wlod_gl;                 // tile kernel, either variant
     if (wlod_fast && !wlod_gl && sizeof(double) * (size_t)(W + TILE) * 4 + 16 > 150 * 1024) wlod_fast = false;
     if (wlod_fast && !wlod_gl && (rc = ensure_score_rows(p, error, M, mu, W))) return rc;
+    // continuous likelihoods have no code table: the generic kernel takes its terms from the raw matrix
+    if (mode == MODE_WLOD && use_gl && p->gl_cont && !wlod_fast && (rc = ensure_gl_terms(p))) return rc;
     // transposed write-out patch only while rows + patch keep 8 workgroups (32 waves) on a CU
     const size_t wlod_rows = wlod_gl ? 0 : sizeof(double) * (size_t)(W + TILE) * 4;
     const size_t wlod_patch = sizeof(double) * (size_t)WAVE * WT_PITCH;
@@ -540,7 +781,13 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         if (3 * L.pitch[c] * 8 + 512 >= (int64_t)1 << 32)
             return fail(GARLIC_ERR_INVALID, "chromosome %d too long for 32-bit row offsets", c);
 
-    const bool reuse = p->plan.valid && p->plan.mode == (int)mode && p->plan.W == W &&
+    uint64_t blocks_hash = 0;
+    if (blocks) {
+        blocks_hash = 0xCBF29CE484222325ull;
+        for (uint8_t b : *blocks) blocks_hash = (blocks_hash ^ (b ? 1u : 2u)) * 0x100000001B3ull;
+        blocks_hash |= 1;
+    }
+    const bool reuse = p->plan.valid && p->plan.blocks_hash == blocks_hash && p->plan.mode == (int)mode && p->plan.W == W &&
                        p->plan.max_gap == max_gap && p->plan.ind_begin == ind_begin &&
                        p->plan.ind_count == ind_count && p->plan.pitch_align == pitch_align &&
                        p->plan.wlod_fast == wlod_fast && p->plan.thin_step == thin_step;
@@ -564,7 +811,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         items.reserve(runs.size() * nblk);
         for (size_t i = 0; i < order.size(); i++) {
             const Run &r = runs[order[i]];
-            for (int k = 0; k < nblk; k++) items.push_back(ChainItem{r.chr, r.a, r.b, k * WAVE});
+            for (int k = 0; k < nblk; k++)
+                if (!blocks || (*blocks)[(size_t)k]) items.push_back(ChainItem{r.chr, r.a, r.b, k * WAVE});
         }
         chrs.resize(p->nchr);
         for (int c = 0; c < p->nchr; c++)
@@ -705,7 +953,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     } else if (n_items) {
         VariantArgs a{p->d_packed.p, p->d_tab.p,  p->d_tabgl.p, p->d_codes.p, p->d_decay.p, p->d_rld.p,
                       p->d_items.p,  p->d_chrs.p, d_out,        p->nind_pad,  p->nwordrows, ind_begin,    ind_count,
-                      W,             (int32_t)p->gl_values.size(), use_gl ? 1 : 0};
+                      W,             (int32_t)p->gl_values.size(), use_gl ? 1 : 0,
+                      (use_gl && p->gl_cont) ? p->d_glterms.p : nullptr, (int64_t)(GOFF + p->nloci + GPAD_BACK)};
         if (mode == MODE_LOD_GL && p->glterms_valid && !p->glterms_scaled) {
             hipLaunchKernelGGL(lod_chain_terms_kernel, dim3((unsigned)n_items), dim3(2 * WAVE), 0, ctx->stream, a,
                                (int)n_items, (int64_t)(GOFF + p->nloci + GPAD_BACK), p->d_glterms.p);
@@ -749,7 +998,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     p->plan.valid = true;
     p->plan.mode = (int)mode; p->plan.W = W; p->plan.max_gap = max_gap; p->plan.ind_begin = ind_begin;
     p->plan.ind_count = ind_count; p->plan.pitch_align = pitch_align;
-    p->plan.wlod_fast = wlod_fast; p->plan.thin_step = thin_step;
+    p->plan.wlod_fast = wlod_fast; p->plan.thin_step = thin_step; p->plan.blocks_hash = blocks_hash;
     p->plan.n_items = n_items; p->plan.n_fill = n_fill; p->plan.n_runs = n_runs; p->plan.n_valid = n_valid;
     st.n_valid_windows = n_valid;
     st.n_missing = p->nloci - n_valid;
@@ -835,6 +1084,7 @@ int garlic_ctx_destroy(garlic_ctx *ctx)
         if (ctx->hist0[i]) (void)hipEventDestroy(ctx->hist0[i]);
         if (ctx->hist1[i]) (void)hipEventDestroy(ctx->hist1[i]);
     }
+    ctx->d_logtab.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return GARLIC_OK;
@@ -902,7 +1152,7 @@ int garlic_panel_destroy(garlic_panel *p)
     p->d_blk_offsets.release(); p->d_total.release(); p->d_boundaries.release();
     p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release(); p->d_row_counts.release(); p->d_codes.release(); p->d_tabgl.release();
     p->d_rld.release(); p->d_decay.release(); p->d_stage64.release(); p->d_phase.release(); p->lds.release();
-    p->d_glterms.release(); p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release();
+    p->d_glterms.release(); p->d_glval.release(); p->d_freq.release(); p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release();
     p->d_out.release(); p->d_feed.release();
     delete p;
     return GARLIC_OK;
@@ -932,6 +1182,7 @@ int garlic_panel_set_map(garlic_panel *p, const int32_t *pos, const double *gpos
     p->seg_valid = false;
     p->decay_valid = false;
     p->plan.valid = false;
+    if (p->glterms_scaled) p->glterms_valid = false;   // (term * nomut) * norec of the old positions
     return GARLIC_OK;
 }
 
@@ -943,6 +1194,7 @@ int garlic_panel_set_freq(garlic_panel *p, const double *freq)
     p->tab_valid = false;
     p->tabgl_valid = false;
     p->glterms_valid = false;
+    p->dfreq_valid = false;
     return GARLIC_OK;
 }
 
@@ -1045,14 +1297,18 @@ int garlic_panel_set_gl(garlic_panel *p, const double *gl, int64_t ld, int64_t l
     if ((rc = set_device(p->ctx))) return rc;
     hipStream_t s = p->ctx->stream;
     const int64_t rows_total = GOFF + p->nloci + GPAD_BACK;
-    if (!p->d_codes.p) {
+    if ((rc = restart_continuous_upload(p))) return rc;
+    if (!p->gl_cont && getenv("GARLIC_TGLS_CONTINUOUS") && (rc = switch_to_continuous(p))) return rc;
+    if (!p->gl_cont && !p->d_codes.p) {
         if ((rc = p->d_codes.reserve((size_t)(rows_total * p->nind_pad)))) return rc;
         HIP_TRY(hipMemsetAsync(p->d_codes.p, 0, (size_t)(rows_total * p->nind_pad), s));
     }
-    // distinct error probabilities -> one-byte codes (the term table needs the host libm).  Coded on
-    // the device against the dictionary so far; values it does not know come back, join the
-    // dictionary and the slab is coded again (a hash look-up per genotype on the host took minutes
-    // at 1e10 genotypes).
+    // Few distinct error probabilities (GQ / PL integers) -> one-byte codes: the term table per (SNP,
+    // code, genotype) comes from the host libm and the panel keeps 1 B instead of 8 B per genotype.
+    // Coded on the device against the dictionary so far; values it does not know come back, join the
+    // dictionary and the slab is coded again (a hash look-up per genotype on the host took minutes at
+    // 1e10 genotypes).  When the dictionary is full (256 values: --gl-type GL, continuous inputs) the
+    // panel switches to keeping the values themselves and evaluates lod() on the device.
     constexpr int UNK_CAP = 8192;
     DevBuf<double> stage;
     DevBuf<uint64_t> d_bits, d_unk;
@@ -1073,7 +1329,7 @@ int garlic_panel_set_gl(garlic_panel *p, const double *gl, int64_t ld, int64_t l
             e = hipMemcpyAsync(stage.p, src, sizeof(double) * nrows * ld, hipMemcpyHostToDevice, s);
             src = stage.p;
         }
-        while (e == hipSuccess) {   // until the slab holds no value outside the dictionary
+        while (e == hipSuccess && !p->gl_cont) {   // until the slab holds no value outside the dictionary
             // dictionary, sorted by bit pattern
             std::vector<std::pair<uint64_t, uint8_t>> dict;
             for (auto &kv : p->gl_code) dict.emplace_back(kv.first, (uint8_t)kv.second);
@@ -1101,10 +1357,10 @@ int garlic_panel_set_gl(garlic_panel *p, const double *gl, int64_t ld, int64_t l
             for (int k = 0; k < got; k++) {
                 if (p->gl_code.count(unk[k])) continue;
                 const int code = (int)p->gl_values.size();
-                if (code >= GL_DICT_MAX)
-                    return done(fail(GARLIC_ERR_INVALID,
-                                     "more than 256 distinct genotype-likelihood values: the dictionary "
-                                     "TGLS path of this build needs quantised inputs (GQ / PL integers)"));
+                if (code >= GL_DICT_MAX) {       // continuous inputs: keep values, not codes
+                    if ((rc = switch_to_continuous(p))) return done(rc);
+                    break;
+                }
                 double v;
                 memcpy(&v, &unk[k], sizeof v);
                 p->gl_code.emplace(unk[k], code);
@@ -1112,8 +1368,16 @@ int garlic_panel_set_gl(garlic_panel *p, const double *gl, int64_t ld, int64_t l
                 p->tabgl_valid = false;
             }
         }
+        if (e == hipSuccess && p->gl_cont) {
+            hipLaunchKernelGGL(gl_store_kernel, dim3(2048), dim3(256), 0, s, src, ld, locus_begin + at, nrows, p->nind,
+                               rows_total, p->d_glval.p);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(s);          // the staging slab is free again
+        }
         if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "set_gl: %s", hipGetErrorString(e)));
     }
+    if (p->gl_cont && !p->gl_cover.empty())
+        memset(p->gl_cover.data() + locus_begin, 1, (size_t)locus_count);
     p->have_gl = true;
     p->glterms_valid = false;
     return done(GARLIC_OK);
@@ -1132,30 +1396,48 @@ int garlic_panel_set_gl_codes(garlic_panel *p, const uint8_t *codes, int64_t ld,
     if ((rc = set_device(p->ctx))) return rc;
     hipStream_t s = p->ctx->stream;
     const int64_t rows_total = GOFF + p->nloci + GPAD_BACK;
-    if (!p->d_codes.p) {
-        if ((rc = p->d_codes.reserve((size_t)(rows_total * p->nind_pad)))) return rc;
-        HIP_TRY(hipMemsetAsync(p->d_codes.p, 0, (size_t)(rows_total * p->nind_pad), s));
-    }
-    // the caller's table joins the panel's dictionary; its codes are translated on the device
+    if ((rc = restart_continuous_upload(p))) return rc;
+    if (!p->gl_cont && getenv("GARLIC_TGLS_CONTINUOUS") && (rc = switch_to_continuous(p))) return rc;
+    // the caller's table joins the panel's dictionary; its codes are translated on the device.  A
+    // panel whose tables add up to more than 256 values keeps the values themselves from then on.
     uint8_t remap[256] = {0};
-    for (int k = 0; k < nvalues; k++) {
+    for (int k = 0; k < nvalues && !p->gl_cont; k++) {
         uint64_t bits;
         memcpy(&bits, &values[k], sizeof bits);
         auto it = p->gl_code.find(bits);
         if (it == p->gl_code.end()) {
             const int code = (int)p->gl_values.size();
-            if (code >= GL_DICT_MAX)
-                return fail(GARLIC_ERR_INVALID, "more than 256 distinct genotype-likelihood values in one panel");
+            if (code >= GL_DICT_MAX) {
+                if (!p->d_codes.p) {   // nothing coded yet: start from an empty value matrix
+                    p->gl_code.clear();
+                    p->gl_values.clear();
+                }
+                if ((rc = switch_to_continuous(p))) return rc;
+                break;
+            }
             it = p->gl_code.emplace(bits, code).first;
             p->gl_values.push_back(values[k]);
             p->tabgl_valid = false;
         }
         remap[k] = (uint8_t)it->second;
     }
+    if (!p->gl_cont && !p->d_codes.p) {
+        if ((rc = p->d_codes.reserve((size_t)(rows_total * p->nind_pad)))) return rc;
+        HIP_TRY(hipMemsetAsync(p->d_codes.p, 0, (size_t)(rows_total * p->nind_pad), s));
+    }
     DevBuf<uint8_t> stage, d_remap;
-    auto done = [&](int code) { stage.release(); d_remap.release(); return code; };
-    if ((rc = d_remap.reserve(256))) return done(rc);
-    hipError_t e = hipMemcpyAsync(d_remap.p, remap, 256, hipMemcpyHostToDevice, s);
+    DevBuf<double> d_dict;
+    auto done = [&](int code) { stage.release(); d_remap.release(); d_dict.release(); return code; };
+    hipError_t e = hipSuccess;
+    if (p->gl_cont) {
+        std::vector<double> dict(GL_DICT_MAX, 0.0);
+        std::copy(values, values + nvalues, dict.begin());
+        if ((rc = d_dict.reserve(GL_DICT_MAX))) return done(rc);
+        e = hipMemcpy(d_dict.p, dict.data(), sizeof(double) * GL_DICT_MAX, hipMemcpyHostToDevice);
+    } else {
+        if ((rc = d_remap.reserve(256))) return done(rc);
+        e = hipMemcpy(d_remap.p, remap, 256, hipMemcpyHostToDevice);
+    }
     const int64_t slab_rows = (where == GARLIC_HOST) ? std::max<int64_t>(16, ((int64_t)256 << 20) / ld) : locus_count;
     for (int64_t at = 0; e == hipSuccess && at < locus_count; at += slab_rows) {
         const int64_t nrows = std::min(slab_rows, locus_count - at);
@@ -1166,12 +1448,18 @@ int garlic_panel_set_gl_codes(garlic_panel *p, const uint8_t *codes, int64_t ld,
             src = stage.p;
         }
         if (e != hipSuccess) break;
-        hipLaunchKernelGGL(gl_recode_kernel, dim3(2048), dim3(256), 0, s, src, ld, nrows, p->nind, p->nind_pad, d_remap.p,
-                           p->d_codes.p + (GOFF + locus_begin + at) * p->nind_pad);
+        if (p->gl_cont)
+            hipLaunchKernelGGL(gl_store_codes_kernel, dim3(2048), dim3(256), 0, s, src, ld, locus_begin + at, nrows, p->nind,
+                               d_dict.p, rows_total, p->d_glval.p);
+        else
+            hipLaunchKernelGGL(gl_recode_kernel, dim3(2048), dim3(256), 0, s, src, ld, nrows, p->nind, p->nind_pad, d_remap.p,
+                               p->d_codes.p + (GOFF + locus_begin + at) * p->nind_pad);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipStreamSynchronize(s);                      // staging slab (and remap) free again
+        if (e == hipSuccess) e = hipStreamSynchronize(s);                      // staging slab free again
     }
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "set_gl_codes: %s", hipGetErrorString(e)));
+    if (p->gl_cont && !p->gl_cover.empty())
+        memset(p->gl_cover.data() + locus_begin, 1, (size_t)locus_count);
     p->have_gl = true;
     p->glterms_valid = false;
     return done(GARLIC_OK);
@@ -1285,12 +1573,14 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
     if ((rc = ld_check(p, winsize, phased))) return rc;
     if (!locus_counts || !pair_counts) return fail(GARLIC_ERR_INVALID, "count buffers are required");
     if (n_sub < 0 || (n_sub > 0 && !sub_idx)) return fail(GARLIC_ERR_INVALID, "bad LD subsample");
+    // sub_idx == NULL: every individual; otherwise exactly the n_sub listed ones -- none when n_sub is 0
+    // (a shard that holds no member of a panel-wide subsample)
     hipStream_t s = p->ctx->stream;
     const int nblk = (int)(p->nind_pad / WAVE);
     // LD subsample as one bit per individual (order and repeats do not matter for counts of a set;
     // the reference draws distinct indices, garlic-data.cpp:361-362)
     std::vector<uint64_t> sub((size_t)nblk, 0);
-    if (n_sub == 0) {
+    if (!sub_idx) {
         for (int i = 0; i < p->nind; i++) sub[i >> 6] |= (uint64_t)1 << (i & 63);
     } else {
         for (int k = 0; k < n_sub; k++) {
@@ -1541,8 +1831,8 @@ int garlic_wlod_windows(garlic_panel *p, int32_t winsize, double error, int32_t 
 // sample); else the full score matrix, sampled every `step` loci
 static int flatten_impl(garlic_panel *p, const double *scores, int32_t pitch_align, int32_t nind_out,
                         int32_t step, double *feed, int64_t feed_capacity, int64_t *count, int64_t *chr_counts,
-                        int32_t thinned = 0)
-{
+                        int32_t thinned = 0, const int32_t *d_ind_list = nullptr, int32_t n_list = 0)
+{   // d_ind_list (device): the rows of the feed, in this order inside every chromosome; NULL: 0 .. nind_out-1
     if (!p || !scores || !count) return fail(GARLIC_ERR_INVALID, "panel, scores and count are required");
     if (step < 1 || pitch_align < 1 || nind_out < 1)
         return fail(GARLIC_ERR_INVALID, "step, pitch_align and nind_out must be >= 1");
@@ -1556,13 +1846,14 @@ static int flatten_impl(garlic_panel *p, const double *scores, int32_t pitch_ali
         chrs[c] = ChrDev{p->chr_off[c], L.base[c], L.pitch[c], cols, 0};
     }
     if (thinned > 0) step = 1;
-    const int nrows = p->nchr * nind_out;
+    const int per_chr = d_ind_list ? n_list : nind_out;
+    const int nrows = p->nchr * per_chr;
     if ((rc = p->d_chrs.reserve(chrs.size()))) return rc;
     if ((rc = p->d_row_counts.reserve((size_t)nrows))) return rc;
     p->plan.valid = false; // d_chrs is shared with the work plan
     HIP_TRY(hipMemcpyAsync(p->d_chrs.p, chrs.data(), sizeof(ChrDev) * chrs.size(), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(feed_count_kernel, dim3((unsigned)nrows), dim3(WAVE), 0, s, scores, p->d_chrs.p, p->nchr,
-                       nind_out, step, p->d_row_counts.p);
+                       per_chr, d_ind_list, step, p->d_row_counts.p);
     std::vector<int64_t> counts((size_t)nrows);
     HIP_TRY(hipMemcpyAsync(counts.data(), p->d_row_counts.p, sizeof(int64_t) * nrows, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1570,7 +1861,7 @@ static int flatten_impl(garlic_panel *p, const double *scores, int32_t pitch_ali
     if (chr_counts)
         for (int c = 0; c < p->nchr; c++) {
             chr_counts[c] = 0;
-            for (int i = 0; i < nind_out; i++) chr_counts[c] += counts[(size_t)c * nind_out + i];
+            for (int i = 0; i < per_chr; i++) chr_counts[c] += counts[(size_t)c * per_chr + i];
         }
     for (auto &c : counts) { const int64_t n = c; c = total; total += n; }
     *count = total;
@@ -1578,7 +1869,7 @@ static int flatten_impl(garlic_panel *p, const double *scores, int32_t pitch_ali
     if (!feed) return fail(GARLIC_ERR_INVALID, "feed is NULL");
     HIP_TRY(hipMemcpyAsync(p->d_row_counts.p, counts.data(), sizeof(int64_t) * nrows, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(feed_write_kernel, dim3((unsigned)nrows), dim3(WAVE), 0, s, scores, p->d_chrs.p, p->nchr,
-                       nind_out, step, p->d_row_counts.p, feed);
+                       per_chr, d_ind_list, step, p->d_row_counts.p, feed);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     return GARLIC_OK;
@@ -1591,14 +1882,35 @@ int garlic_lod_flatten(garlic_panel *p, const double *scores, int32_t pitch_alig
 }
 
 // LOD / wLOD scores and their thinned KDE feed in one call: the scores never leave the device
-int garlic_lod_feed(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
-                    int32_t weighted, int32_t M, double mu, int32_t step, double *feed,
-                    int64_t feed_capacity, int64_t *count, int64_t *chr_counts)
+int garlic_lod_feed_subset(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
+                           int32_t weighted, int32_t M, double mu, int32_t step, const int32_t *ind_idx, int32_t n_idx,
+                           double *feed, int64_t feed_capacity, int64_t *count, int64_t *chr_counts)
 {
     if (!p || !count) return fail(GARLIC_ERR_INVALID, "panel and count are required");
     if (step < 1) return fail(GARLIC_ERR_INVALID, "step must be >= 1");
+    if (ind_idx && n_idx < 1) return fail(GARLIC_ERR_INVALID, "an individual list needs at least one entry");
     int rc;
     if ((rc = set_device(p->ctx))) return rc;
+    // the listed individuals (convertSubsetWinData2DoubleData's randInd[]) and the blocks that hold them
+    const int nblk = (p->nind + WAVE - 1) / WAVE;
+    std::vector<uint8_t> blocks;
+    DevBuf<int32_t> d_list;
+    auto done = [&](int code) { d_list.release(); return code; };
+    if (ind_idx) {
+        blocks.assign((size_t)nblk, 0);
+        std::vector<uint8_t> seen((size_t)p->nind, 0);
+        for (int k = 0; k < n_idx; k++) {
+            const int i = ind_idx[k];
+            if (i < 0 || i >= p->nind) return fail(GARLIC_ERR_INVALID, "feed individual %d outside panel of %d", i, p->nind);
+            if (seen[(size_t)i]) return fail(GARLIC_ERR_INVALID, "feed individual %d listed twice", i);
+            seen[(size_t)i] = 1;
+            blocks[(size_t)(i >> 6)] = 1;
+        }
+        if ((rc = d_list.reserve((size_t)n_idx))) return done(rc);
+        hipError_t e = hipMemcpy(d_list.p, ind_idx, sizeof(int32_t) * (size_t)n_idx, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "feed: %s", hipGetErrorString(e)));
+    }
+    const int32_t n_rows = ind_idx ? n_idx : p->nind;
     // Unweighted --error scores with a real thinning step: the chain kernel stores only the sampled
     // windows (8/step B per window instead of 8 B, no full-size scratch).  Otherwise the full scores
     // go to the panel's device scratch (the one host-output calls use; it stays allocated, hipMalloc
@@ -1607,22 +1919,39 @@ int garlic_lod_feed(garlic_panel *p, int32_t winsize, double error, int32_t max_
     const Layout L = make_layout(p, 32, p->nind, thinned);
     DevBuf<double> &scores = p->d_out;
     DevBuf<double> &d_feed = p->d_feed;            // kept with the panel: window-size sweeps call this repeatedly
-    auto done = [&](int code) { return code; };
     if ((rc = scores.reserve((size_t)L.total))) return done(rc);
     if (weighted) p->wlod_use_gl = use_gl != 0;
     rc = launch_lod(p, weighted ? MODE_WLOD : (use_gl ? MODE_LOD_GL : MODE_LOD), winsize, error, max_gap, M, mu, 0,
-                    p->nind, 32, scores.p, GARLIC_DEVICE, thinned);
+                    p->nind, 32, scores.p, GARLIC_DEVICE, thinned, ind_idx ? &blocks : nullptr);
     if (rc) return done(rc);
     // at most ceil(nloci_c / step) values per (chromosome, individual)
     int64_t cap = 0;
-    for (int c = 0; c < p->nchr; c++) cap += ((int64_t)p->chr_nloci[c] + step - 1) / step * p->nind;
+    for (int c = 0; c < p->nchr; c++) cap += ((int64_t)p->chr_nloci[c] + step - 1) / step * n_rows;
     if ((rc = d_feed.reserve((size_t)std::max<int64_t>(cap, 1)))) return done(rc);
-    if ((rc = flatten_impl(p, scores.p, 32, p->nind, step, d_feed.p, cap, count, chr_counts, thinned))) return done(rc);
+    if ((rc = flatten_impl(p, scores.p, 32, p->nind, step, d_feed.p, cap, count, chr_counts, thinned,
+                           ind_idx ? d_list.p : nullptr, n_idx)))
+        return done(rc);
     if (*count > feed_capacity || *count == 0) return done(GARLIC_OK);
     if (!feed) return done(fail(GARLIC_ERR_INVALID, "feed is NULL"));
     hipError_t e = hipMemcpy(feed, d_feed.p, sizeof(double) * (size_t)*count, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "feed copy-out: %s", hipGetErrorString(e)));
     return done(GARLIC_OK);
+}
+
+int garlic_lod_feed(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
+                    int32_t weighted, int32_t M, double mu, int32_t step, double *feed,
+                    int64_t feed_capacity, int64_t *count, int64_t *chr_counts)
+{
+    return garlic_lod_feed_subset(p, winsize, error, max_gap, use_gl, weighted, M, mu, step, nullptr, 0, feed,
+                                  feed_capacity, count, chr_counts);
+}
+
+int garlic_panel_tgls_mode(garlic_panel *p, int32_t *mode, int32_t *terms_by)
+{
+    if (!p || !mode) return fail(GARLIC_ERR_INVALID, "panel and mode are required");
+    *mode = !p->have_gl ? 0 : (p->gl_cont ? GARLIC_TGLS_CONTINUOUS : GARLIC_TGLS_DICTIONARY);
+    if (terms_by) *terms_by = p->glterms_valid ? p->gl_terms_by : 0;
+    return GARLIC_OK;
 }
 
 int garlic_roh_coverage(garlic_panel *p, const double *scores, int32_t pitch_align, int32_t nind_out,

@@ -29,8 +29,18 @@
 //   ld_sum_kernel      the ordered window sums
 #pragma once
 #include "lod_kernels.hpp"
+#include "tgls_math.hpp"
 
 namespace garlic {
+
+// 0/0 (a SNP pair no sampled individual has both genotypes for; a SNP nobody is genotyped at) is the
+// one invalid operation of this path.  x86 answers with its default NaN, sign bit set, and every
+// later operation hands that NaN on unchanged; gfx950's default NaN has the sign clear.  The value
+// is made x86's where it arises, so that LD weights, wLOD scores and --raw-lod text ("-nan") match.
+__device__ __forceinline__ double x86_nan_if_nan(double v)
+{
+    return v != v ? f64_from_bits(X86_DEFAULT_NAN) : v;
+}
 
 // One workgroup per genotype word row (16 SNPs); wave w takes the 64-individual blocks w, w+4, ...
 // planes: [blk][nloci] 64-bit masks, bit = individual of the block;  M = non-missing and in the LD
@@ -247,7 +257,7 @@ __global__ void ld_homfreq_kernel(const int32_t *__restrict__ counts, int64_t nl
     if (l >= nloci) return;
     double hom = (double)counts[2 * l], total = (double)counts[2 * l + 1];
     hom /= total;                                   // 0/0 = NaN as on the host: such SNPs give hr2 = 0
-    hf[l] = hom;
+    hf[l] = x86_nan_if_nan(hom);
 }
 
 // garlic-data.cpp:558-583 with the two counts already taken
@@ -259,7 +269,7 @@ __device__ __forceinline__ double hr2_from_counts(double HA, double HB, int32_t 
     HAB /= total;
     const double H = HAB - HA * HB;
     const double v = H * H / (HA * (1 - HA) * HB * (1 - HB));
-    return (v > 1) ? 1.0 : v;
+    return (v > 1) ? 1.0 : x86_nan_if_nan(v);     // HA, HB are finite here: a NaN is the 0/0 of HAB /= total
 }
 
 // fwd[i * W + d] = hr2(i, i + d);  bwd[(i + d) * W + d] = hr2(i + d, i)      (d = 1 .. W-1)
@@ -294,7 +304,7 @@ ld_sum_kernel(const double *__restrict__ fwd, const double *__restrict__ bwd, in
             else if (i > t) term = bwd[i * W + (i - t)];
             acc += term;
         }
-        ld[s * W + k] = acc;
+        ld[s * W + k] = x86_nan_if_nan(acc);
     }
 }
 
@@ -385,7 +395,7 @@ ld_sum_tiled_kernel(const double *__restrict__ fwd, const double *__restrict__ b
     if (k < W) {
 #pragma unroll
         for (int q = 0; q < LD_SUM_B; q++)
-            if (q < ns) ld[(s0 + q) * W + k] = acc[q];
+            if (q < ns) ld[(s0 + q) * W + k] = x86_nan_if_nan(acc[q]);
     }
 }
 

@@ -13,6 +13,7 @@
 //         IEEE division done once on the device.
 #pragma once
 #include "lod_kernels.hpp"
+#include "tgls_math.hpp"
 #include "wlod_loop_gfx950.inc"
 
 
@@ -31,11 +32,14 @@ struct VariantArgs {
     int64_t nind_pad;
     int64_t nwordrows;
     int32_t ind_begin, ind_count, winsize, ncodes, use_gl;
+    const double *terms;      // use_gl with continuous likelihoods: raw term matrix [blk][term_rows][64], else NULL
+    int64_t term_rows;
 };
 
 // per-SNP term of this lane's individual; G = padded global locus index
 __device__ __forceinline__ double variant_term(const VariantArgs &p, int64_t G, int64_t col)
 {
+    if (p.use_gl && p.terms) return p.terms[((col >> 6) * p.term_rows + G) * WAVE + (col & 63)];
     const uint32_t word = p.packed[packed_index(G >> 4, col, p.nwordrows)];
     const uint32_t g = (word >> (2 * (int)(G & 15))) & 3u;
     if (p.use_gl) {
@@ -220,6 +224,87 @@ gl_terms_kernel(VariantArgs p, int64_t nloci, int64_t rows, double *__restrict__
     }
 }
 
+// ---- Continuous likelihoods (--gl-type GL / PL: more distinct values than a dictionary holds).
+// The error probabilities live in the term matrix's layout, vals[blk][rows][64]; the terms come from
+// lod() evaluated on the device with glibc's log10 restated (tgls_math.hpp).
+// gl_store_kernel: caller rows [locus_count][ld] -> vals (loci [l0, l0 + locus_count)).
+__global__ void __launch_bounds__(256)
+gl_store_kernel(const double *__restrict__ gl, int64_t ld, int64_t l0, int64_t locus_count, int32_t nind,
+                int64_t rows, double *__restrict__ vals)
+{
+    const int64_t n = locus_count * nind;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t l = e / nind;
+        const int64_t i = e - l * nind;
+        vals[((i >> 6) * rows + GOFF + l0 + l) * WAVE + (i & 63)] = gl[l * ld + i];
+    }
+}
+
+// the dictionary overflowed: what has been coded so far becomes values (codes: [rows][nind_pad])
+__global__ void __launch_bounds__(256)
+gl_decode_kernel(const uint8_t *__restrict__ codes, const double *__restrict__ dict, int64_t nind_pad, int64_t rows,
+                 double *__restrict__ vals)
+{
+    __shared__ double d_s[GL_DICT_MAX];
+    d_s[threadIdx.x] = dict[threadIdx.x];
+    __syncthreads();
+    const int64_t n = rows * nind_pad;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t G = e / nind_pad;
+        const int64_t i = e - G * nind_pad;
+        vals[((i >> 6) * rows + G) * WAVE + (i & 63)] = d_s[codes[e]];
+    }
+}
+
+// caller's one-byte codes + value table straight to values (garlic_panel_set_gl_codes in continuous mode)
+__global__ void __launch_bounds__(256)
+gl_store_codes_kernel(const uint8_t *__restrict__ rows_in, int64_t ld, int64_t l0, int64_t locus_count, int32_t nind,
+                      const double *__restrict__ dict, int64_t rows, double *__restrict__ vals)
+{
+    __shared__ double d_s[GL_DICT_MAX];
+    d_s[threadIdx.x] = dict[threadIdx.x];
+    __syncthreads();
+    const int64_t n = locus_count * nind;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t l = e / nind;
+        const int64_t i = e - l * nind;
+        vals[((i >> 6) * rows + GOFF + l0 + l) * WAVE + (i & 63)] = d_s[rows_in[l * ld + i]];
+    }
+}
+
+// terms[blk][G][lane] = lod(genotype, freq[G], vals[blk][G][lane]) for the padded rows [G0, G1); vals and
+// terms may be the same buffer (each element is read, then written, by one thread).  freq: [rows],
+// pad rows hold 0 (-> term +0.0, like the code-3 genotypes of pad rows and pad columns).
+__global__ void __launch_bounds__(256)
+gl_terms_cont_kernel(const uint32_t *__restrict__ packed, int64_t nwordrows, const double *__restrict__ freq,
+                     const double *__restrict__ logtab, const double *vals, int64_t G0, int64_t G1, int64_t rows,
+                     double *terms)
+{
+    __shared__ double tab_s[256];
+    tab_s[threadIdx.x] = logtab[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    const int64_t blk = blockIdx.y, col = blk * WAVE + lane;
+    const int64_t g0 = G0 + (int64_t)blockIdx.x * 64;
+    for (int64_t G = g0 + wave; G < min(G1, g0 + 64); G += 4) {
+        const uint32_t word = packed[packed_index(G >> 4, col, nwordrows)];
+        const uint32_t g = (word >> (2 * (int)(G & 15))) & 3u;
+        const int64_t at = (blk * rows + G) * WAVE + lane;
+        terms[at] = lod_term(g, freq[G], vals[at], tab_s);
+    }
+}
+
+// start-up check of the device's log10 against the host's: out[i] = glibc_log10(in[i])
+__global__ void __launch_bounds__(256)
+log10_probe_kernel(const double *__restrict__ in, const double *__restrict__ logtab, int64_t n, double *__restrict__ out)
+{
+    __shared__ double tab_s[256];
+    tab_s[threadIdx.x] = logtab[threadIdx.x];
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = glibc_log10(in[i], tab_s);
+}
+
 // wLOD with per-genotype likelihoods reads scores, (term * nomut) * norec (garlic-roh.cpp:249), from
 // the same matrix: scaled in place (and rebuilt by gl_terms_kernel when the unweighted TGLS chain
 // needs the raw terms again -- a session normally uses one of the two).  decay: [rows][2].
@@ -327,12 +412,19 @@ lod_chain_terms_kernel(VariantArgs p, int n_items, int64_t rows, const double *_
     }
 }
 
+// 1.0 / x with a NaN handed on as x86 does (the operand, quieted): nothing may depend on how the
+// division expansion of gfx950 treats payloads
+__device__ __forceinline__ double reciprocal_x86(double x)
+{
+    return x != x ? f64_from_bits(f64_bits(x) | 0x0008000000000000ull) : 1.0 / x;
+}
+
 // ---- 1.0 / LD, IEEE division (garlic-roh.cpp:270 does it per use; the quotient is the same double)
 __global__ void reciprocal_kernel(const double *__restrict__ ld, double *__restrict__ rld, int64_t n)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) rld[i] = 1.0 / ld[i];
+    for (; i < n; i += stride) rld[i] = reciprocal_x86(ld[i]);
 }
 
 // ---- wLOD: every valid window summed afresh (garlic-roh.cpp:253-273)
@@ -686,7 +778,7 @@ __global__ void skew_reciprocal_kernel(const double *__restrict__ ld, double *__
         const int64_t l = lo + i / W;
         const int j = (int)(i % W);
         const int64_t s = l - j;
-        D[l * W + j] = (s >= lo) ? 1.0 / ld[s * W + j] : 0.0;
+        D[l * W + j] = (s >= lo) ? reciprocal_x86(ld[s * W + j]) : 0.0;
     }
 }
 
@@ -695,12 +787,16 @@ __global__ void skew_reciprocal_kernel(const double *__restrict__ ld, double *__
 // rank the keepers with a ballot (integer work: exact whatever the order).
 __device__ __forceinline__ bool feed_keep(double x) { return x != MISSING_D && !(x != x); }
 
+// rows: (chromosome, r) pairs, r = 0 .. nrows-1; individual = ind_list ? ind_list[r] : r
+// (convertSubsetWinData2DoubleData, garlic-data.cpp:2071-2150: the same loops over randInd[])
 __global__ void __launch_bounds__(WAVE)
-feed_count_kernel(const double *scores, const ChrDev *chrs, int nchr, int nind, int step, int64_t *row_counts)
+feed_count_kernel(const double *scores, const ChrDev *chrs, int nchr, int nrows, const int32_t *ind_list, int step,
+                  int64_t *row_counts)
 {
-    const int row = blockIdx.x; // chr * nind + ind
-    const ChrDev c = chrs[row / nind];
-    const double *src = scores + c.out_base + (int64_t)(row % nind) * c.out_pitch;
+    const int row = blockIdx.x; // chr * nrows + r
+    const ChrDev c = chrs[row / nrows];
+    const int ind = ind_list ? ind_list[row % nrows] : row % nrows;
+    const double *src = scores + c.out_base + (int64_t)ind * c.out_pitch;
     const int nsamp = (c.nloci + step - 1) / step;
     int cnt = 0;
     for (int k = threadIdx.x; k < nsamp; k += WAVE) cnt += feed_keep(src[(int64_t)k * step]) ? 1 : 0;
@@ -709,12 +805,13 @@ feed_count_kernel(const double *scores, const ChrDev *chrs, int nchr, int nind, 
 }
 
 __global__ void __launch_bounds__(WAVE)
-feed_write_kernel(const double *scores, const ChrDev *chrs, int nchr, int nind, int step,
+feed_write_kernel(const double *scores, const ChrDev *chrs, int nchr, int nrows, const int32_t *ind_list, int step,
                   const int64_t *row_offsets, double *feed)
 {
     const int row = blockIdx.x;
-    const ChrDev c = chrs[row / nind];
-    const double *src = scores + c.out_base + (int64_t)(row % nind) * c.out_pitch;
+    const ChrDev c = chrs[row / nrows];
+    const int ind = ind_list ? ind_list[row % nrows] : row % nrows;
+    const double *src = scores + c.out_base + (int64_t)ind * c.out_pitch;
     const int nsamp = (c.nloci + step - 1) / step;
     int64_t base = row_offsets[row];
     for (int k0 = 0; k0 < nsamp; k0 += WAVE) {

@@ -1048,11 +1048,19 @@ std::vector<WinData *> *LodEngine::wlodWindowsResident(int winsize, double error
     return run(true, winsize, error, MAX_GAP, M, mu);
 }
 
-DoubleData *LodEngine::lodFeed(int winsize, double error, int MAX_GAP, int step, bool weighted, int M, double mu)
+DoubleData *LodEngine::lodFeed(int winsize, double error, int MAX_GAP, int step, bool weighted, int M, double mu,
+                               const std::vector<int> *kdeSubsample)
 {
     std::cerr << "Calculating LOD scores with winsize " << winsize << " (thinned on the device, step " << step << ").\n";
     const int nchr = (int)impl->chr_nloci.size();
     const size_t ns = impl->shards.size();
+    // --kde-subsample (convertSubsetWinData2DoubleData, garlic-data.cpp:2071-2150): panel-wide indices in
+    // increasing order (what gsl_ran_choose returns), so that the shards' feeds -- each over its own part
+    // of the list -- merge per chromosome in shard order exactly as for the whole panel
+    const bool subset = kdeSubsample && !kdeSubsample->empty();
+    if (subset)
+        for (size_t i = 1; i < kdeSubsample->size(); i++)
+            if ((*kdeSubsample)[i] <= (*kdeSubsample)[i - 1]) fail("KDE subsample must be in increasing order");
     std::vector<std::vector<double>> feeds(ns);
     std::vector<std::vector<int64_t>> per_chr(ns, std::vector<int64_t>(nchr, 0));
     std::vector<std::string> errors(ns);
@@ -1060,11 +1068,19 @@ DoubleData *LodEngine::lodFeed(int winsize, double error, int MAX_GAP, int step,
     for (size_t k = 0; k < ns; k++)
         th.emplace_back([&, k] {
             auto &s = impl->shards[k];
+            std::vector<int32_t> mine;
+            if (subset) {
+                for (int g : *kdeSubsample)
+                    if (g >= s.ind_begin && g < s.ind_begin + s.nind) mine.push_back(g - s.ind_begin);
+                if (mine.empty()) { feeds[k].clear(); return; }      // no listed individual lives here
+            }
+            const int64_t rows = subset ? (int64_t)mine.size() : s.nind;
             int64_t cap = 0, n = 0;
-            for (int c = 0; c < nchr; c++) cap += ((int64_t)impl->chr_nloci[c] + step - 1) / step * s.nind;
+            for (int c = 0; c < nchr; c++) cap += ((int64_t)impl->chr_nloci[c] + step - 1) / step * rows;
             feeds[k].resize((size_t)std::max<int64_t>(cap, 1));
-            if (garlic_lod_feed(s.panel, winsize, error, MAX_GAP, impl->use_gl, weighted, M, mu, step, feeds[k].data(),
-                                cap, &n, per_chr[k].data()) != GARLIC_OK)
+            if (garlic_lod_feed_subset(s.panel, winsize, error, MAX_GAP, impl->use_gl, weighted, M, mu, step,
+                                       subset ? mine.data() : nullptr, (int32_t)mine.size(), feeds[k].data(), cap, &n,
+                                       per_chr[k].data()) != GARLIC_OK)
                 errors[k] = garlic_hip_last_error();
             else
                 feeds[k].resize((size_t)n);
@@ -1112,19 +1128,19 @@ std::vector<LDData *> *LodEngine::ldWeights(int winsize, const std::vector<int> 
         std::vector<int32_t> l1, p1;
         std::vector<int32_t> &lo = ns == 1 ? loc : l1, &pa = ns == 1 ? pair : p1;
         lo.resize(loc.size()); pa.resize(pair.size());
-        // none of the subsample lives here: only the homFreq counts (an empty list would mean "all":
-        // count everything, then drop the pair counts)
-        const bool none = !subsample.empty() && sub.empty();
-        if (garlic_ld_counts(s.panel, winsize, ph, (none || sub.empty()) ? nullptr : sub.data(),
-                             none ? 0 : (int32_t)sub.size(), lo.data(), pa.data(), GARLIC_HOST) != GARLIC_OK) {
+        // subsample given: the shard's part of it, possibly empty (a non-NULL pointer with n_sub = 0 means
+        // "none of them": pair counts zero, the homFreq counts still over every individual)
+        static const int32_t no_index = 0;
+        const int32_t *sub_ptr = subsample.empty() ? nullptr : (sub.empty() ? &no_index : sub.data());
+        if (garlic_ld_counts(s.panel, winsize, ph, sub_ptr, (int32_t)sub.size(), lo.data(), pa.data(), GARLIC_HOST) !=
+            GARLIC_OK) {
             errors[k] = garlic_hip_last_error();
             return;
         }
         if (ns == 1) return;
         std::lock_guard<std::mutex> hold(sum_lock);
         for (size_t i = 0; i < loc.size(); i++) loc[i] += lo[i];
-        if (!none)
-            for (size_t i = 0; i < pair.size(); i++) pair[i] += pa[i];
+        for (size_t i = 0; i < pair.size(); i++) pair[i] += pa[i];
     };
     {
         std::vector<std::thread> th;
@@ -1214,6 +1230,11 @@ std::vector<int> drawLdSubsample(int nind, int ldSubsample, unsigned long long s
     return out;
 }
 
+std::vector<int> drawKdeSubsample(int nind, int kdeSubsample, unsigned long long seed)
+{   // garlic-data.cpp:2081-2096: everyone when the subsample is not smaller than the panel (here: empty list)
+    return drawLdSubsample(nind, kdeSubsample, seed ? seed ^ 0x6B64655F73756273ull : 0);
+}
+
 std::vector<LDData *> *calcLDData(std::vector<HapData *> *haps, std::vector<FreqData *> *freqs,
                                   std::vector<MapData *> *maps, std::vector<GenoFreqData *> * /*genoFreq*/,
                                   centromere *centro, int winsize, int /*MAX_GAP*/, bool PHASED,
@@ -1260,6 +1281,31 @@ DoubleData *convertWinData2DoubleData(std::vector<WinData *> *wins, int step)
     int k = 0;
     for (auto w : *wins)
         for (int i = 0; i < w->nind; i++)
+            for (int l = 0; l < w->nloci; l += step) {
+                const double x = w->data[i][l];
+                if (x != MISSING && !std::isnan(x)) d->data[k++] = x;
+            }
+    return d;
+}
+
+DoubleData *convertSubsetWinData2DoubleData(std::vector<WinData *> *wins, const std::vector<int> &randInd, int step)
+{
+    // garlic-data.cpp:2071-2150 with the draw supplied: chr -> randInd[0..] -> every step-th locus
+    int size = 0;
+    for (auto w : *wins)
+        for (int i : randInd) {
+            if (i < 0 || i >= w->nind) { std::cerr << "ERROR: KDE subsample index " << i << " outside the panel.\n"; throw 0; }
+            for (int l = 0; l < w->nloci; l += step) {
+                const double x = w->data[i][l];
+                if (x != MISSING && !std::isnan(x)) size++;
+            }
+        }
+    DoubleData *d = new DoubleData;
+    d->size = size;
+    d->data = new double[size > 0 ? size : 1];
+    int k = 0;
+    for (auto w : *wins)
+        for (int i : randInd)
             for (int l = 0; l < w->nloci; l += step) {
                 const double x = w->data[i][l];
                 if (x != MISSING && !std::isnan(x)) d->data[k++] = x;

@@ -209,6 +209,9 @@ std::vector<LDData *> *calcLDData(std::vector<HapData *> *hapDataByChr, std::vec
 // the individuals calcLDData would use: all when ldSubsample <= 0 or >= nind, else ldSubsample
 // distinct indices in increasing order (what gsl_ran_choose returns, garlic-data.cpp:361-362)
 std::vector<int> drawLdSubsample(int nind, int ldSubsample, unsigned long long seed);
+// the individuals convertSubsetWinData2DoubleData would use (garlic-data.cpp:2081-2096; time-seeded
+// there): empty = everyone (kdeSubsample <= 0 or >= nind), else kdeSubsample distinct indices, increasing
+std::vector<int> drawKdeSubsample(int nind, int kdeSubsample, unsigned long long seed);
 
 // A panel kept on the device(s) across window sizes (exploreWinsizes / selectWinsize call the
 // path once per candidate winsize on the same data, garlic-roh.cpp:726-751,798-837,881-920).
@@ -231,8 +234,11 @@ public:
     // What exploreWinsizes / selectWinsize keep of a window size (garlic-roh.cpp:741-745, 816-823):
     // convertWinData2DoubleData(calcLODWindows(...), step), with the scores thinned on the device(s)
     // -- 8/step bytes per window come back instead of 8.  weighted: wLOD from the resident LD weights.
+    // kdeSubsample (convertSubsetWinData2DoubleData, garlic-data.cpp:2071-2150: selectLODCutoff with
+    // --kde-subsample): the feed of these individuals only, panel-wide indices in increasing order (what
+    // gsl_ran_choose draws); NULL or empty = everyone.  Only their 64-individual blocks are scored.
     DoubleData *lodFeed(int winsize, double error, int MAX_GAP, int step, bool weighted = false, int M = 0,
-                        double mu = 0.0);
+                        double mu = 0.0, const std::vector<int> *kdeSubsample = nullptr);
     LodEngine(const LodEngine &) = delete;
     LodEngine &operator=(const LodEngine &) = delete;
 
@@ -247,6 +253,9 @@ private:
 
 // ---- consumers right after the path
 DoubleData *convertWinData2DoubleData(std::vector<WinData *> *winDataByChr, int step); // :2026
+// :2071 with the drawn individuals (randInd[], any order) supplied instead of a time-seeded gsl_ran_choose
+DoubleData *convertSubsetWinData2DoubleData(std::vector<WinData *> *winDataByChr, const std::vector<int> &randInd,
+                                            int step);
 void writeWinData(std::vector<WinData *> *winDataByChr, IndData *indData,
                   std::vector<MapData *> *mapDataByChr, const std::string &outfile);      // :1704
 

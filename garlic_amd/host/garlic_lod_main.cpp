@@ -31,6 +31,7 @@ struct Args {
     std::vector<int> devices;      // --devices; empty = 0 .. gpus-1
     int ld_subsample = 0;          // src/garlic-cli.cpp:137
     unsigned long long ld_seed = 0; // extension: 0 = time-seeded like the reference
+    unsigned long long kde_seed = 0; // extension: the --kde-subsample draw, 0 = time-seeded like the reference
     double mu = 1e-9, overlap_frac = 0.25;
 };
 
@@ -40,7 +41,7 @@ struct Args {
               << "usage: garlic-lod --tped F --tfam F --out P (--build hg18|hg19|hg38 | --centromere F)\n"
                  "         (--error E | --tgls F --gl-type GQ|GL|PL) (--winsize W | --winsize-multi W1 W2 ...)\n"
                  "         [--auto-winsize] [--auto-winsize-step N] [--max-gap N] [--overlap-frac X]\n"
-                 "         [--freq-file F] [--tped-missing C] [--raw-lod] [--kde-subsample N] [--no-kde-thinning]\n"
+                 "         [--freq-file F] [--tped-missing C] [--raw-lod] [--kde-subsample N] [--kde-seed S] [--no-kde-thinning]\n"
                  "         [--weighted --map F --M N --mu X --ld-subsample N --ld-seed S --threads N]\n"
                  "         [--gpus N | --devices 0,1,...] [--genotype-cache F]\n";
     exit(1);
@@ -81,6 +82,7 @@ Args parse(int argc, char **argv)
         else if (f == "--phased") a.phased = !a.phased;
         else if (f == "--raw-lod") a.raw_lod = !a.raw_lod;
         else if (f == "--kde-subsample") a.kde_subsample = atoi(val().c_str());
+        else if (f == "--kde-seed") a.kde_seed = strtoull(val().c_str(), nullptr, 10);
         else if (f == "--no-kde-thinning") a.kde_thinning = !a.kde_thinning;
         else if (f == "--gpus") a.gpus = atoi(val().c_str());
         else if (f == "--devices") {   // explicit HIP ordinals, e.g. 0,1,2,3 (an ordinal may repeat: shards share that GPU)
@@ -187,11 +189,19 @@ int main(int argc, char **argv)
         std::vector<int> sizes = a.winsize_multi.empty() ? std::vector<int>{a.winsize} : a.winsize_multi;
         LodEngine engine(haps, freqs, maps, gls, &centro, USE_GL, devices); // one upload, many window sizes
         const std::vector<int> ldsub = a.weighted ? drawLdSubsample(numInd, a.ld_subsample, a.ld_seed) : std::vector<int>();
+        // selectLODCutoff (garlic-roh.cpp:674-675): the KDE sees --kde-subsample individuals (default 20,
+        // garlic-cli.cpp:131), 0 = everyone.  The ROH stage scores everyone; --raw-lod still writes all rows.
+        const std::vector<int> kdesub = drawKdeSubsample(numInd, a.kde_subsample, a.kde_seed);
+        if (!kdesub.empty()) {
+            std::cerr << "Individuals used for KDE:";
+            for (int i : kdesub) std::cerr << " " << ind->indID[i];
+            std::cerr << "\n";
+        }
         for (int W : sizes) {
             if (a.weighted) engine.ldWeights(W, ldsub, false, a.phased);   // garlic-main.cpp:346-357: LD weights per window size
             const std::string feed_path = a.out + "." + std::to_string(W) + "SNPs.lod.f64";
             if (!a.raw_lod) {   // only the KDE feed is wanted: thin on the device, no full-score download
-                DoubleData *feed = engine.lodFeed(W, a.error, a.max_gap, a.kde_thinning ? W : 1, a.weighted, a.M, a.mu);
+                DoubleData *feed = engine.lodFeed(W, a.error, a.max_gap, a.kde_thinning ? W : 1, a.weighted, a.M, a.mu, &kdesub);
                 writeFeed(feed_path, feed);
                 releaseDoubleData(feed);
                 continue;
@@ -199,7 +209,8 @@ int main(int argc, char **argv)
             std::vector<WinData *> *win = a.weighted ? engine.wlodWindowsResident(W, a.error, a.max_gap, a.M, a.mu)
                                                      : engine.lodWindows(W, a.error, a.max_gap);
             writeWinData(win, ind, maps, sizes.size() == 1 ? a.out : a.out + "." + std::to_string(W) + "SNPs");
-            DoubleData *feed = convertWinData2DoubleData(win, a.kde_thinning ? W : 1);
+            DoubleData *feed = kdesub.empty() ? convertWinData2DoubleData(win, a.kde_thinning ? W : 1)
+                                              : convertSubsetWinData2DoubleData(win, kdesub, a.kde_thinning ? W : 1);
             writeFeed(feed_path, feed);
             releaseDoubleData(feed);
             releaseWinData(win);

@@ -37,8 +37,10 @@
 extern "C" {
 #endif
 
-/* 2: the LD functions take `phased`; garlic_panel_set_phase */
-#define GARLIC_HIP_ABI_VERSION 2
+/* 2: the LD functions take `phased`; garlic_panel_set_phase
+ * 3: likelihoods may be continuous (no 256-value limit), garlic_panel_tgls_mode; an LD subsample may be
+ *    empty (sub_idx != NULL, n_sub = 0); garlic_lod_feed_subset */
+#define GARLIC_HIP_ABI_VERSION 3
 
 #define GARLIC_OK 0
 #define GARLIC_ERR_INVALID 1  /* bad argument (e.g. winsize <= 1: src/garlic-cli.cpp:433-442) */
@@ -112,17 +114,33 @@ int garlic_panel_set_genotypes_2bit(garlic_panel *panel, const uint8_t *rows, in
                                     int32_t where);
 
 /* GenoLikeData::data (src/garlic-data.h:91): per-genotype error probabilities, already converted
- * as readTGLSData does (src/garlic-data.cpp:1557-1576); same addressing as genotypes. */
+ * as readTGLSData does (src/garlic-data.cpp:1557-1576); same addressing as genotypes.  Any doubles:
+ * while a panel has seen at most 256 distinct values (--gl-type GQ, PL integers) it keeps one-byte
+ * dictionary codes and the host tabulates lod() per (SNP, value, genotype) with the host libm; beyond
+ * that (--gl-type GL, continuous values) it keeps the values themselves (8 bytes per genotype) and
+ * lod() (src/garlic-roh.cpp:355-386) runs on the device with glibc's log10 restated operation by
+ * operation -- checked against the host's log10 when first needed; should they ever differ, the terms
+ * are computed on the host instead.  Same scores either way: those of the reference on this host.
+ * When the device cannot hold values and terms side by side the values are converted in place at the
+ * first computation; changing genotypes, frequencies, the map or the weighting parameters (M, mu)
+ * afterwards then needs the likelihoods uploaded again, over all loci (GARLIC_ERR_STATE says so). */
 int garlic_panel_set_gl(garlic_panel *panel, const double *gl, int64_t ld, int64_t locus_begin,
                         int64_t locus_count, int32_t where);
 
 /* The same likelihoods already dictionary-coded, as a reader that converts GQ / PL integers produces
  * them anyway: codes[(l - locus_begin) * ld + i] indexes values[0 .. nvalues), nvalues <= 256, the
  * error probabilities as readTGLSData converts them.  One byte per genotype on the host and over
- * PCIe instead of eight.  Every call may bring its own table; a panel holds at most 256 distinct
- * values in all. */
+ * PCIe instead of eight.  Every call may bring its own table; a panel whose tables add up to more than
+ * 256 distinct values keeps the values themselves from then on (see garlic_panel_set_gl). */
 int garlic_panel_set_gl_codes(garlic_panel *panel, const uint8_t *codes, int64_t ld, int64_t locus_begin,
                               int64_t locus_count, const double *values, int32_t nvalues, int32_t where);
+
+/* How the panel holds its likelihoods: 0 none yet, GARLIC_TGLS_DICTIONARY, GARLIC_TGLS_CONTINUOUS.
+ * *terms_by (may be NULL): who computed the current TGLS term matrix -- 0 nothing computed yet or
+ * tabulated from the dictionary, 1 the device (log10 verified against the host), 2 the host. */
+#define GARLIC_TGLS_DICTIONARY 1
+#define GARLIC_TGLS_CONTINUOUS 2
+int garlic_panel_tgls_mode(garlic_panel *panel, int32_t *mode, int32_t *terms_by);
 
 /* HapData::firstCopy (src/garlic-data.h:36; filled by readTPED under --phased,
  * src/garlic-data.cpp:106,129: "the first allele of the pair is the counted allele"), one byte per
@@ -140,9 +158,11 @@ int garlic_panel_set_ld(garlic_panel *panel, int32_t winsize, const double *ld, 
  *                     every individual of the panel;
  *       phased != 0:  c = r2  (calcR2LD :426-535, r2 :585-617; --phased), from the allele
  *                     frequencies of garlic_panel_set_freq and the phase of garlic_panel_set_phase.
- * The pair counts run over the individuals sub_idx[0 .. n_sub) (n_sub = 0: all).  The reference
- * draws that subsample with a time-seeded RNG (:346-364, --ld-subsample); here the caller supplies
- * it.  The result is installed as the panel's LD weights for winsize (as garlic_panel_set_ld would)
+ * The pair counts run over the individuals sub_idx[0 .. n_sub); sub_idx == NULL: all of them; a
+ * non-NULL sub_idx with n_sub = 0: none (what a shard that holds no member of a panel-wide subsample
+ * passes to garlic_ld_counts: its pair counts are zero, its locus counts still cover everyone).  The
+ * reference draws that subsample with a time-seeded RNG (:346-364, --ld-subsample); here the caller
+ * supplies it.  The result is installed as the panel's LD weights for winsize (as garlic_panel_set_ld would)
  * and, if ld_out is not NULL, also written there (nloci * winsize doubles, ld[l * winsize + k]). */
 int garlic_panel_compute_ld(garlic_panel *panel, int32_t winsize, int32_t phased, const int32_t *sub_idx,
                             int32_t n_sub, double *ld_out, int32_t where);
@@ -225,6 +245,16 @@ int garlic_lod_flatten(garlic_panel *panel, const double *scores, int32_t pitch_
 int garlic_lod_feed(garlic_panel *panel, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
                     int32_t weighted, int32_t M, double mu, int32_t step, double *feed,
                     int64_t feed_capacity, int64_t *count, int64_t *chr_counts);
+
+/* convertSubsetWinData2DoubleData (src/garlic-data.cpp:2071-2150; selectLODCutoff, src/garlic-roh.cpp:
+ * 674-675, --kde-subsample): garlic_lod_feed for the individuals ind_idx[0 .. n_idx) only, in that
+ * order inside every chromosome (chromosome -> ind_idx[0] .. ind_idx[n_idx-1] -> locus).  The reference
+ * draws them with a time-seeded gsl_ran_choose, which keeps the TFAM order; here the caller supplies
+ * them (distinct, each in [0, nind)).  Only the 64-individual blocks that hold a listed individual
+ * are scored.  ind_idx == NULL: everyone (= garlic_lod_feed).  chr_counts as there. */
+int garlic_lod_feed_subset(garlic_panel *panel, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
+                           int32_t weighted, int32_t M, double mu, int32_t step, const int32_t *ind_idx,
+                           int32_t n_idx, double *feed, int64_t feed_capacity, int64_t *count, int64_t *chr_counts);
 
 /* First half of assembleROHWindows (src/garlic-roh.cpp:446-454) on the device: for every individual
  * and SNP the number of windows with score >= cutoff that cover the SNP,

@@ -341,6 +341,24 @@ int64_t oracle_flatten(int nloci, int nind, const double *win, int step, double 
     return n;
 }
 
+/* garlic-data.cpp:2071-2150 (convertSubsetWinData2DoubleData), one chromosome, with the individuals
+ * the reference draws (gsl_ran_choose, time-seeded; GSL is absent from the mount, so the function
+ * itself cannot be linked into oracle/_ref) supplied by the caller: the same two loops with
+ * data[randInd[ind]] in place of data[ind].  Pinned against the real convertWinData2DoubleData
+ * applied to the rows win[randInd] (tests/test_oracle_vs_ref.py::test_subset_flatten). */
+int64_t oracle_flatten_subset(int nloci, int nind, const double *win, int step, const int32_t *rand_ind,
+                              int n_sub, double *out)
+{
+    int64_t n = 0;
+    (void)nind;
+    for (int ind = 0; ind < n_sub; ind++)
+        for (int locus = 0; locus < nloci; locus += step) {
+            double x = win[(size_t)rand_ind[ind] * nloci + locus];
+            if (x != ORACLE_MISSING && !isnan(x)) out[n++] = x;
+        }
+    return n;
+}
+
 /* Validity of each window start as garlic-roh.cpp:50-125 leaves it (shared by all
  * individuals): s < nloci-W+1, SNP s itself not inside the centromere, and no breaking
  * pair (k-1,k) for s < k <= s+W-1. */

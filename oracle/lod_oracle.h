@@ -78,6 +78,9 @@ void oracle_r2_ld(int nloci, int nind, const int16_t *genotypes, const uint8_t *
 
 /* garlic-data.cpp:2026-2069, one chromosome; returns number of values written. */
 int64_t oracle_flatten(int nloci, int nind, const double *win, int step, double *out);
+/* garlic-data.cpp:2071-2150 with the drawn individuals rand_ind[0 .. n_sub) supplied */
+int64_t oracle_flatten_subset(int nloci, int nind, const double *win, int step, const int32_t *rand_ind,
+                              int n_sub, double *out);
 void oracle_roh_coverage(int nloci, int nind, const double *win, int winsize, double cutoff,
                          int16_t *inwin);
 

@@ -67,6 +67,8 @@ def oracle():
         lib.oracle_r2_ld.argtypes = [C.c_int, C.c_int, _sp, _bp, _dp, C.c_int, _ip, C.c_int, _dp]
         lib.oracle_flatten.restype = C.c_int64
         lib.oracle_flatten.argtypes = [C.c_int, C.c_int, _dp, C.c_int, _dp]
+        lib.oracle_flatten_subset.restype = C.c_int64
+        lib.oracle_flatten_subset.argtypes = [C.c_int, C.c_int, _dp, C.c_int, _ip, C.c_int, _dp]
         lib.oracle_roh_coverage.restype = None
         lib.oracle_roh_coverage.argtypes = [C.c_int, C.c_int, _dp, C.c_int, C.c_double, _sp]
         lib.oracle_mask.restype = None
@@ -200,6 +202,16 @@ def oracle_flatten(win, step):
     nind, nloci = win.shape
     out = np.empty(win.size, dtype=np.float64)
     n = oracle().oracle_flatten(nloci, nind, _p(win, _dp), step, _p(out, _dp))
+    return out[:n].copy()
+
+
+def oracle_flatten_subset(win, step, idx):
+    """convertSubsetWinData2DoubleData (garlic-data.cpp:2071-2150) with the drawn individuals given"""
+    win = np.ascontiguousarray(win, dtype=np.float64)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    nind, nloci = win.shape
+    out = np.empty(max(1, idx.shape[0] * nloci), dtype=np.float64)
+    n = oracle().oracle_flatten_subset(nloci, nind, _p(win, _dp), step, _p(idx, _ip), idx.shape[0], _p(out, _dp))
     return out[:n].copy()
 
 

@@ -21,13 +21,50 @@ def read_rows(path):
         return [line.split() for line in f]
 
 
-def run_tool(tmp_path, *extra):
+def run_tool(tmp_path, *extra, want_stderr=False):
+    """--kde-subsample 0 (everyone feeds the KDE) unless the test passes its own: the default, 20 of the
+    24 individuals drawn with a time seed as in the reference, would differ from run to run"""
     out = str(tmp_path / "mine")
     cmd = [TOOL, "--tped", os.path.join(E2E, "tiny.tped.gz"), "--tfam", os.path.join(E2E, "tiny.tfam"),
-           "--centromere", os.path.join(E2E, "tiny.centromeres.txt"), "--error", "0.001", "--out", out, *extra]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+           "--centromere", os.path.join(E2E, "tiny.centromeres.txt"), "--error", "0.001", "--out", out]
+    if "--kde-subsample" not in extra:
+        cmd += ["--kde-subsample", "0"]
+    r = subprocess.run(cmd + list(extra), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    return out
+    return (out, r.stderr) if want_stderr else out
+
+
+def tiny_panels():
+    """independent re-parse of the tped (first non-missing allele is the counted one), monomorphic sites dropped"""
+    chroms = {}
+    with gzip.open(os.path.join(E2E, "tiny.tped.gz"), "rt") as f:
+        for line in f:
+            t = line.split()
+            chroms.setdefault(t[0], []).append(t)
+    cen = {l.split()[0]: (int(l.split()[1]), int(l.split()[2])) for l in open(os.path.join(E2E, "tiny.centromeres.txt"))}
+    per_chr = []
+    for c, rows in chroms.items():
+        pos = np.array([int(float(t[3])) for t in rows], dtype=np.int32)
+        geno = np.zeros((len(rows), 24), dtype=np.int16)
+        freq = np.zeros(len(rows))
+        for l, t in enumerate(rows):
+            al = t[4:]
+            one = next((x for x in al if x != "0"), "0")
+            cnt = tot = 0
+            for i in range(24):
+                a1, a2 = al[2 * i], al[2 * i + 1]
+                if a1 == "0" or a2 == "0":
+                    geno[l, i] = -9
+                else:
+                    geno[l, i] = (a1 == one) + (a2 == one)
+                for x in (a1, a2):
+                    if x != "0":
+                        tot += 1
+                        cnt += x == one
+            freq[l] = cnt / tot if tot else 0.0
+        keep = (freq > 0) & (freq < 1)
+        per_chr.append((geno[keep], freq[keep], pos[keep], cen[c]))
+    return per_chr
 
 
 def test_freq_and_raw_lod_match_reference_binary(tmp_path):
@@ -102,41 +139,46 @@ def test_tgls_raw_lod_matches_reference_binary(tmp_path):
 def test_kde_feed_matches_oracle(tmp_path):
     """<out>.<W>SNPs.lod.f64 = convertWinData2DoubleData of the scores (garlic-data.cpp:2026), bit exact."""
     out = run_tool(tmp_path, "--winsize-multi", "20", "45")
-    # independent re-parse of the tped (first non-missing allele is the counted one)
-    chroms = {}
-    with gzip.open(os.path.join(E2E, "tiny.tped.gz"), "rt") as f:
-        for line in f:
-            t = line.split()
-            chroms.setdefault(t[0], []).append(t)
-    cen = {l.split()[0]: (int(l.split()[1]), int(l.split()[2])) for l in open(os.path.join(E2E, "tiny.centromeres.txt"))}
-    per_chr = []
-    for c, rows in chroms.items():
-        pos = np.array([int(float(t[3])) for t in rows], dtype=np.int32)
-        geno = np.zeros((len(rows), 24), dtype=np.int16)
-        freq = np.zeros(len(rows))
-        for l, t in enumerate(rows):
-            al = t[4:]
-            one = next((x for x in al if x != "0"), "0")
-            cnt = tot = 0
-            for i in range(24):
-                a1, a2 = al[2 * i], al[2 * i + 1]
-                if a1 == "0" or a2 == "0":
-                    geno[l, i] = -9
-                else:
-                    geno[l, i] = (a1 == one) + (a2 == one)
-                for x in (a1, a2):
-                    if x != "0":
-                        tot += 1
-                        cnt += x == one
-            freq[l] = cnt / tot if tot else 0.0
-        keep = (freq > 0) & (freq < 1)
-        per_chr.append((geno[keep], freq[keep], pos[keep], cen[c]))
+    per_chr = tiny_panels()
     for W in (20, 45):
         want = np.concatenate([
             ol.oracle_flatten(ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, 200000), W)
             for g, f, p, (cs, ce) in per_chr])
         got = np.fromfile(f"{out}.{W}SNPs.lod.f64", dtype=np.float64)
         assert ol.bits_equal(got, want), W
+
+
+def test_kde_subsample_feed(tmp_path):
+    """--kde-subsample N (selectLODCutoff -> convertSubsetWinData2DoubleData, garlic-data.cpp:2071-2150): the
+    feed holds the drawn individuals only, in TFAM order; the draw is named on stderr as the reference logs
+    it; a seed makes it repeatable, also across shardings and through the --raw-lod (host-side) path"""
+    ids = [l.split()[1] for l in open(os.path.join(E2E, "tiny.tfam"))]
+    per_chr = tiny_panels()
+    feeds = []
+    for k, extra in enumerate(([], ["--devices", "0,0,0"], ["--raw-lod"])):
+        d = tmp_path / f"s{k}"
+        d.mkdir()
+        out, err = run_tool(d, "--winsize", "30", "--kde-subsample", "7", "--kde-seed", "3", *extra, want_stderr=True)
+        line = next(l for l in err.splitlines() if l.startswith("Individuals used for KDE:"))
+        idx = np.array([ids.index(x) for x in line.split(":")[1].split()], dtype=np.int32)
+        assert idx.shape[0] == 7 and (np.diff(idx) > 0).all()
+        want = np.concatenate([
+            ol.oracle_flatten_subset(ol.oracle_calc_lod(g, f, p, cs, ce, 30, 0.001, 200000), 30, idx)
+            for g, f, p, (cs, ce) in per_chr])
+        got = np.fromfile(f"{out}.30SNPs.lod.f64", dtype=np.float64)
+        assert ol.bits_equal(got, want), extra
+        feeds.append((idx, got))
+    assert all(np.array_equal(feeds[0][0], i) and ol.bits_equal(feeds[0][1], g) for i, g in feeds[1:])
+    # the default is the reference's: 20 individuals (garlic-cli.cpp:131)
+    d = tmp_path / "dflt"
+    d.mkdir()
+    cmd = [TOOL, "--tped", os.path.join(E2E, "tiny.tped.gz"), "--tfam", os.path.join(E2E, "tiny.tfam"),
+           "--centromere", os.path.join(E2E, "tiny.centromeres.txt"), "--error", "0.001", "--out", str(d / "x"),
+           "--winsize", "30"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0
+    line = next(l for l in r.stderr.splitlines() if l.startswith("Individuals used for KDE:"))
+    assert len(line.split(":")[1].split()) == 20
 
 
 def test_sharded_run_equals_single_device(tmp_path):

@@ -27,15 +27,9 @@ def oracle_ld(chroms, W, sub=None):
 
 
 def same(a, b):
-    """bit-equal; NaNs (a pair no individual of the subsample has both genotypes for: 0/0) must sit at
-    the same places -- their sign bit is the one thing x86 and gfx950 disagree on (0/0 is -nan there,
-    +nan here), and GARLIC only ever tests them with isnan (garlic-data.cpp:2040)"""
-    a = np.ascontiguousarray(a, dtype=np.float64)
-    b = np.ascontiguousarray(b, dtype=np.float64)
-    if a.shape != b.shape or not np.array_equal(np.isnan(a), np.isnan(b)):
-        return False
-    ok = ~np.isnan(a)
-    return np.array_equal(a[ok].view(np.uint64), b[ok].view(np.uint64))
+    """bit-equal, NaNs included: a pair no individual of the subsample has both genotypes for is 0/0 =
+    x86's default NaN (sign bit set), which the kernels reproduce"""
+    return ol.bits_equal(a, b)
 
 
 @pytest.mark.parametrize("W", [2, 7, 30, 100])
@@ -88,6 +82,54 @@ def test_ld_sharded_counts_sum_to_the_whole(gpu_ctx):
         shard = [(g[:, lo:hi].copy(), f, p, cs, ce) for g, f, p, cs, ce in chroms]
         parts.append((make_panel(gpu_ctx, shard, hi - lo), sub[(sub >= lo) & (sub < hi)] - lo))
     counts = [panel.ld_counts(W, sub_idx=s) for panel, s in parts]
+    loc = counts[0][0] + counts[1][0]
+    pair = counts[0][1] + counts[1][1]
+    for panel, _ in parts:
+        assert same(panel.ld_finish(W, loc, pair), want)
+        panel.close()
+
+
+def test_nan_weights_reach_wlod_with_the_x86_sign(gpu_ctx):
+    """two neighbouring SNPs genotyped in disjoint halves of the panel: hr2 = 0/0.  The NaN is x86's
+    default one (-nan) in the LD weights and in every wLOD score that uses them, bit for bit"""
+    rng = np.random.default_rng(31)
+    W, nind, mg = 20, 70, 200000
+    chroms = [ol.random_panel(rng, n, nind, max_gap=mg, mono=0.0, gaps=0, centro=False) for n in (300, 120)]
+    g0 = chroms[0][0]
+    g0[40, :35] = -9
+    g0[41, 35:] = -9
+    gpos = [c[2] * 1e-6 for c in chroms]
+    with make_panel(gpu_ctx, chroms, nind) as panel:
+        ld = panel.compute_ld(W)
+        out = panel.wlod_windows(W, 0.001, mg, 7, 1e-9, pitch_align=32)
+    want_ld = oracle_ld(chroms, W)
+    assert np.isnan(want_ld).any() and (np.signbit(want_ld[np.isnan(want_ld)])).all()
+    assert same(ld, want_ld)
+    off = 0
+    for c, (g, f, p, cs, ce) in enumerate(chroms):
+        ldc = want_ld[off:off + g.shape[0]]
+        off += g.shape[0]
+        want = ol.oracle_calc_wlod(g, f, p, gpos[c], ldc, cs, ce, W, 0.001, mg, 1e-9, 7)
+        assert c != 0 or np.isnan(want).any()
+        assert same(out[c], want), c
+
+
+def test_ld_shard_without_any_subsample_member(gpu_ctx):
+    """a panel-wide LD subsample that lies entirely in the first shard: the second shard passes an EMPTY
+    list (non-NULL, n_sub = 0) -- zero pair counts, its locus counts still over all its individuals --
+    and the finished weights equal the single-panel ones (NULL would have meant "everyone")"""
+    rng = np.random.default_rng(13)
+    W, nind, cut = 15, 130, 70
+    chroms = [ol.random_panel(rng, n, nind, max_gap=10 ** 9, gaps=0, miss=0.03) for n in (260, 140)]
+    sub = np.sort(rng.choice(cut, size=30, replace=False)).astype(np.int32)      # all below the cut
+    want = oracle_ld(chroms, W, sub)
+    parts = []
+    for lo, hi in ((0, cut), (cut, nind)):
+        shard = [(g[:, lo:hi].copy(), f, p, cs, ce) for g, f, p, cs, ce in chroms]
+        parts.append((make_panel(gpu_ctx, shard, hi - lo), (sub[(sub >= lo) & (sub < hi)] - lo).astype(np.int32)))
+    assert parts[1][1].shape[0] == 0
+    counts = [panel.ld_counts(W, sub_idx=s) for panel, s in parts]
+    assert not counts[1][1].any() and counts[1][0][:, 1].max() > 0
     loc = counts[0][0] + counts[1][0]
     pair = counts[0][1] + counts[1][1]
     for panel, _ in parts:

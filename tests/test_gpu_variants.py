@@ -49,15 +49,6 @@ def test_tgls_random_multichr_and_chunked_upload(gpu_ctx):
             assert ol.bits_equal(np.ascontiguousarray(out[c]), want), c
 
 
-def test_too_many_distinct_likelihoods_is_refused(gpu_ctx):
-    rng = np.random.default_rng(3)
-    g, f, p, cs, ce = ol.random_panel(rng, 100, 8)
-    with abi.Panel(gpu_ctx, [100], 8) as panel:
-        with pytest.raises(abi.GarlicError) as e:
-            panel.set_gl(rng.uniform(0.001, 0.5, size=(100, 8)))
-        assert e.value.code == abi.ERR_INVALID
-
-
 def test_wlod_golden(gpu_ctx):
     d = np.load(os.path.join(G, "wlod.npz"))
     cs, ce = (int(x) for x in d["centro"])
@@ -267,6 +258,51 @@ def test_lod_feed_one_call(gpu_ctx):
 
 
 
+def test_lod_feed_of_a_subsample(gpu_ctx):
+    """garlic_lod_feed_subset = convertSubsetWinData2DoubleData (garlic-data.cpp:2071-2150, --kde-subsample)
+    with the drawn individuals supplied: chromosome -> listed individual -> locus, for the thinned chain
+    write-out (only the blocks that hold a listed individual are scored), the full-score paths (TGLS, wLOD,
+    small steps), ascending draws as gsl_ran_choose leaves them and an arbitrary order"""
+    rng = np.random.default_rng(23)
+    mg, W, nind = 200000, 30, 330
+    sizes = [2500, 400, 64]
+    chroms = [ol.random_panel(rng, n, nind, max_gap=mg, gaps=2 if n > 1000 else 0) for n in sizes]
+    gpos = [c[2] * 1e-6 for c in chroms]
+    lds = [rng.uniform(1.0, 8.0, size=(n, W)) for n in sizes]
+    err = [rng.choice([1e-3, 0.01, 0.2], size=c[0].shape) for c in chroms]
+    draws = [np.sort(rng.choice(nind, size=20, replace=False)), np.array([329, 0, 64, 63, 200]), np.array([128]),
+             np.arange(nind)]
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms],
+                      gpos=np.concatenate(gpos))
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        panel.set_gl(np.concatenate(err, axis=0))
+        panel.set_ld(W, np.concatenate(lds, axis=0))
+        wins = {}
+        for mode in ("lod", "tgls", "wlod"):
+            wins[mode] = []
+            for c, (g, f, p, cs, ce) in enumerate(chroms):
+                if mode == "wlod":
+                    wins[mode].append(ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, 0.001, mg, 1e-9, 7))
+                else:
+                    wins[mode].append(ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg, gl=err[c] if mode == "tgls" else None))
+        for idx in draws:
+            for mode, steps in (("lod", (W, 7, 1)), ("tgls", (W,)), ("wlod", (W,))):
+                for step in steps:
+                    feed, per_chr = panel.lod_feed(W, 0.001, mg, step, use_gl=(mode == "tgls"), weighted=(mode == "wlod"),
+                                                   ind_idx=idx)
+                    want = [ol.oracle_flatten_subset(w, step, idx) for w in wins[mode]]
+                    assert [len(w) for w in want] == list(per_chr), (mode, step, idx[:3])
+                    assert ol.bits_equal(feed, np.concatenate(want)), (mode, step, idx[:3])
+            # the whole-panel feed afterwards (other block set: a new plan)
+            feed, _ = panel.lod_feed(W, 0.001, mg, W)
+            assert ol.bits_equal(feed, np.concatenate([ol.oracle_flatten(w, W) for w in wins["lod"]]))
+        for bad in ([0, 0], [nind], [-1]):
+            with pytest.raises(abi.GarlicError):
+                panel.lod_feed(W, 0.001, mg, W, ind_idx=np.array(bad))
+
+
 @pytest.mark.parametrize("W,step", [(30, 30), (100, 100), (100, 7), (50, 33), (64, 64), (20, 4), (100, 1000)])
 def test_lod_feed_thinned_write_out(gpu_ctx, W, step):
     """unweighted feed with step >= 4: the chain kernel itself stores only the sampled windows (POST's
@@ -330,5 +366,5 @@ def test_tgls_from_dictionary_codes(gpu_ctx):
         for c, (g, f, p, cs, ce) in enumerate(chroms):
             want = ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.5, mg, gl=tables[c][codes[c]])
             assert ol.bits_equal(np.ascontiguousarray(out[c]), want), c
-        with pytest.raises(abi.GarlicError):
+        with pytest.raises(abi.GarlicError):      # a caller's table holds at most 256 values (one-byte codes)
             panel.set_gl_codes(codes[0], np.linspace(0.1, 0.9, 257))

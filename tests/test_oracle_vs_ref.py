@@ -120,6 +120,26 @@ def _segments_from_coverage(inwin, pos, cS, cE, W, max_gap, overlap_frac):
     return out
 
 
+def test_subset_flatten():
+    """convertSubsetWinData2DoubleData (garlic-data.cpp:2071-2150) needs GSL for its draw and cannot be
+    linked here; its two loops are convertWinData2DoubleData's with data[randInd[ind]] for data[ind], so
+    the oracle's restatement (drawn individuals injected) must equal the REAL convertWinData2DoubleData
+    on the rows win[randInd] -- in the draw's order, ascending as gsl_ran_choose leaves it, or any other"""
+    rng = np.random.default_rng(17)
+    for _ in range(60):
+        nloci, nind = int(rng.integers(1, 300)), int(rng.integers(1, 40))
+        win = rng.normal(size=(nind, nloci))
+        win[rng.random(win.shape) < 0.2] = ol.MISSING
+        win[rng.random(win.shape) < 0.02] = np.nan
+        step = int(rng.choice([1, 7, 30, nloci + 5]))
+        k = int(rng.integers(1, nind + 1))
+        idx = rng.choice(nind, size=k, replace=False).astype(np.int32)
+        for order in (np.sort(idx), idx):
+            want = ol.ref_flatten(np.ascontiguousarray(win[order]), step)
+            assert ol.bits_equal(ol.oracle_flatten_subset(win, step, order), want)
+        assert ol.bits_equal(ol.oracle_flatten_subset(win, step, np.arange(nind)), ol.ref_flatten(win, step))
+
+
 def test_roh_coverage_through_the_reference_segments():
     """oracle_roh_coverage restates the inWin[] loop in the middle of assembleROHWindows
     (garlic-roh.cpp:446-454), which the reference does not expose.  Pinned here through what it feeds:

@@ -779,7 +779,8 @@ def gen_all(thin=False):
 def main():
     lines = gen_all()
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(here, "..", "garlic_amd", "csrc", "chain_loop_gfx950.inc")
+    # GARLIC_GEN_OUT: write somewhere else (tests/test_generated_cpu.py checks the committed file is current)
+    path = os.path.join(os.environ.get("GARLIC_GEN_OUT") or os.path.join(here, "..", "garlic_amd", "csrc"), "chain_loop_gfx950.inc")
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_chain_asm.py -- do not edit; see that file for roles and schedule.\n")
         f.write("// One inline-asm block: steady-state loop of lod_chain_kernel, 4 waves in 4 roles (gfx950).\n")

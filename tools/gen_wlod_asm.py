@@ -207,7 +207,8 @@ def build(gl):
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(here, "..", "garlic_amd", "csrc", "wlod_loop_gfx950.inc")
+    # GARLIC_GEN_OUT: write somewhere else (tests/test_generated_cpu.py checks the committed file is current)
+    path = os.path.join(os.environ.get("GARLIC_GEN_OUT") or os.path.join(here, "..", "garlic_amd", "csrc"), "wlod_loop_gfx950.inc")
     total = 0
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_wlod_asm.py -- do not edit; see that file for the schedule.\n")
