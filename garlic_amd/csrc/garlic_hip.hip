@@ -474,6 +474,9 @@ int switch_to_continuous(garlic_panel *p)
     const size_t n = (size_t)rows * p->nind_pad;
     hipStream_t s = p->ctx->stream;
     int rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    p->d_glterms.release();          // terms of the dictionary the panel leaves behind
+    p->glterms_valid = false;
     if ((rc = p->d_glval.reserve(n))) return rc;
     if (p->d_codes.p && !p->gl_values.empty()) {
         std::vector<double> dict(GL_DICT_MAX, 0.0);
