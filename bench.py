@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- Phase-I window LOD throughput on MI355X (BASELINE.json metric).
 
-A "step" is one full pass of the hot path (calcLODWindows, reference src/garlic-roh.cpp:279) over
-a synthetic SNP x individual panel that is already resident in HBM as 2-bit packed genotypes:
-segment planning, MISSING fill and the LOD chain kernel, writing every window score of every
-individual (FP64, individual-major) into HBM.
+A "step" is one full pass of the hot path (calcLODWindows, reference src/garlic-roh.cpp:279) over a
+synthetic SNP x individual panel that is already resident in HBM as 2-bit packed genotypes: the MISSING
+fill and the LOD chain kernel, writing every window score of every individual (FP64, individual-major)
+into HBM.  (The work plan -- gap / centromere segments, runs, the longest-first work list -- is made by the
+first call and stays resident; the timed passes, which repeat its arguments, only enqueue the two kernels.)
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3w100|small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|ns|c3w100|small] [--mode lod|wlod|tgls]
+                    [--also auto|none|leg,leg..] [--no-cpu]
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU).  Individuals
-shard across ranks (weak scaling: every rank owns --inds individuals of all SNPs); there is no
-collective on the data path, only the timing barrier.
+N = 1 (default): the workload BASELINE.json's metric is quoted on, configs[1] (C2: 1M SNPs x 1000
+individuals, --winsize 100, unweighted).  N > 1 is launched by the driver through torch.distributed.run, one
+rank per GPU, and runs the north star's panel: 10M SNPs, 1250 individuals per rank (N = 8: the configured
+10M x 10k panel; --workload ns runs one such shard at N = 1).  Individuals shard across ranks, every rank
+owns all SNPs of its individuals (weak scaling); there is no collective on the data path -- only the timing
+barrier, and with --mode wlod one integer all-reduce of the LD pair counts before the timed region.
 
-Rank 0 prints ONE JSON line; `roofline` prices the dominant kernel (lod_chain_kernel) against HBM,
-`cpu_baseline` times the reference's own calcLOD (oracle/_ref, built from the reference sources in
-the build container) or, if that library is absent, the C port in oracle/, on a bounded sample of
-the same panel on the host cores -- and the GPU scores of those individuals are compared with
-it bit for bit.
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against its bound with the kernel's
+HIP-event time measured live on the stream it runs on; `cpu_baseline` times the reference's own calcLOD
+(oracle/_ref, built from the reference sources in the build container) or, if that library is absent, the C
+port in oracle/, on a bounded sample of the same panel on the host cores -- and the GPU scores of those
+individuals are compared with it bit for bit.  At N = 1 the line also carries, under `also`, the other
+configured workloads with their own roofline objects (C3: 5M x 5k x four window sizes, full scores and
+thinned feed; C4 / C5 per-GPU shard, 10M x 1250: unweighted, LD weights, wLOD, TGLS, GL-weighted wLOD) and
+`end_to_end` (host int16 genotypes in -> host doubles out through the C ABI, PCIe included); legs are skipped,
+and say so, once the run has used its time budget (--also-budget-s).
 """
 import argparse
 import json
@@ -30,31 +39,53 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (nloci, inds per GPU, winsize, BASELINE.json config it is)
-    "c2": (1_000_000, 1000, 100, "synthetic 1M SNPs x 1k inds, --winsize 100 --overlap-frac 0.25, unweighted LOD"),
-    "c3w100": (5_000_000, 5000, 100, "synthetic 5M SNPs x 5k inds, one window size (100) of config 3"),
-    "small": (100_000, 256, 100, "smoke-sized panel (not a BASELINE config)"),
+    # name: (nloci, inds per GPU, winsize, seed offset, BASELINE.json config it is)
+    "c2": (1_000_000, 1000, 100, 1, "synthetic 1M SNPs x 1k inds, --winsize 100 --overlap-frac 0.25, unweighted LOD"),
+    "ns": (10_000_000, 1250, 100, 3, "synthetic 10M SNPs x 10k inds sharded over 8 GPUs: 1250 inds per GPU (configs 4/5 panel)"),
+    "c3w100": (5_000_000, 5000, 100, 2, "synthetic 5M SNPs x 5k inds, one window size (100) of config 3"),
+    "small": (100_000, 256, 100, 0, "smoke-sized panel (not a BASELINE config)"),
 }
-ALG_BYTES_PER_WINDOW = 8.25  # 0.25 B 2-bit genotype in + 8 B double out
+BYTES_LOD = 8.25     # 0.25 B 2-bit genotype in + 8 B double out per sliding window
+BYTES_TGLS = 16.25   # 8 B term + 0.25 B genotype + 8 B score ("GL as doubles" row)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_PEAK_TFLOPS = 39.3      # FP64 vector peak counted as separate mul + add (78.6 TFLOP/s counts FMAs; wLOD may not fuse)
+ERROR, MAX_GAP, M_GEN, MU = 0.001, 200000, 7, 1e-9
+T_START = time.perf_counter()
 
 
-def cpu_baseline(spec, geno_sample, W, error, max_gap, gpu_rows, seconds_budget=25.0):
-    """Times the CPU path on `geno_sample` (int16 [nloci][n_s]) one chromosome at a time and
-    checks the GPU rows against it.  Returns the cpu_baseline JSON object."""
+def hbm_roofline(kernel, bytes_per_launch, kernel_ms, **extra):
+    a = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "kernel": kernel, "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+         "traffic": None, "traffic_source": "not measured in this run: PMC passes are separate rocprofv3 runs, "
+                                            "see profiles/ (bytes per launch of the same kernel and panel)",
+         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch}
+    r.update(extra)
+    return r
+
+
+def fp64_roofline(kernel, windows, W, kernel_ms, **extra):
+    flops = 2.0 * windows * W        # one v_mul_f64 + one v_add_f64 per (window, term): the product rounds before the add
+    a = flops / (kernel_ms * 1e-3) / 1e12
+    r = {"bound": "fp64 valu (separately rounded multiply + add per term: no FMA, no MFMA)", "kernel": kernel,
+         "achieved": a, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / FP64_PEAK_TFLOPS, "traffic": None,
+         "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops}
+    r.update(extra)
+    return r
+
+
+def cpu_baseline(spec, geno_sample, W, gpu_rows, seconds_budget=25.0):
+    """Times the CPU path on `geno_sample` (int16 [nloci][n_s]) one chromosome at a time and checks the GPU
+    rows against it.  Returns the cpu_baseline JSON object."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
 
     use_ref = ol.have_ref()
     n_s = geno_sample.shape[1]
-    t_total = 0.0
-    windows = 0
-    mismatches = 0
+    t_total, windows, mismatches = 0.0, 0, 0
     for c in range(spec.nchr):
         lo, hi = int(spec.chr_off[c]), int(spec.chr_off[c + 1])
         g = np.ascontiguousarray(geno_sample[lo:hi])
-        args = (g, spec.freq[lo:hi], spec.pos[lo:hi], int(spec.centro_start[c]),
-                int(spec.centro_end[c]), W, error, max_gap)
+        args = (g, spec.freq[lo:hi], spec.pos[lo:hi], int(spec.centro_start[c]), int(spec.centro_end[c]), W, ERROR, MAX_GAP)
         t0 = time.perf_counter()
         want = ol.ref_calc_lod(*args) if use_ref else ol.oracle_calc_lod(*args)
         t_total += time.perf_counter() - t0
@@ -62,16 +93,13 @@ def cpu_baseline(spec, geno_sample, W, error, max_gap, gpu_rows, seconds_budget=
         mismatches += ol.count_mismatch(np.ascontiguousarray(gpu_rows[c]), want)
         if t_total > seconds_budget:
             break
-    lod_windows_per_s = windows / W / t_total
-    # (ii) all host cores, SURVEY 8(d): independent slices of individuals, one per core, through
-    # the C port (oracle/) -- the reference itself has no threaded calcLOD.  One chromosome's worth
-    # of the same sample, enough to state a rate; not part of cpu_baseline.value.
-    # the GPU box gives one GPU's job a share of 16 host cores whatever the affinity mask says
+    # (ii) all host cores, SURVEY 8(d): independent slices of individuals, one per core, through the C port
+    # (oracle/) -- the reference itself has no threaded calcLOD.  One chromosome's worth of the same sample.
+    # The GPU box gives one GPU's job a share of 16 host cores whatever the affinity mask says.
     ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("GARLIC_BENCH_CORES", "16")))
     lo, hi = int(spec.chr_off[0]), int(spec.chr_off[1])
-    g0 = np.ascontiguousarray(geno_sample[lo:hi])
-    a0 = (g0, spec.freq[lo:hi], spec.pos[lo:hi], int(spec.centro_start[0]), int(spec.centro_end[0]),
-          W, error, max_gap)
+    a0 = (np.ascontiguousarray(geno_sample[lo:hi]), spec.freq[lo:hi], spec.pos[lo:hi], int(spec.centro_start[0]),
+          int(spec.centro_end[0]), W, ERROR, MAX_GAP)
     ol.oracle_calc_lod(*a0, threads=ncores)                 # page in, spin up the team
     reps, t_all = 0, 0.0
     while t_all < 3.0 and reps < 20:
@@ -79,20 +107,206 @@ def cpu_baseline(spec, geno_sample, W, error, max_gap, gpu_rows, seconds_budget=
         ol.oracle_calc_lod(*a0, threads=ncores)
         t_all += time.perf_counter() - t0
         reps += 1
-    all_cores = (hi - lo) * n_s * reps / W / t_all
     return {
-        "value": lod_windows_per_s,
-        "unit": "LOD-windows/s",
-        "cores": 1,
+        "value": windows / W / t_total, "unit": "LOD-windows/s", "cores": 1,
         "kind": "reference" if use_ref else "port",
         "sample": f"{n_s} individuals x {windows // n_s} SNPs ({c + 1} of {spec.nchr} chromosomes) of the same panel, "
                   f"single thread (calcLOD is single-threaded in the reference), {t_total:.1f} s",
         "sliding_windows_per_s": windows / t_total,
         "gpu_bit_mismatches_on_sample": int(mismatches),
-        "all_cores": {"value": all_cores, "unit": "LOD-windows/s", "cores": ncores, "kind": "port",
+        "all_cores": {"value": (hi - lo) * n_s * reps / W / t_all, "unit": "LOD-windows/s", "cores": ncores, "kind": "port",
                       "sample": f"{n_s} individuals x {hi - lo} SNPs (chromosome 1), {n_s // max(1, ncores)} "
                                 f"individuals per core, {reps} repetitions, {t_all:.1f} s"},
     }
+
+
+def load_panel(ctx, spec, nind, dev, ind_offset=0, n_cpu=0, gq=False):
+    """device-resident panel of `nind` individuals drawn on the device; n_cpu: also keep the first n_cpu
+    individuals' genotypes on the host (CPU baseline); gq: GQ ~ U{3..60} likelihoods (--gl-type GQ, config 5)"""
+    import torch
+    from garlic_amd import abi, synth
+    panel = abi.Panel(ctx, spec.chr_nloci, nind)
+    panel.set_map(spec.pos, spec.centro_start, spec.centro_end, gpos=spec.gpos)
+    panel.set_freq(spec.freq)
+    geno_sample = np.empty((spec.nloci, n_cpu), dtype=np.int16) if n_cpu else None
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(spec.seed * 7 + ind_offset)
+    for l0, g in synth.genotype_chunks(spec, nind, dev, ind_offset=ind_offset):
+        torch.cuda.synchronize()
+        panel.set_genotypes_device(g.data_ptr(), g.shape[1], l0, g.shape[0])
+        if n_cpu:
+            geno_sample[l0:l0 + g.shape[0]] = g[:, :n_cpu].cpu().numpy()
+        if gq:   # error = 10^max(-10, -GQ/10)   (SURVEY 8(d), garlic-data.cpp:1557)
+            q = torch.randint(3, 61, g.shape, generator=gen, device=dev).to(torch.float64)
+            gl = torch.pow(torch.tensor(10.0, dtype=torch.float64, device=dev), -q / 10.0)
+            torch.cuda.synchronize()
+            panel.set_gl_device(gl.data_ptr(), gl.shape[1], l0, gl.shape[0])
+            del q, gl
+    return panel, geno_sample
+
+
+def timed_passes(ctx, call, steps, warmup, sync):
+    """`warmup` untimed then `steps` timed passes of call(), enqueued back to back; returns (seconds for
+    the timed passes, mean HIP-event ms of the dominant kernel over them)"""
+    for _ in range(warmup):
+        call()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        call()
+    sync()
+    dt = time.perf_counter() - t0
+    k = ctx.recent_kernel_ms(min(steps, 32))
+    return dt, float(np.mean(k))
+
+
+# ------------------------------------------------------------------------------------------------ also legs
+def leg_c3(ctx, dev, steps):
+    """config 3: 5M SNPs x 5k individuals, --winsize-multi 50 100 200 300 on ONE resident panel: the four
+    full-score passes (200 GB of scores each, into the same buffer) and the four thinned feeds
+    (--auto-winsize / exploreWinsizes keep only convertWinData2DoubleData(.., step = winsize))"""
+    import torch
+    from garlic_amd import synth
+    nloci, nind = 5_000_000, 5000
+    sizes = [50, 100, 200, 300]
+    spec = synth.PanelSpec(nloci, seed=20260101 + 2, max_gap=MAX_GAP)
+    panel, _ = load_panel(ctx, spec, nind, dev)
+    base, pitch, total = panel.out_layout(32, nind)
+    out = torch.empty(total, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    res = {"workload": "synthetic 5M SNPs x 5k inds, --winsize-multi 50 100 200 300 (config 3), one resident panel",
+           "snps": nloci, "inds": nind, "winsizes": sizes}
+    full, feed = {}, {}
+    for W in sizes:
+        call = lambda: panel.lod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP)
+        dt, k = timed_passes(ctx, call, steps, 1, torch.cuda.synchronize)
+        full[W] = {"ms_per_pass": dt / steps * 1e3, "kernel_ms": k}
+    k_all = sum(v["kernel_ms"] for v in full.values())
+    t_all = sum(v["ms_per_pass"] for v in full.values())
+    res["full_scores"] = {
+        "per_winsize": full, "four_sizes_ms": t_all,
+        "lod_windows_per_s": sum(nloci * nind / W for W in sizes) / (t_all * 1e-3),
+        "sliding_windows_per_s": 4 * nloci * nind / (t_all * 1e-3),
+        "roofline": hbm_roofline("lod_chain_kernel", 4 * BYTES_LOD * nloci * nind, k_all,
+                                 note="the four launches of one --winsize-multi call together")}
+    del out
+    torch.cuda.empty_cache()
+    for W in sizes:
+        panel.lod_feed(W, ERROR, MAX_GAP, W, copy=False)             # plan + scratch
+        ks, ws = [], []
+        for _ in range(max(2, steps // 2)):
+            t0 = time.perf_counter()
+            f, _ = panel.lod_feed(W, ERROR, MAX_GAP, W, copy=False)
+            ws.append(time.perf_counter() - t0)
+            ks.append(panel.stats()["chain_kernel_ms"])
+        feed[W] = {"kernel_ms": float(np.mean(ks)), "call_ms": float(np.mean(ws)) * 1e3, "feed_values": int(f.shape[0])}
+    k_all = sum(v["kernel_ms"] for v in feed.values())
+    bytes_feed = sum((0.25 + 8.0 / W) * nloci * nind for W in sizes)
+    res["thinned_feed"] = {
+        "per_winsize": feed, "four_sizes_kernel_ms": k_all, "four_sizes_call_ms": sum(v["call_ms"] for v in feed.values()),
+        "sliding_windows_per_s": 4 * nloci * nind / (k_all * 1e-3),
+        "roofline": hbm_roofline("lod_chain_kernel<thinned>", bytes_feed, k_all,
+                                 note="0.25 + 8/W B per window (SURVEY 8(d) 'thinned output'): with the stores gone the kernel "
+                                      "runs at the pace of the sequential FP64 chain, far from any memory bound")}
+    panel.close()
+    return res
+
+
+def leg_ns(ctx, dev, steps):
+    """configs 4 and 5, one GPU's shard: 10M SNPs x 1250 individuals -- unweighted scores, LD weights
+    (all individuals; --ld-subsample 500), wLOD, TGLS (--gl-type GQ), GL-weighted wLOD"""
+    import torch
+    from garlic_amd import synth
+    nloci, nind, W = 10_000_000, 1250, 100
+    spec = synth.PanelSpec(nloci, seed=20260101 + 3, max_gap=MAX_GAP)
+    panel, _ = load_panel(ctx, spec, nind, dev, gq=True)
+    base, pitch, total = panel.out_layout(32, nind)
+    out = torch.empty(total, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    win = nloci * nind
+    res = {"workload": "synthetic 10M SNPs x 1250 inds (one GPU's shard of the 10M x 10k panel of configs 4 and 5), --winsize 100",
+           "snps": nloci, "inds": nind, "winsize": W}
+
+    def rate(k_ms, dt):
+        return {"kernel_ms": k_ms, "ms_per_pass": dt / steps * 1e3, "sliding_windows_per_s": win / (dt / steps),
+                "lod_windows_per_s": win / W / (dt / steps)}
+
+    dt, k = timed_passes(ctx, lambda: panel.lod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP), steps, 1,
+                         torch.cuda.synchronize)
+    res["lod"] = dict(rate(k, dt), roofline=hbm_roofline("lod_chain_kernel", BYTES_LOD * win, k))
+    # LD weights: integer pair counts (AND + popcount on bit planes) + W^2 ordered FP64 adds per window start
+    for name, sub in (("ld_all_individuals", None),
+                      ("ld_subsample_500", np.sort(np.random.default_rng(1).choice(nind, 500, replace=False)).astype(np.int32))):
+        panel.compute_ld(W, sub_idx=sub, want_output=False)
+        ts = []
+        for _ in range(max(2, steps // 2)):
+            t0 = time.perf_counter()
+            panel.compute_ld(W, sub_idx=sub, want_output=False)
+            ts.append(time.perf_counter() - t0)
+        t = float(np.mean(ts))
+        nsub = nind if sub is None else 500
+        adds = float(nloci) * W * W
+        res[name] = {"call_ms": t * 1e3, "snps_per_s": nloci / t,
+                     "roofline": {"bound": "fp64 valu adds + LDS reads (W^2 ordered adds per window start: one v_add_f64 and one "
+                                           "8-B LDS read each); the counts are AND + popcount over the subsample's bit planes",
+                                  "kernel": "ld_* (planes, pair counts, hr2, ordered sums, reciprocals) -- the whole call",
+                                  "achieved": adds / t / 1e12, "peak": FP64_PEAK_TFLOPS / 2, "unit": "TFLOP/s (adds only)",
+                                  "frac": adds / t / 1e12 / (FP64_PEAK_TFLOPS / 2), "traffic": None,
+                                  "ordered_adds_per_call": adds,
+                                  "popcounts_per_call": float(nloci) * (W - 1) * 2 * ((nsub + 63) // 64)}}
+    dt, k = timed_passes(ctx, lambda: panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU), steps, 1,
+                         torch.cuda.synchronize)
+    res["wlod"] = dict(rate(k, dt), roofline=fp64_roofline("wlod_tile_kernel", win, W, k))
+    panel.release_scratch()
+    dt, k = timed_passes(ctx, lambda: panel.lod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, use_gl=True), steps, 1,
+                         torch.cuda.synchronize)
+    res["tgls"] = dict(rate(k, dt), roofline=hbm_roofline("lod_chain_terms_kernel", BYTES_TGLS * win, k,
+                                                          note="term matrix built once per panel (gl_terms_kernel), not in the pass"))
+    dt, k = timed_passes(ctx, lambda: panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU, use_gl=True),
+                         steps, 1, torch.cuda.synchronize)
+    res["wlod_gl"] = dict(rate(k, dt), roofline=fp64_roofline("wlod_tile_glring_kernel", win, W, k))
+    panel.close()
+    del out
+    torch.cuda.empty_cache()
+    return res
+
+
+def leg_end_to_end(ctx, dev):
+    """what a drop-in calcLODWindows pays at C2 size: host int16 genotypes in (upload + 2-bit packing), one
+    garlic_lod_windows call with HOST output in the reference's dense rows, PCIe both ways; and the feed-only
+    form (scores + thinning on the device, 8/W bytes per window back)"""
+    from garlic_amd import abi, synth
+    nloci, nind, W = WORKLOADS["c2"][:3]
+    spec = synth.PanelSpec(nloci, seed=20260101 + 1, max_gap=MAX_GAP)
+    geno = np.empty((nloci, nind), dtype=np.int16)
+    for l0, g in synth.genotype_chunks(spec, nind, dev):
+        geno[l0:l0 + g.shape[0]] = g.cpu().numpy()
+    t0 = time.perf_counter()
+    panel = abi.Panel(ctx, spec.chr_nloci, nind)
+    panel.set_map(spec.pos, spec.centro_start, spec.centro_end)
+    panel.set_freq(spec.freq)
+    panel.set_genotypes(geno)
+    t_up = time.perf_counter() - t0
+    base, pitch, total = panel.out_layout(1, nind)
+    out = np.empty(total, dtype=np.float64)
+    out[::512] = 0   # touch the pages once: the timed call should not pay first-touch faults
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        abi.check(abi.lib().garlic_lod_windows(panel.handle, W, ERROR, MAX_GAP, 0, 0, nind, 1, abi._vp(out.ctypes.data), abi.HOST))
+        times.append(time.perf_counter() - t0)
+    st = panel.stats()
+    panel.lod_feed(W, ERROR, MAX_GAP, W)
+    t0 = time.perf_counter()
+    feed, _ = panel.lod_feed(W, ERROR, MAX_GAP, W, copy=False)
+    t_feed = time.perf_counter() - t0
+    panel.close()
+    win = nloci * nind
+    return {"workload": "C2 through the C ABI with HOST buffers (the drop-in call): int16 genotypes in, doubles out",
+            "upload_and_pack_s": t_up, "lod_windows_host_output_s": min(times), "of_which_kernel_ms": st["chain_kernel_ms"],
+            "value": win / W / min(times), "unit": "LOD-windows/s", "includes": "PCIe D2H of 8 GB of scores (upload timed separately)",
+            "with_upload": win / W / (min(times) + t_up),
+            "feed_only": {"call_s": t_feed, "value": win / W / t_feed, "unit": "LOD-windows/s", "feed_values": int(feed.shape[0])}}
 
 
 def main():
@@ -100,15 +314,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="lod", choices=["lod", "wlod", "tgls"])
     ap.add_argument("--inds", type=int, default=0, help="individuals per GPU (default: workload's)")
     ap.add_argument("--cpu-inds", type=int, default=512, help="individuals in the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--out-candidates", type=int, default=4,
+                    help="score buffers to try for the timed passes (placement in VRAM changes the kernel time)")
+    ap.add_argument("--also", default="auto", help="auto | none | comma list of c3,ns,e2e (N = 1 only)")
+    ap.add_argument("--also-budget-s", type=float, default=330.0,
+                    help="no further `also` leg is started once the run has taken this long")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from garlic_amd import abi, synth
+    from garlic_amd import abi, shard, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -130,34 +350,78 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
-    nloci, nind, W, desc = WORKLOADS[args.workload]
+    wl = args.workload or ("c2" if world == 1 else "ns")
+    nloci, nind, W, seed_off, desc = WORKLOADS[wl]
     if args.inds:
         nind = args.inds
-    error, max_gap = 0.001, 200000
-    cfg_index = {"c2": 1, "c3w100": 2, "small": 0}[args.workload]
-    spec = synth.PanelSpec(nloci, seed=20260101 + cfg_index, max_gap=max_gap)
+    spec = synth.PanelSpec(nloci, seed=20260101 + seed_off, max_gap=MAX_GAP)
 
     ctx = abi.Context(local_rank)
     ctx.set_async(True)   # repeated passes with device-resident output are enqueued back to back
-    panel = abi.Panel(ctx, spec.chr_nloci, nind)
-    panel.set_map(spec.pos, spec.centro_start, spec.centro_end, gpos=spec.gpos)
-    panel.set_freq(spec.freq)
     # CPU baseline: rank 0 of the single-GPU run only (the other ranks of a larger run would wait for it)
-    n_cpu = 0 if (args.no_cpu or rank != 0 or world > 1) else min(args.cpu_inds, nind)
-    geno_sample = np.empty((nloci, n_cpu), dtype=np.int16) if n_cpu else None
-    for l0, g in synth.genotype_chunks(spec, nind, dev, ind_offset=rank * nind):
-        torch.cuda.synchronize()
-        panel.set_genotypes_device(g.data_ptr(), g.shape[1], l0, g.shape[0])
-        if n_cpu:
-            geno_sample[l0:l0 + g.shape[0]] = g[:, :n_cpu].cpu().numpy()
-    del g
+    n_cpu = 0 if (args.no_cpu or rank != 0 or world > 1 or args.mode != "lod") else min(args.cpu_inds, nind)
+    panel, geno_sample = load_panel(ctx, spec, nind, dev, ind_offset=rank * nind, n_cpu=n_cpu, gq=(args.mode == "tgls"))
 
     PITCH_ALIGN = 32
     base, pitch, total = panel.out_layout(PITCH_ALIGN, nind)
-    out = torch.empty(total, dtype=torch.float64, device=dev)
+    # Where the driver puts the score buffer in VRAM changes the chain kernel's time by up to 18 % (same
+    # code, same virtual layout, same box: 1.36 .. 1.64 ms at C2 -- DESIGN.md section 4, "placement").  A plain
+    # streaming fill runs equally fast on every allocation; what differs is how the kernel's few HBM reads mix
+    # with its write stream.  A caller that keeps its score buffer (GARLIC's sweep over window sizes does) can
+    # pick a good one once: while they fit, a few candidate buffers are allocated side by side, each is timed
+    # on three passes, the fastest is kept and the others are freed.  Every candidate's time is reported.
+    placement = None
+    n_cand = 1 if (args.out_candidates <= 1 or total * 8 * args.out_candidates > (96 << 30) or args.mode != "lod") else args.out_candidates
+    if n_cand > 1:
+        cands = [torch.empty(total, dtype=torch.float64, device=dev) for _ in range(n_cand)]
+        torch.cuda.synchronize()
+        times = []
+        for c in cands:
+            for _ in range(2):
+                panel.lod_windows_device(c.data_ptr(), W, ERROR, MAX_GAP, pitch_align=PITCH_ALIGN)
+            ctx.synchronize()
+            for _ in range(3):
+                panel.lod_windows_device(c.data_ptr(), W, ERROR, MAX_GAP, pitch_align=PITCH_ALIGN)
+            times.append(float(np.mean(ctx.recent_kernel_ms(3))))
+        best = int(np.argmin(times))
+        out = cands[best]
+        placement = {"candidates_kernel_ms": times, "kept": best,
+                     "note": "score buffers allocated side by side, 3 timed passes each, fastest kept"}
+        del cands, c
+        torch.cuda.empty_cache()
+    else:
+        out = torch.empty(total, dtype=torch.float64, device=dev)
+    setup = {}
+    if args.mode == "wlod":
+        # LD weights (calcLDData) from --ld-subsample 500 of the WHOLE panel: every rank counts over its own
+        # individuals, the integer counts are summed over ranks (the one collective of the weighted path,
+        # RCCL all-reduce), every rank finishes the floating-point part identically
+        sub = np.sort(np.random.default_rng(20260101).choice(nind * world, size=min(500, nind * world), replace=False))
+        mine = shard.split_subsample(sub, nind * world, world, rank)
+        loc = torch.zeros((nloci, 2), dtype=torch.int32, device=dev)
+        pair = torch.zeros((nloci, W, 2), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        panel.ld_counts_device(W, loc.data_ptr(), pair.data_ptr(), sub_idx=mine)
+        if world > 1:
+            if rehearse:
+                l2, p2 = shard.allreduce_ld_counts(loc.cpu(), pair.cpu())
+                loc.copy_(l2); pair.copy_(p2)
+            else:
+                shard.allreduce_ld_counts(loc, pair)
+        torch.cuda.synchronize()
+        panel.ld_finish_device(W, loc.data_ptr(), pair.data_ptr())
+        setup["ld_weights_s"] = time.perf_counter() - t0
+        del loc, pair
+        torch.cuda.empty_cache()
 
     def step():
-        panel.lod_windows_device(out.data_ptr(), W, error, max_gap, pitch_align=PITCH_ALIGN)
+        if args.mode == "lod":
+            panel.lod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, pitch_align=PITCH_ALIGN)
+        elif args.mode == "tgls":
+            panel.lod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, pitch_align=PITCH_ALIGN, use_gl=True)
+        else:
+            panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU, pitch_align=PITCH_ALIGN)
 
     for _ in range(args.warmup):
         step()
@@ -171,8 +435,13 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank = [float(x.item()) / args.steps * 1e3 for x in gathered]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -183,14 +452,14 @@ def main():
     if rank == 0:
         windows_per_step = nloci * nind * world            # sliding windows (SNPs x inds)
         lod_windows_per_step = windows_per_step / W        # BASELINE.json unit
-        ms_per_step = elapsed / args.steps * 1e3
         k_ms = float(np.mean(kernel_ms))
-        achieved = ALG_BYTES_PER_WINDOW * nloci * nind / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and args.workload == "c2" and nind == WORKLOADS["c2"][1]:
-            with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+        win_rank = nloci * nind
+        if args.mode == "lod":
+            roof = hbm_roofline("lod_chain_kernel", BYTES_LOD * win_rank, k_ms)
+        elif args.mode == "tgls":
+            roof = hbm_roofline("lod_chain_terms_kernel", BYTES_TGLS * win_rank, k_ms)
+        else:
+            roof = fp64_roofline("wlod_tile_kernel", win_rank, W, k_ms)
         res = {
             "metric": "LOD-windows/sec (SNPs x inds / winsize)",
             "value": lod_windows_per_step * args.steps / elapsed,
@@ -198,33 +467,29 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": desc,
+                "workload": desc, "mode": {"lod": "unweighted --error", "wlod": "--weighted (LD weights from --ld-subsample 500)",
+                                           "tgls": "TGLS --gl-type GQ"}[args.mode],
                 "snps": nloci, "inds_per_gpu": nind, "inds_total": nind * world, "winsize": W,
-                "error": error, "max_gap": max_gap, "output": "full FP64 scores, individual-major",
-                "sharding": "individuals across GPUs, no collective",
+                "error": ERROR, "max_gap": MAX_GAP, "output": "full FP64 scores, individual-major",
+                "sharding": "individuals across GPUs, no collective on the data path",
             },
             "sliding_windows_per_s": windows_per_step * args.steps / elapsed,
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "lod_chain_kernel",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel_ms": k_ms,
-                "algorithmic_bytes_per_launch": ALG_BYTES_PER_WINDOW * nloci * nind,
-            },
-            "plan": {k: int(st[k]) for k in ("n_segments", "n_runs", "n_chain_items",
-                                             "n_valid_windows", "n_missing")},
+            "roofline": roof,
+            "plan": {k: int(st[k]) for k in ("n_segments", "n_runs", "n_chain_items", "n_valid_windows", "n_missing")},
         }
+        if per_rank is not None:
+            res["ms_per_step_by_rank"] = per_rank
+        if setup:
+            res["setup"] = setup
+        if placement:
+            res["output_placement"] = placement
         if n_cpu:
             host = out.cpu().numpy() if total * 8 < (6 << 30) else None
             rows = []
@@ -235,12 +500,40 @@ def main():
                 else:
                     blk = out[base[c]: base[c] + nind * pitch[c]].view(nind, pitch[c])[:n_cpu].cpu().numpy()
                 rows.append(blk[:n_cpu, :n])
-            res["cpu_baseline"] = cpu_baseline(spec, geno_sample, W, error, max_gap, rows)
+            res["cpu_baseline"] = cpu_baseline(spec, geno_sample, W, rows)
             res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
+            del host
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
     panel.close()
+    del out, geno_sample
+    torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and args.also != "none":
+        want = ["e2e", "ns", "c3"] if args.also == "auto" else [x for x in args.also.split(",") if x]
+        also = {}
+        ctx.set_async(True)
+        for name in want:
+            used = time.perf_counter() - T_START
+            if used > args.also_budget_s:
+                also[name] = {"skipped": f"time budget: {used:.0f} s used of --also-budget-s {args.also_budget_s:.0f}"}
+                continue
+            t0 = time.perf_counter()
+            try:
+                if name == "e2e":
+                    ctx.set_async(False)
+                    res["end_to_end"] = leg_end_to_end(ctx, dev)
+                    ctx.set_async(True)
+                    continue
+                also[{"ns": "c4_c5_shard", "c3": "c3_multi_winsize"}[name]] = dict(
+                    (leg_ns if name == "ns" else leg_c3)(ctx, dev, max(3, min(args.steps, 10))),
+                    leg_wall_s=None)
+                also[{"ns": "c4_c5_shard", "c3": "c3_multi_winsize"}[name]]["leg_wall_s"] = time.perf_counter() - t0
+            except Exception as e:   # a leg that fails (e.g. another process holds the memory) must not cost the headline
+                also[name] = {"failed": f"{type(e).__name__}: {e}"}
+        res["also"] = also
+    if rank == 0:
+        print(json.dumps(res))
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

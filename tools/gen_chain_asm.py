@@ -630,19 +630,28 @@ def pre_tile(g, slot, uid):
     e(f"s_branch PRE_POLL_{uid}_%=")
     e(f"PRE_GO_{uid}_%=:")
     g.drained()
-    gen_prefetch(g, slot, slot % CHPERIOD == 0)
-    e(f"s_waitcnt vmcnt({loads_in_flight(slot)})")
-    e(f"s_add_u32 s{S_F1}, s{S_K}, {NSLOT - NFLY + 1}")
-    e(f"s_max_u32 s{S_F1}, s{S_F1}, {NSLOT}")
-    e(f"v_mov_b32_e32 v{V_TMP1}, s{S_F1}")
-    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP1} offset:16")  # tabs_landed = tiles 0 .. k+NSLOT-NFLY (a count)
+    if "prefirst" in ABL:
+        gen_prefetch(g, slot, slot % CHPERIOD == 0)
+        e(f"s_waitcnt vmcnt({loads_in_flight(slot)})")
+        e(f"s_add_u32 s{S_F1}, s{S_K}, {NSLOT - NFLY + 1}")
+        e(f"s_max_u32 s{S_F1}, s{S_F1}, {NSLOT}")
+        e(f"v_mov_b32_e32 v{V_TMP1}, s{S_F1}")
+        e(f"ds_write_b32 v{V_FLAG}, v{V_TMP1} offset:16")  # tabs_landed = tiles 0 .. k+NSLOT-NFLY (a count)
+    # what CHAIN waits for comes first: the requests below may block at issue behind POST's stores
     post_expand(g, (slot + ELEAD) % NSLOT)
-    e(f"s_add_u32 s{S_K}, s{S_K}, 1")
-    e(f"s_add_u32 s{S_F1}, s{S_K}, {ELEAD - 1}")
+    e(f"s_add_u32 s{S_F1}, s{S_K}, {ELEAD}")
     e(f"v_mov_b32_e32 v{V_TMP1}, s{S_F1}")
     e("s_waitcnt lgkmcnt(0)")
     g.drained()
     e(f"ds_write_b32 v{V_FLAG}, v{V_TMP1} offset:8")   # inputs_ready = k + ELEAD
+    if "prefirst" not in ABL:
+        gen_prefetch(g, slot, slot % CHPERIOD == 0)
+        e(f"s_waitcnt vmcnt({loads_in_flight(slot)})")
+        e(f"s_add_u32 s{S_F1}, s{S_K}, {NSLOT - NFLY + 1}")
+        e(f"s_max_u32 s{S_F1}, s{S_F1}, {NSLOT}")
+        e(f"v_mov_b32_e32 v{V_TMP1}, s{S_F1}")
+        e(f"ds_write_b32 v{V_FLAG}, v{V_TMP1} offset:16")  # tabs_landed = tiles 0 .. k+NSLOT-NFLY (a count)
+    e(f"s_add_u32 s{S_K}, s{S_K}, 1")
 
 
 def gen_pre(g):
