@@ -9,6 +9,7 @@
 #include "lod_kernels.hpp"
 #include "variant_kernels.hpp"
 #include "ld_kernels.hpp"
+#include "tgls_ring_kernel.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -958,7 +959,13 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                       p->d_items.p,  p->d_chrs.p, d_out,        p->nind_pad,  p->nwordrows, ind_begin,    ind_count,
                       W,             (int32_t)p->gl_values.size(), use_gl ? 1 : 0,
                       (use_gl && p->gl_cont) ? p->d_glterms.p : nullptr, (int64_t)(GOFF + p->nloci + GPAD_BACK)};
-        if (mode == MODE_LOD_GL && p->glterms_valid && !p->glterms_scaled) {
+        if (mode == MODE_LOD_GL && p->glterms_valid && !p->glterms_scaled && (ind_begin & (WAVE - 1)) == 0 &&
+            !getenv("GARLIC_TGLS_NO_RING")) {
+            // persistent workgroups, every term row through an LDS ring once (tgls_ring_kernel.hpp)
+            TglsArgs t{p->d_glterms.p, (int64_t)(GOFF + p->nloci + GPAD_BACK), p->d_items.p, p->d_chrs.p, d_out,
+                       ind_begin, ind_count, W, (int32_t)n_items, p->d_counter.p};
+            hipLaunchKernelGGL(lod_chain_ring_kernel, dim3((unsigned)workers), dim3(TG_THREADS), 0, ctx->stream, t);
+        } else if (mode == MODE_LOD_GL && p->glterms_valid && !p->glterms_scaled) {
             hipLaunchKernelGGL(lod_chain_terms_kernel, dim3((unsigned)n_items), dim3(2 * WAVE), 0, ctx->stream, a,
                                (int)n_items, (int64_t)(GOFF + p->nloci + GPAD_BACK), p->d_glterms.p);
         } else if (mode == MODE_LOD_GL) {
