@@ -87,6 +87,15 @@ double host_lod(int genotype, double freq, double error)
     return log10(autozygous / nonAutozygous);
 }
 
+// most negative finite entry of a term table (0 if none is negative)
+double min_finite(const double *x, size_t n)
+{
+    double m = 0.0;
+    for (size_t i = 0; i < n; i++)
+        if (x[i] < m && x[i] > -1.7976931348623157e308) m = x[i];
+    return m;
+}
+
 template <class F> void parallel_for(int64_t n, int64_t grain, F f)
 {
     unsigned hw = std::thread::hardware_concurrency();
@@ -137,6 +146,7 @@ struct garlic_panel {
     DevBuf<double> d_tab;
     bool tab_valid = false;
     double tab_error = 0;
+    double tab_min = 0, tabgl_min = 0, glterms_min = 0;   // most negative finite term (lod_exact_needed)
     // segment boundaries (global loci, ascending), cached per max_gap
     bool seg_valid = false;
     int32_t seg_max_gap = 0;
@@ -289,6 +299,7 @@ int ensure_term_table(garlic_panel *p, double error)
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     p->tab_valid = true;
     p->tab_error = error;
+    p->tab_min = min_finite(tab.data(), tab.size());
     p->h_tab.swap(tab);
     p->wtab_valid = false;
     return GARLIC_OK;
@@ -359,6 +370,17 @@ void plan_runs(const garlic_panel *p, int32_t W, std::vector<Run> &runs, std::ve
 
 enum Mode { MODE_LOD, MODE_LOD_GL, MODE_WLOD };
 
+// The reference tests "previous window has no score" by value (garlic-roh.cpp:79); the tuned chains by
+// position.  They agree unless a scored window sums to exactly -9999.0, which needs W terms that can add
+// up to it: impossible while W * (most negative term) stays above -9999 (a margin covers the rounding of
+// the sums).  Otherwise the exact kernel runs (lod_chain_exact_kernel).  Tables / terms must be current.
+bool lod_exact_needed(const garlic_panel *p, Mode mode, int32_t W)
+{
+    if (getenv("GARLIC_EXACT_CHAIN")) return true;
+    const double tmin = mode == MODE_LOD ? p->tab_min : (p->gl_cont ? p->glterms_min : p->tabgl_min);
+    return (double)W * tmin <= -9990.0;
+}
+
 // ---- TGLS: term table per (SNP, error code, genotype), host libm
 int ensure_gl_table(garlic_panel *p)
 {
@@ -387,6 +409,7 @@ int ensure_gl_table(garlic_panel *p)
     HIP_TRY(hipStreamSynchronize(p->ctx->stream));
     p->tabgl_valid = true;
     p->tabgl_ncodes = ncodes;
+    p->tabgl_min = min_finite(tab.data(), tab.size());
     p->glterms_valid = false;
     return GARLIC_OK;
 }
@@ -630,6 +653,18 @@ int ensure_gl_terms(garlic_panel *p, bool scaled = false, int32_t M = 0, double 
         }
         p->gl_terms_by = on_host ? 2 : 1;
         p->glterms_scaled = false;
+        {   // most negative finite term, for lod_exact_needed
+            constexpr int NB = 1024;
+            DevBuf<double> d_part;
+            if ((rc = d_part.reserve(NB))) return rc;
+            double part[NB];
+            hipLaunchKernelGGL(min_finite_kernel, dim3(NB), dim3(256), 0, s, p->d_glterms.p, (int64_t)n, d_part.p);
+            hipError_t e = hipMemcpyAsync(part, d_part.p, sizeof part, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            d_part.release();
+            if (e != hipSuccess) return fail(GARLIC_ERR_HIP, "term minimum: %s", hipGetErrorString(e));
+            p->glterms_min = min_finite(part, NB);
+        }
     } else if (rebuild) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GARLIC_OK;
@@ -756,6 +791,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // tuned wLOD kernels: 16 window accumulators per lane; scores from one LDS row per SNP (plain
     // --error) or from the TGLS score matrix (use_gl); very narrow / very wide windows keep the
     // generic kernel
+    const bool exact = mode != MODE_WLOD && lod_exact_needed(p, mode, W);
+    if (exact && thin_step > 0) return fail(GARLIC_ERR_INVALID, "internal: thinned output with the exact chain");
     const bool wlod_shape_ok = mode == MODE_WLOD && W >= WLOD_R && W + 64 <= GPAD_BACK &&
                                !getenv("GARLIC_WLOD_GENERIC");
     if (wlod_shape_ok && use_gl && (rc = ensure_gl_terms(p, true, M, mu))) return rc;
@@ -924,6 +961,12 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         else
             hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, false>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
                                a_packed, a_wtab, a_skew, d_out, a);
+    } else if (n_items && exact) {
+        VariantArgs a{p->d_packed.p, p->d_tab.p,  p->d_tabgl.p, p->d_codes.p, p->d_decay.p, p->d_rld.p,
+                      p->d_items.p,  p->d_chrs.p, d_out,        p->nind_pad,  p->nwordrows, ind_begin,    ind_count,
+                      W,             (int32_t)p->gl_values.size(), use_gl ? 1 : 0,
+                      (use_gl && p->gl_cont) ? p->d_glterms.p : nullptr, (int64_t)(GOFF + p->nloci + GPAD_BACK)};
+        hipLaunchKernelGGL(lod_chain_exact_kernel, dim3((unsigned)n_items), dim3(WAVE), 0, ctx->stream, a, (int)n_items);
     } else if (n_items && mode == MODE_LOD) {
         ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p,     p->d_chrs.p,     d_out, p->nind_pad, p->nwordrows,
                     ind_begin,     ind_count,  W,               (int32_t)n_items, thin_step, p->d_counter.p, nullptr};
@@ -1925,7 +1968,12 @@ int garlic_lod_feed_subset(garlic_panel *p, int32_t winsize, double error, int32
     // windows (8/step B per window instead of 8 B, no full-size scratch).  Otherwise the full scores
     // go to the panel's device scratch (the one host-output calls use; it stays allocated, hipMalloc
     // of 8 GB per call would cost more than the kernels) and are sampled from there.
-    const int32_t thinned = (!weighted && !use_gl && step >= 4 && !getenv("GARLIC_FEED_FULL")) ? step : 0;
+    int32_t thinned = (!weighted && !use_gl && step >= 4 && !getenv("GARLIC_FEED_FULL")) ? step : 0;
+    if (thinned) {   // the exact chain (lod_exact_needed) writes full scores only
+        if (!p->have_freq) return done(fail(GARLIC_ERR_STATE, "panel needs map, freq and genotypes before computing LOD"));
+        if ((rc = ensure_term_table(p, error))) return done(rc);
+        if (lod_exact_needed(p, MODE_LOD, winsize)) thinned = 0;
+    }
     const Layout L = make_layout(p, 32, p->nind, thinned);
     DevBuf<double> &scores = p->d_out;
     DevBuf<double> &d_feed = p->d_feed;            // kept with the panel: window-size sweeps call this repeatedly

@@ -427,6 +427,71 @@ __global__ void reciprocal_kernel(const double *__restrict__ ld, double *__restr
     for (; i < n; i += stride) rld[i] = reciprocal_x86(ld[i]);
 }
 
+// ---- The reference's rolling sum to the letter, for the inputs where the letter matters.
+// calcLOD decides "the previous window holds no score" by VALUE (garlic-roh.cpp:79: win[ind][locus-1] !=
+// MISSING): a scored window whose sum is exactly -9999.0 makes the next window a fresh left-to-right sum of
+// its W terms instead of (previous - leaving) + entering -- the same real number, another rounding.  The
+// tuned chains carry "previous window scored" by position.  The two can only differ when a window sum can
+// reach -9999 at all: the host checks W * (most negative term of the panel) against that (lod_exact_needed
+// in garlic_hip.hip; with --error 0.001 a window would need 3333 heterozygous SNPs), and only then runs this
+// kernel: one wavefront per (run, 64 individuals), lane = individual, every term looked up in memory, the
+// reference's control flow per window.  Slow (it is never on a realistic input's path), exact.
+__global__ void __launch_bounds__(WAVE)
+lod_chain_exact_kernel(VariantArgs p, int n_items)
+{
+    __shared__ double tile[WAVE * TPITCH];
+    const int item = blockIdx.x;
+    if (item >= n_items) return;
+    const ChainItem it = p.items[item];
+    if (it.chr < 0) return;
+    const ChrDev c = p.chrs[it.chr];
+    const int lane = threadIdx.x, W = p.winsize, a = it.a, b = it.b;
+    const int rows_valid = min(WAVE, p.ind_count - it.ind0);
+    const int64_t col = (int64_t)p.ind_begin + it.ind0 + lane;
+    const int64_t Gbase = c.loc_base + GOFF;
+    double *out_row0 = p.out + c.out_base + (int64_t)it.ind0 * c.out_pitch;
+    double prev = MISSING_D;                               // the window in front of a run holds no score
+    for (int s0 = a & ~(TILE - 1); s0 <= b; s0 += TILE) {
+        for (int j = 0; j < TILE; j++) {
+            const int s = s0 + j;
+            double v = 0.0;
+            if (s >= a && s <= b) {
+                if (prev != MISSING_D) {                   // garlic-roh.cpp:79, 92-100 (NaN != MISSING: rolls on)
+                    v = (prev - variant_term(p, Gbase + s - 1, col)) + variant_term(p, Gbase + s + W - 1, col);
+                } else {                                   // :57-71 / :106-120: from 0, left to right
+                    for (int i = 0; i < W; i++) v += variant_term(p, Gbase + s + i, col);
+                }
+                prev = v;
+            }
+            tile[lane * TPITCH + j] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        variant_store(tile, s0, a, b, lane, rows_valid, out_row0 + s0, c.out_pitch);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// most negative finite value of a double array (one partial per workgroup; the host takes their minimum)
+__global__ void __launch_bounds__(256)
+min_finite_kernel(const double *__restrict__ x, int64_t n, double *__restrict__ partial)
+{
+    __shared__ double red[256];
+    double m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = x[i];
+        if (v < m && v > -1.7976931348623157e308) m = v;   // NaN and -inf fail the comparisons
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) red[threadIdx.x] = fmin(red[threadIdx.x], red[threadIdx.x + d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 // ---- wLOD: every valid window summed afresh (garlic-roh.cpp:253-273)
 // dynamic LDS: score ring [ring][64] doubles | rld row [winsize] | transpose tile [64][TPITCH]
 __global__ void __launch_bounds__(WAVE)

@@ -227,3 +227,71 @@ def test_weighted_terms_follow_a_new_map(gpu_ctx):
             panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms],
                           gpos=np.concatenate(gpos2))
             check_wlod(panel, chroms, err, gpos2, lds, W, pitch_align=32)
+
+
+def test_a_window_sum_of_exactly_minus_9999(gpu_ctx):
+    """garlic-roh.cpp:79 decides "the previous window holds no score" by VALUE: a scored window that sums to
+    exactly -9999.0 makes the next one a fresh left-to-right sum instead of (previous - leaving) + entering.
+    Constructed here: 40 heterozygous SNPs at frequency 0.5 (lod = log10(error)) with per-genotype errors
+    near 1e-250, the last one chosen so that the left-to-right sum of the run's first window is -9999.0 to
+    the bit.  The library notices that W * (most negative term) can reach -9999 and runs its exact chain."""
+    o = ol.oracle()
+    W, n, nind = 40, 200, 3
+    rng = np.random.default_rng(0)
+    e0 = 10.0 ** (-rng.uniform(2, 6, size=n))
+    e0[:39] = 10.0 ** (-rng.uniform(249.5, 250.5, size=39))
+    lod1 = lambda x: o.oracle_lod(1, 0.5, float(x))
+    S = 0.0
+    for x in e0[:39]:
+        S += lod1(x)
+    target = -9999.0 - S
+    lo, hi = int(np.float64(1e-300).view(np.uint64)), int(np.float64(1e-200).view(np.uint64))
+    while lo < hi:                      # lod is monotone in the error: bisection on the bit pattern
+        mid = (lo + hi) // 2
+        if lod1(np.uint64(mid).view(np.float64)) < target:
+            lo = mid + 1
+        else:
+            hi = mid
+    e0[39] = np.uint64(lo).view(np.float64)
+    assert lod1(e0[39]) == target and S + target == -9999.0
+    g = rng.integers(0, 3, size=(n, nind)).astype(np.int16)
+    g[:, 0] = 1
+    f = np.full(n, 0.5)
+    pos = (np.arange(n, dtype=np.int64) * 1000 + 1000).astype(np.int32)
+    e = 10.0 ** (-rng.uniform(2, 6, size=(n, nind)))
+    e[:, 0] = e0
+    want = ol.oracle_calc_lod(g, f, pos, 0, 0, W, 0.001, MG, gl=e)
+    t = [lod1(x) for x in e0]
+    fresh = 0.0
+    for i in range(1, W + 1):
+        fresh += t[i]
+    assert want[0, 0] == -9999.0 and want[0, 1] == fresh != (-9999.0 - t[0]) + t[W]   # the by-value branch is live
+    with make_panel(gpu_ctx, [(g, f, pos, 0, 0)], nind) as panel:
+        panel.set_gl(e)
+        for pa in (1, 32):
+            out = panel.lod_windows(W, 0.001, MG, use_gl=True, pitch_align=pa)
+            assert ol.bits_equal(np.ascontiguousarray(out[0]), want), pa
+        feed, _ = panel.lod_feed(W, 0.001, MG, 7, use_gl=True)
+        assert ol.bits_equal(feed, ol.oracle_flatten(want, 7))     # -9999.0 is dropped as MISSING, as in the reference
+
+
+def test_exact_chain_forced(gpu_ctx):
+    """GARLIC_EXACT_CHAIN=1: the to-the-letter kernel on ordinary panels (unweighted, dictionary TGLS,
+    continuous TGLS, the feed) equals the oracle like the tuned chains do"""
+    rng = np.random.default_rng(61)
+    nind, sizes, W = 130, [700, 45, 300], 30
+    chroms = [ol.random_panel(rng, n, nind, max_gap=MG, gaps=2 if n > 500 else 0) for n in sizes]
+    with env(GARLIC_EXACT_CHAIN=1):
+        for kind in ("dictionary", "continuous"):
+            err = [rng.choice([1e-3, 0.01, 0.2], size=c[0].shape) if kind == "dictionary"
+                   else rng.uniform(1e-4, 0.5, size=c[0].shape) for c in chroms]
+            with make_panel(gpu_ctx, chroms, nind) as panel:
+                panel.set_gl(np.concatenate(err, axis=0))
+                check_tgls(panel, chroms, err, W, pitch_align=32)
+                check_tgls(panel, chroms, err, W, ind_begin=37, ind_count=70, pitch_align=1)
+                got = panel.lod_windows(W, 0.001, MG, pitch_align=32)
+                wants = [ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, MG) for g, f, p, cs, ce in chroms]
+                for c in range(len(chroms)):
+                    assert ol.bits_equal(np.ascontiguousarray(got[c]), wants[c]), (kind, c)
+                feed, per_chr = panel.lod_feed(W, 0.001, MG, W)
+                assert ol.bits_equal(feed, np.concatenate([ol.oracle_flatten(w, W) for w in wants]))
