@@ -371,6 +371,7 @@ struct TpedLine {          // one parsed TPED line (garlic-data.cpp:56-141)
     bool *first = nullptr;
     char one = 0;
     double freq = 0;
+    int total = 0;         // non-missing alleles on the line
 };
 
 TpedLine parseTpedLine(const std::string &line, char TPED_MISSING, bool PHASED)
@@ -409,6 +410,7 @@ TpedLine parseTpedLine(const std::string &line, char TPED_MISSING, bool PHASED)
         if (r.first) r.first[i] = (a1 == one);   // garlic-data.cpp:129
     }
     r.one = one;
+    r.total = total;
     r.freq = total == 0 ? 0.0 : double(nalleles) / double(total); // garlic-data.cpp:140-141
     return r;
 }
@@ -416,8 +418,15 @@ TpedLine parseTpedLine(const std::string &line, char TPED_MISSING, bool PHASED)
 
 void loadTPEDData(const std::string &tpedfile, int &numLoci, int &numInd, std::vector<HapData *> **hapDataByChr,
                   std::vector<MapData *> **mapDataByChr, std::vector<FreqData *> **freqDataByChr,
-                  char TPED_MISSING, bool PHASED)
+                  char TPED_MISSING, bool PHASED, int nresample, unsigned long long resampleSeed)
 {
+    // --resample (garlic-data.cpp:16-20, 142-148): the frequency of every SNP becomes the fraction of
+    // nresample uniform draws that fall at or below it, one generator for the whole file, in file order.
+    // The reference's generator is GSL's default, mt19937 seeded with time(NULL), gsl_rng_uniform =
+    // 32 bits / 2^32: std::mt19937 seeded alike is the same stream (GSL maps seed 0 to 4357), so a run
+    // given the reference's seed resamples to the same frequencies.
+    const unsigned long long seed0 = resampleSeed ? resampleSeed : (unsigned long long)time(nullptr);
+    std::mt19937 resampler((uint32_t)(seed0 & 0xffffffffull) ? (uint32_t)(seed0 & 0xffffffffull) : 4357u);
     LineReader in(tpedfile);
     *hapDataByChr = new std::vector<HapData *>;
     *mapDataByChr = new std::vector<MapData *>;
@@ -465,6 +474,12 @@ void loadTPEDData(const std::string &tpedfile, int &numLoci, int &numInd, std::v
             ppos.push_back(r.p);
             names.push_back(r.name);
             allele.push_back(r.one);
+            if (nresample > 0 && r.total != 0) {
+                int count = 0;
+                for (int i = 0; i < nresample; i++)
+                    if ((double)resampler() / 4294967296.0 <= r.freq) count++;
+                r.freq = double(count) / double(nresample);
+            }
             freq.push_back(r.freq);
         }
     }

@@ -132,7 +132,10 @@ void releaseIndData(IndData *d);
 void loadTPEDData(const std::string &tpedfile, int &numLoci, int &numInd,
                   std::vector<HapData *> **hapDataByChr, std::vector<MapData *> **mapDataByChr,
                   std::vector<FreqData *> **freqDataByChr, char TPED_MISSING,
-                  bool PHASED = false);                                          // garlic-data.cpp:10
+                  bool PHASED = false, int nresample = 0,
+                  unsigned long long resampleSeed = 0);                          // garlic-data.cpp:10
+// nresample > 0 (--resample, garlic-data.cpp:142-148): binomial resampling of every frequency, one mt19937
+// stream in file order; resampleSeed 0 = time(NULL) as in the reference, else the stream GSL gives that seed
 void scanIndData3(const std::string &filename, int &numInd, std::string &popName);  // :1893
 IndData *readIndData3(const std::string &filename, int numInd);                     // :1963
 std::vector<GenoLikeData *> *readTGLSData(const std::string &filename, int expectedLoci, int expectedInd,

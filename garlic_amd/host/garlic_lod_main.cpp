@@ -30,6 +30,8 @@ struct Args {
     int auto_winsize_step = 10, max_gap = 200000, M = 7, threads = 1, kde_subsample = 20, gpus = 1;
     std::vector<int> devices;      // --devices; empty = 0 .. gpus-1
     int ld_subsample = 0;          // src/garlic-cli.cpp:137
+    int resample = 0;              // src/garlic-cli.cpp:62-64: resamples for the allele frequencies
+    unsigned long long resample_seed = 0;   // extension: 0 = time-seeded like the reference
     unsigned long long ld_seed = 0; // extension: 0 = time-seeded like the reference
     unsigned long long kde_seed = 0; // extension: the --kde-subsample draw, 0 = time-seeded like the reference
     double mu = 1e-9, overlap_frac = 0.25;
@@ -43,7 +45,7 @@ struct Args {
                  "         [--auto-winsize] [--auto-winsize-step N] [--max-gap N] [--overlap-frac X]\n"
                  "         [--freq-file F] [--tped-missing C] [--raw-lod] [--kde-subsample N] [--kde-seed S] [--no-kde-thinning]\n"
                  "         [--weighted --map F --M N --mu X --ld-subsample N --ld-seed S --threads N]\n"
-                 "         [--gpus N | --devices 0,1,...] [--genotype-cache F]\n";
+                 "         [--resample N --resample-seed S] [--gpus N | --devices 0,1,...] [--genotype-cache F]\n";
     exit(1);
 }
 
@@ -83,6 +85,8 @@ Args parse(int argc, char **argv)
         else if (f == "--raw-lod") a.raw_lod = !a.raw_lod;
         else if (f == "--kde-subsample") a.kde_subsample = atoi(val().c_str());
         else if (f == "--kde-seed") a.kde_seed = strtoull(val().c_str(), nullptr, 10);
+        else if (f == "--resample") a.resample = atoi(val().c_str());
+        else if (f == "--resample-seed") a.resample_seed = strtoull(val().c_str(), nullptr, 10);
         else if (f == "--no-kde-thinning") a.kde_thinning = !a.kde_thinning;
         else if (f == "--gpus") a.gpus = atoi(val().c_str());
         else if (f == "--devices") {   // explicit HIP ordinals, e.g. 0,1,2,3 (an ordinal may repeat: shards share that GPU)
@@ -148,7 +152,9 @@ int main(int argc, char **argv)
                 return 1;
             }
         } else {
-            loadTPEDData(a.tped, numLoci, numInd, &haps, &maps, &freqs, a.tped_missing, a.phased);
+            loadTPEDData(a.tped, numLoci, numInd, &haps, &maps, &freqs, a.tped_missing, a.phased, a.resample,
+                         a.resample_seed);
+            if (a.resample > 0) std::cerr << "Allele frequencies resampled: " << a.resample << "\n";   // garlic-main.cpp:91
             if (a.cache != "none") {
                 writeGenotypeCache(a.cache, haps, maps, freqs);
                 std::cerr << "Wrote genotype cache " << a.cache << "\n";

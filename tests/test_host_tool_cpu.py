@@ -71,3 +71,25 @@ def test_compact_host_containers(tmp_path):
     r = subprocess.run([exe, os.path.join(E2E, "tiny.tped.gz"), os.path.join(E2E, "tiny.tgls.gz"), "GQ", str(tmp_path)],
                        capture_output=True, text=True)
     assert r.returncode == 0 and "host_unit ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_resample_is_the_gsl_mt19937_stream(tmp_path):
+    """--resample N (garlic-data.cpp:16-20, 142-148): per SNP, in file order, N draws of one mt19937 stream
+    (GSL's default generator, gsl_rng_uniform = 32 bits / 2^32); with --resample-seed the draw is repeatable and
+    equals the textbook generator seeded alike (numpy's legacy RandomState = init_genrand, as GSL).  Ingest is
+    host code: the .freq.gz is written before the tool asks for a GPU."""
+    import gzip
+    import numpy as np
+    outs = {}
+    for tag, extra in (("plain", []), ("r7", ["--resample", "50", "--resample-seed", "7"]),
+                       ("r7b", ["--resample", "50", "--resample-seed", "7"]), ("r8", ["--resample", "50", "--resample-seed", "8"])):
+        out = str(tmp_path / tag)
+        run(*BASE, "--centromere", os.path.join(E2E, "tiny.centromeres.txt"), "--error", "0.001", "--winsize", "30",
+            "--out", out, *extra)
+        outs[tag] = np.array([float(l.split()[-1]) for l in list(gzip.open(out + ".freq.gz", "rt"))[1:]])
+    assert np.array_equal(outs["r7"], outs["r7b"]) and not np.array_equal(outs["r7"], outs["r8"])
+    assert np.allclose(outs["r7"] * 50, np.round(outs["r7"] * 50))
+    raw = np.random.RandomState(7).randint(0, 2 ** 32, size=outs["plain"].shape[0] * 50, dtype=np.uint64) / 4294967296.0
+    want = np.array([np.count_nonzero(raw[50 * k: 50 * k + 50] <= f) / 50.0 for k, f in enumerate(outs["plain"])])
+    # (.freq.gz prints 6 digits: a draw within 1e-6 of the frequency may fall on the other side)
+    assert np.count_nonzero(want != outs["r7"]) <= 2
