@@ -579,6 +579,22 @@ lod_chain_kernel(ChainArgs p)
             const uint32_t a_roff0 = (uint32_t)((GARLIC_CHAIN_CHROWS * chunk0) & wmask) * 256u;
             const uint32_t a_laddr0 = (uint32_t)(st.lead_w & wmask) * 256u;
             const uint32_t a_taddr0 = (uint32_t)(st.trail_w & wmask) * 256u;
+            if (wave == 0) {
+                // PRE's spreading tables (tools/gen_chain_asm.py, post_expand): entry b = the four genotypes
+                // of byte b, one per byte, times 16 (entering stream) / times 64 (leaving stream).  They live
+                // in the generic path's slot, which the head tile above has just finished with; every wave
+                // drains its LDS operations and meets at a barrier at the top of the loop.
+                uint32_t tin[4], tout[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t bb = 4u * (uint32_t)lane + (uint32_t)q;
+                    const uint32_t sp = (bb & 3u) | (((bb >> 2) & 3u) << 8) | (((bb >> 4) & 3u) << 16) | (((bb >> 6) & 3u) << 24);
+                    tin[q] = sp << 4;
+                    tout[q] = sp << 6;
+                }
+                *reinterpret_cast<uint4 *>(smem + GARLIC_CHAIN_SPREAD_IN + lane * 16) = make_uint4(tin[0], tin[1], tin[2], tin[3]);
+                *reinterpret_cast<uint4 *>(smem + GARLIC_CHAIN_SPREAD_OUT + lane * 16) = make_uint4(tout[0], tout[1], tout[2], tout[3]);
+            }
             if (THIN) {
                 // first sampled locus at or after s0; POST stores one column per sample
                 // (the division runs on the vector ALU: make the wave-uniform result scalar again)

@@ -50,7 +50,8 @@ CHAIN per tile (32 window starts x 64 individuals), software pipeline over 8-ste
   iteration g:  wait R(g) | issue R(g+1) | C(g) (+) A(g+2)
 
 LDS map (bytes; lod_kernels.hpp takes GARLIC_CHAIN_LDS_* from the generated file):
-      0  generic-path slot (3072), item word (3072), flags (3584 .. 3603)
+      0  generic-path slot (3072; during the loop: PRE's two 1-KB spreading tables), item word (3072),
+         flags (3584 .. 3603)
    4096  COMB ring  NEXP x 8192    per step 16 entries x {t_out, t_in}    (CHAIN: immediate offsets)
       +  EXP ring   NEXP x 2048    32 bytes per lane
       +  TAB ring   NSLOT x 2048   {lead term rows 1024, trail term rows 1024}        (LDS-DMA target)
@@ -83,6 +84,7 @@ NEXP = 4              # depth of the rings CHAIN reads (combined term table, exp
 ELEAD = 3             # PRE prepares tile k+ELEAD once CHAIN has finished tile k
 assert NSLOT % NEXP == 0 and ELEAD < NEXP and ELEAD <= NSLOT - NFLY and NSLOT % NTILE == 0
 FLAGS = 3584          # +0 tiles_done, +4 tiles_stored, +8 exp_ready, +12 comb_ready, +16 tabs_landed
+SPREAD_IN, SPREAD_OUT = 0, 1024   # PRE's genotype-spreading tables (inside the generic path's slot, idle during the loop)
 # Rings.  What CHAIN reads with immediate offsets (16-bit DS offset field) comes first:
 #   COMB  tile t -> slot t % NEXP: per window step one 256-B table of the 16 (leaving genotype,
 #         entering genotype) combinations, entry = {t_out, t_in}: ONE look-up per window
@@ -437,20 +439,39 @@ def post_expand(g, slot):
     e(f"v_alignbit_b32 v{V_TH}, v{V_WT2}, v{V_WT1}, s{S_SHT}")
     e(f"v_mov_b32_e32 v{V_LC}, v{V_WL2}")
     e(f"v_mov_b32_e32 v{V_TC}, v{V_WT2}")
-    t = [V_X + 8 + i for i in range(8)]          # scratch: g_in 0-3, g_out 4-7
-    for d in range(8):                            # dword d holds steps 4d..4d+3
-        lsrc, tsrc = (V_LL, V_TL) if d < 4 else (V_LH, V_TH)
-        o = 8 * (d % 4)
-        dst = V_X + d
-        for i in range(4):
-            e(f"v_bfe_u32 v{t[i]}, v{lsrc}, {o + 2 * i}, 2")
-            e(f"v_bfe_u32 v{t[4 + i]}, v{tsrc}, {o + 2 * i}, 2")
-        for i in range(4):
-            e(f"v_lshl_or_b32 v{t[i]}, v{t[4 + i]}, 2, v{t[i]}")      # 4 * g_out + g_in
-        e(f"v_lshl_or_b32 v{t[0]}, v{t[1]}, 8, v{t[0]}")
-        e(f"v_lshl_or_b32 v{t[2]}, v{t[3]}, 8, v{t[2]}")
-        e(f"v_lshl_or_b32 v{dst}, v{t[2]}, 16, v{t[0]}")
-        e(f"v_lshlrev_b32_e32 v{dst}, 4, v{dst}")
+    if "bfeexpand" in ABL:                        # the all-VALU expansion this replaced: 16 instructions per dword
+        t = [V_X + 8 + i for i in range(8)]      # scratch: g_in 0-3, g_out 4-7
+        for d in range(8):                        # dword d holds steps 4d..4d+3
+            lsrc, tsrc = (V_LL, V_TL) if d < 4 else (V_LH, V_TH)
+            o = 8 * (d % 4)
+            dst = V_X + d
+            for i in range(4):
+                e(f"v_bfe_u32 v{t[i]}, v{lsrc}, {o + 2 * i}, 2")
+                e(f"v_bfe_u32 v{t[4 + i]}, v{tsrc}, {o + 2 * i}, 2")
+            for i in range(4):
+                e(f"v_lshl_or_b32 v{t[i]}, v{t[4 + i]}, 2, v{t[i]}")      # 4 * g_out + g_in
+            e(f"v_lshl_or_b32 v{t[0]}, v{t[1]}, 8, v{t[0]}")
+            e(f"v_lshl_or_b32 v{t[2]}, v{t[3]}, 8, v{t[2]}")
+            e(f"v_lshl_or_b32 v{dst}, v{t[2]}, 16, v{t[0]}")
+            e(f"v_lshlrev_b32_e32 v{dst}, 4, v{dst}")
+    else:
+        # Four genotypes (one byte of a stream) -> four offset bytes through two 256-entry tables in LDS
+        # (SPREAD_IN[b] = genotype k of b, times 16, in byte k; SPREAD_OUT the same times 64; written by
+        # lod_chain_kernel before the loop): per dword two byte extractions (SDWA, scaled to a table
+        # offset), two look-ups and an OR instead of 16 VALU instructions -- the expansion was what PRE
+        # spent most of its time on, and in the thinned kernel PRE sets the pace.
+        sel = "dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD"
+        for d in range(8):
+            lsrc, tsrc = (V_LL, V_TL) if d < 4 else (V_LH, V_TH)
+            e(f"v_lshlrev_b32_sdwa v{V_X + d}, 2, v{lsrc} {sel} src1_sel:BYTE_{d % 4}")
+            e(f"v_lshlrev_b32_sdwa v{V_X + 8 + d}, 2, v{tsrc} {sel} src1_sel:BYTE_{d % 4}")
+        rd = []
+        for d in range(8):
+            g.lds(f"ds_read_b32 v{V_X + d}, v{V_X + d} offset:{SPREAD_IN}")
+            rd.append(g.lds(f"ds_read_b32 v{V_X + 8 + d}, v{V_X + 8 + d} offset:{SPREAD_OUT}"))
+        for d in range(8):
+            g.wait_lds(rd[d])
+            e(f"v_or_b32_e32 v{V_X + d}, v{V_X + d}, v{V_X + 8 + d}")
     for h in range(2):                            # V_LANE32P holds EXP_BASE + lane*32
         g.lds(f"ds_write_b128 v{V_LANE32P}, {quad(V_X + 4 * h)} offset:{s4 * EXP_SLOT + 16 * h}")
 
@@ -800,6 +821,7 @@ def main():
         # entering-stream word row minus leaving-stream word row the genotype ring can span
         f.write(f"#define GARLIC_CHAIN_MAX_DW {WROWS - 2 * NSLOT - 3 * CHROWS}\n")
         f.write(f"#define GARLIC_CHAIN_CHROWS {CHROWS}\n")
+        f.write(f"#define GARLIC_CHAIN_SPREAD_IN {SPREAD_IN}\n#define GARLIC_CHAIN_SPREAD_OUT {SPREAD_OUT}\n")
         for name, body in (("GARLIC_CHAIN_LOOP_ASM", lines), ("GARLIC_CHAIN_LOOP_ASM_THIN", gen_all(thin=True))):
             f.write(f"#define {name} \\\n")
             for ln in body:
