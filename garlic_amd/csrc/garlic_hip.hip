@@ -928,7 +928,11 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     p->stats_slot = (int)(ctx->n_calls % garlic_ctx::HIST);
     HIP_TRY(hipEventRecord(ctx->hist0[p->stats_slot], ctx->stream));
     if (wlod_fast) {
-        const int nquad = (nblk + WLOD_WAVES - 1) / WLOD_WAVES;
+        // plain --error scores: two blocks per wave (every scalar-loaded weight used twice); the per-genotype
+        // variants keep one block per wave (their term rows, not the weights, set their pace)
+        const bool two_blocks = !wlod_gl && !getenv("GARLIC_WLOD_ONE_BLOCK");
+        const int per_wg = two_blocks ? WLOD2_BLOCKS : WLOD_WAVES;
+        const int nquad = (nblk + per_wg - 1) / per_wg;
         WlodArgs a{p->d_valid.p, p->d_chrs.p, p->d_tiles.p, p->nwordrows, p->nchr, ind_begin, ind_count, W, nquad,
                    (uint32_t)((int64_t)p->plan.n_tiles * nquad), (wlod_gl_ring ? ring_patch : wlod_use_patch) ? 1 : 0,
                    (int64_t)(GOFF + p->nloci + GPAD_BACK), wlod_gl_ring ? 1 : 0};
@@ -936,7 +940,10 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         const double *a_wtab = wlod_gl ? p->d_glterms.p : p->d_wtab.p, *a_skew = p->d_skew.p + SKEW_FRONT;
         const unsigned wl_grid = (a.n_work + 7u) / 8u * 8u;
         const dim3 wl_block(WLOD_WAVES * WAVE);
-        if (wlod_lds > 48 * 1024) {
+        if (wlod_lds > 48 * 1024 && two_blocks) {
+            const void *fn = aligned16 ? (const void *)wlod_tile2_kernel<WLOD_R, true> : (const void *)wlod_tile2_kernel<WLOD_R, false>;
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlod_lds));
+        } else if (wlod_lds > 48 * 1024) {
             const void *fn = wlod_gl ? (aligned16 ? (const void *)wlod_tile_gl_kernel<WLOD_R, true>
                                                   : (const void *)wlod_tile_gl_kernel<WLOD_R, false>)
                                      : (aligned16 ? (const void *)wlod_tile_kernel<WLOD_R, true>
@@ -954,6 +961,12 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                                a_packed, a_wtab, a_skew, d_out, a);
         else if (wlod_gl)
             hipLaunchKernelGGL((wlod_tile_gl_kernel<WLOD_R, false>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
+                               a_packed, a_wtab, a_skew, d_out, a);
+        else if (two_blocks && aligned16)
+            hipLaunchKernelGGL((wlod_tile2_kernel<WLOD_R, true>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
+                               a_packed, a_wtab, a_skew, d_out, a);
+        else if (two_blocks)
+            hipLaunchKernelGGL((wlod_tile2_kernel<WLOD_R, false>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
                                a_packed, a_wtab, a_skew, d_out, a);
         else if (aligned16)
             hipLaunchKernelGGL((wlod_tile_kernel<WLOD_R, true>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,

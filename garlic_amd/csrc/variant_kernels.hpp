@@ -688,6 +688,66 @@ __device__ __forceinline__ void wlod_group_scores(const double *tcol, int64_t G,
     }
 }
 
+// Write-out of one group of R windows x 64 individuals (accumulators in registers): windows without a
+// score become MISSING (garlic-roh.cpp:232); then 128 contiguous bytes per row and instruction,
+// non-temporal, transposed through ONE LDS patch [64][WT_PITCH] per workgroup that its waves take turns
+// on (a patch per wave would cost the occupancy the scalar weight loads need; 16 B per lane and row
+// straight from registers left 0.45 ms of L2 write-back work per 1.6 GB).  The host enables the patch
+// while score rows + patch still allow 8 waves per SIMD; otherwise (wide windows, dense / unaligned
+// layouts) each lane writes its own row.
+template <int R, bool ALIGNED16>
+__device__ __forceinline__ void wlod_write_group(double (&acc)[R], uint32_t gm, const ChrDev &c, const WlodArgs &p,
+                                                 double *__restrict__ out, double *patch, int *patch_lock,
+                                                 int ind0, int s0, int grp, int lane)
+{
+    const bool row_ok = ind0 + lane < p.ind_count;
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = (gm != 0 && ((gm >> r) & 1u)) ? acc[r] : MISSING_D;
+    const int sg = s0 + grp * R;
+    if (ALIGNED16 && p.use_patch) {
+        if (lane == 0)
+            while (atomicCAS(patch_lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < R; r += 2)
+            *reinterpret_cast<double2 *>(patch + lane * WT_PITCH + r) = make_double2(acc[r], acc[r + 1]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int cc = 2 * (lane & 7);
+        double *out_blk = out + c.out_base + (int64_t)ind0 * c.out_pitch + s0 + grp * R + cc;
+        const double *prow = patch + (lane >> 3) * WT_PITCH + cc;
+        double *dst = out_blk + (int64_t)(lane >> 3) * c.out_pitch;
+#pragma unroll 1
+        for (int q = 0; q < 8; q++, prow += 8 * WT_PITCH, dst += 8 * c.out_pitch) {
+            // (one row piece at a time, rolled: registers are what buys occupancy here)
+            const int rrow = 8 * q + (lane >> 3);
+            const double2 v = *reinterpret_cast<const double2 *>(prow);
+            if (ind0 + rrow >= p.ind_count) continue;
+            if (sg + cc + 1 < c.nloci) {
+                __builtin_nontemporal_store(v.x, dst);
+                __builtin_nontemporal_store(v.y, dst + 1);
+            } else if (sg + cc < c.nloci) {
+                dst[0] = v.x;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) atomicExch(patch_lock, 0);
+    } else if (row_ok) {
+        double *out_row = out + c.out_base + (int64_t)(ind0 + lane) * c.out_pitch + s0;
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            if (ALIGNED16 && sg + r + 1 < c.nloci) {
+                *reinterpret_cast<double2 *>(out_row + grp * R + r) = make_double2(acc[r], acc[r + 1]);
+            } else {
+                if (sg + r < c.nloci) out_row[grp * R + r] = acc[r];
+                if (sg + r + 1 < c.nloci) out_row[grp * R + r + 1] = acc[r + 1];
+            }
+        }
+    }
+}
+
 template <int R, bool ALIGNED16, bool FROM_SCORES, bool GL_RING = false>
 __device__ __forceinline__ void
 wlod_tile_body(const uint32_t *__restrict__ packed,
@@ -731,8 +791,6 @@ wlod_tile_body(const uint32_t *__restrict__ packed,
     }
     __syncthreads();
     if (!active) return;
-    const bool row_ok = ind0 + lane < p.ind_count;
-    double *out_row = out + c.out_base + (int64_t)(ind0 + lane) * c.out_pitch + s0;
 #pragma unroll 1
     for (int grp = 0; grp < TILE / R; grp++) {
         double acc[R];
@@ -752,56 +810,7 @@ wlod_tile_body(const uint32_t *__restrict__ packed,
                 wlod_group<R>(rows + grp * R * 4, gcol, G0 + grp * R,
                               D + (c.loc_base + s0 + grp * R) * (int64_t)W, W, acc);
         }
-        // windows without a score are MISSING (garlic-roh.cpp:232)
-#pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = (gm != 0 && ((gm >> r) & 1u)) ? acc[r] : MISSING_D;
-        const int sg = s0 + grp * R;
-        if (ALIGNED16 && p.use_patch) {
-            // Write-out: 128 contiguous bytes per row and instruction, non-temporal, transposed
-            // through ONE LDS patch [64][WT_PITCH] per workgroup that its waves take turns on
-            // (a patch per wave would cost the occupancy the scalar weight loads need; 16 B per
-            // lane and row straight from registers left 0.45 ms of L2 write-back work per 1.6 GB).
-            // The host enables it while score rows + patch still allow 8 waves per SIMD.
-            if (lane == 0)
-                while (atomicCAS(patch_lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < R; r += 2)
-                *reinterpret_cast<double2 *>(patch + lane * WT_PITCH + r) = make_double2(acc[r], acc[r + 1]);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int cc = 2 * (lane & 7);
-            double *out_blk = out + c.out_base + (int64_t)ind0 * c.out_pitch + s0 + grp * R + cc;
-            const double *prow = patch + (lane >> 3) * WT_PITCH + cc;
-            double *dst = out_blk + (int64_t)(lane >> 3) * c.out_pitch;
-#pragma unroll 1
-            for (int q = 0; q < 8; q++, prow += 8 * WT_PITCH, dst += 8 * c.out_pitch) {
-                // (one row piece at a time, rolled: registers are what buys occupancy here)
-                const int rrow = 8 * q + (lane >> 3);
-                const double2 v = *reinterpret_cast<const double2 *>(prow);
-                if (ind0 + rrow >= p.ind_count) continue;
-                if (sg + cc + 1 < c.nloci) {
-                    __builtin_nontemporal_store(v.x, dst);
-                    __builtin_nontemporal_store(v.y, dst + 1);
-                } else if (sg + cc < c.nloci) {
-                    dst[0] = v.x;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) atomicExch(patch_lock, 0);
-        } else if (row_ok) {   // wide windows, dense / unaligned layouts: each lane writes its own row
-#pragma unroll
-            for (int r = 0; r < R; r += 2) {
-                if (ALIGNED16 && sg + r + 1 < c.nloci) {
-                    *reinterpret_cast<double2 *>(out_row + grp * R + r) = make_double2(acc[r], acc[r + 1]);
-                } else {
-                    if (sg + r < c.nloci) out_row[grp * R + r] = acc[r];
-                    if (sg + r + 1 < c.nloci) out_row[grp * R + r + 1] = acc[r + 1];
-                }
-            }
-        }
+        wlod_write_group<R, ALIGNED16>(acc, gm, c, p, out, patch, patch_lock, ind0, s0, grp, lane);
     }
 }
 
@@ -814,6 +823,90 @@ wlod_tile_kernel(const uint32_t *__restrict__ packed, const double *__restrict__
                  const double *__restrict__ D, double *__restrict__ out, WlodArgs p)
 {
     wlod_tile_body<R, ALIGNED16, false>(packed, wtab, D, out, p);
+}
+
+// Two 64-individual blocks per wave (GARLIC_WLOD2_LOOP_ASM): the 16 weights of a step multiply both blocks'
+// scores.  The scalar data path returns one dword per cycle and CU; at 16 weights (32 dwords) per 32
+// FP64 operations it, not the FP64 pipe, paced wlod_tile_kernel (0.61 of the FP64 peak; 0.78 with every
+// other load left out, measured).  Here a wave spends 64 operations on the same 32 dwords.
+template <int R>
+__device__ __forceinline__ void wlod_group2(const double *rows, const uint32_t *packed, int64_t colA, int64_t colB,
+                                            int64_t nwordrows, int64_t G, const double *Ds, int W, double (&acc)[R],
+                                            double (&bcc)[R])
+{
+    static_assert(R == 16, "the hand-scheduled loop keeps 16 weights per step in SGPRs");
+    uint64_t gaddr = reinterpret_cast<uint64_t>(packed + packed_index(G >> 4, colA, nwordrows));
+    uint64_t gaddrb = reinterpret_cast<uint64_t>(packed + packed_index(G >> 4, colB, nwordrows));
+    uint32_t bit = 2 * (uint32_t)(G & 15);
+    double sc, scn, scb, scnb, t0, t1;
+    uint32_t vt, vtb, word, nextw, wordb, nextwb;
+    uint32_t n = (uint32_t)(W - (R - 1));
+    uint32_t row = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) double *)rows);
+    const double *dp = Ds - (R - 1);
+    const uint32_t stride = (uint32_t)(W + 1) * 8u;
+    asm volatile(GARLIC_WLOD2_LOOP_ASM
+                 : [a0] "=&v"(acc[0]), [a1] "=&v"(acc[1]), [a2] "=&v"(acc[2]), [a3] "=&v"(acc[3]),
+                   [a4] "=&v"(acc[4]), [a5] "=&v"(acc[5]), [a6] "=&v"(acc[6]), [a7] "=&v"(acc[7]),
+                   [a8] "=&v"(acc[8]), [a9] "=&v"(acc[9]), [a10] "=&v"(acc[10]), [a11] "=&v"(acc[11]),
+                   [a12] "=&v"(acc[12]), [a13] "=&v"(acc[13]), [a14] "=&v"(acc[14]), [a15] "=&v"(acc[15]),
+                   [b0] "=&v"(bcc[0]), [b1] "=&v"(bcc[1]), [b2] "=&v"(bcc[2]), [b3] "=&v"(bcc[3]),
+                   [b4] "=&v"(bcc[4]), [b5] "=&v"(bcc[5]), [b6] "=&v"(bcc[6]), [b7] "=&v"(bcc[7]),
+                   [b8] "=&v"(bcc[8]), [b9] "=&v"(bcc[9]), [b10] "=&v"(bcc[10]), [b11] "=&v"(bcc[11]),
+                   [b12] "=&v"(bcc[12]), [b13] "=&v"(bcc[13]), [b14] "=&v"(bcc[14]), [b15] "=&v"(bcc[15]),
+                   [sc] "=&v"(sc), [scn] "=&v"(scn), [scb] "=&v"(scb), [scnb] "=&v"(scnb), [t0] "=&v"(t0), [t1] "=&v"(t1),
+                   [vt] "=&v"(vt), [vtb] "=&v"(vtb), [word] "=&v"(word), [nextw] "=&v"(nextw), [wordb] "=&v"(wordb),
+                   [nextwb] "=&v"(nextwb), [gaddr] "+v"(gaddr), [gaddrb] "+v"(gaddrb), [bit] "+s"(bit),
+                   [row] "+s"(row), [n] "+s"(n)
+                 : [dp] "s"(dp), [stride] "s"(stride), [rowbytes] "s"((uint64_t)(WAVE * 4))
+                 : GARLIC_WLOD_LOOP_CLOBBERS);
+}
+
+constexpr int WLOD2_BLOCKS = 2 * WLOD_WAVES;   // 64-individual blocks per workgroup of the two-block kernel
+
+template <int R, bool ALIGNED16>
+__global__ void __launch_bounds__(WLOD_WAVES * WAVE, 5)   // 5 waves per SIMD: at most 96 VGPRs
+wlod_tile2_kernel(const uint32_t *__restrict__ packed, const double *__restrict__ wtab,
+                  const double *__restrict__ D, double *__restrict__ out, WlodArgs p)
+{   // as wlod_tile_body<R, ALIGNED16, false>, a wave owning the blocks 2w and 2w+1 of its workgroup's eight
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    const int lane = threadIdx.x & (WAVE - 1), W = p.winsize;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *rows = dyn;                                   // [W + TILE][4]
+    const size_t rows_doubles = (size_t)((W + TILE) * 4);
+    int *patch_lock = reinterpret_cast<int *>(dyn + rows_doubles);
+    double *patch = dyn + rows_doubles + 2;
+    if (threadIdx.x == 0) *patch_lock = 0;
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned v = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (v >= p.n_work) return;
+    const int tile_idx = (int)(v / (unsigned)p.nquad);
+    const int ind0A = ((int)(v % (unsigned)p.nquad) * WLOD2_BLOCKS + 2 * wave) * WAVE, ind0B = ind0A + WAVE;
+    const bool activeA = ind0A < p.ind_count, activeB = ind0B < p.ind_count;
+    const int2 td = p.tiles[tile_idx];
+    const ChrDev c = p.chrs[td.x];
+    const int s0 = td.y;
+    const int64_t colA = (int64_t)p.ind_begin + ind0A + lane;
+    const int64_t colB = activeB ? colA + WAVE : colA;   // no second block: the first one again, results dropped
+    const int64_t G0 = c.loc_base + GOFF + s0;
+    const bool has = lane < TILE && s0 + lane < c.nloci && p.valid[c.loc_base + s0 + lane] != 0;
+    const uint32_t vm = (uint32_t)__ballot(has);
+    if (vm != 0) {
+        const double2 *src = reinterpret_cast<const double2 *>(wtab + G0 * 4);
+        double2 *dst = reinterpret_cast<double2 *>(rows);
+        for (int k = threadIdx.x; k < (W + TILE - 1) * 2; k += WLOD_WAVES * WAVE) dst[k] = src[k];
+    }
+    __syncthreads();
+    if (!activeA) return;
+#pragma unroll 1
+    for (int grp = 0; grp < TILE / R; grp++) {
+        double acc[R], bcc[R];
+        const uint32_t gm = (vm >> (grp * R)) & ((1u << R) - 1u);
+        if (gm != 0)
+            wlod_group2<R>(rows + grp * R * 4, packed, colA, colB, p.nwordrows, G0 + grp * R,
+                           D + (c.loc_base + s0 + grp * R) * (int64_t)W, W, acc, bcc);
+        wlod_write_group<R, ALIGNED16>(acc, gm, c, p, out, patch, patch_lock, ind0A, s0, grp, lane);
+        if (activeB) wlod_write_group<R, ALIGNED16>(bcc, gm, c, p, out, patch, patch_lock, ind0B, s0, grp, lane);
+    }
 }
 
 // ... and the hand-scheduled term-matrix variant (per-wave LDS rings): 64 VGPRs again

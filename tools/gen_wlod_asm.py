@@ -30,6 +30,7 @@ declared as clobbers (inline asm cannot name a sub-register of a 512-bit operand
 """
 import os
 
+ABL = os.environ.get("GARLIC_WLOD_ABLATE", "")   # experiments: nosload, nolds, nowait, noint (timing only, results wrong)
 R = 16
 BASE = {"A": 36, "B": 68}
 S_DP = 34
@@ -64,10 +65,11 @@ GL_MASK = GL_RING * 512 - 1
 
 
 class Gen:
-    def __init__(self, gl=False):
+    def __init__(self, gl=False, nb=1):
         self.out = []
         self.uid = 0
         self.gl = gl
+        self.nb = nb          # 64-individual blocks per wave (2: every weight serves two blocks)
 
     def gl_request(self):
         """LDS-DMA of the next two term rows into the ring"""
@@ -104,40 +106,58 @@ class Gen:
         if prefetch:
             e(f"s_add_u32 s{S_DP}, s{S_DP}, %[stride]")
             e(f"s_addc_u32 s{S_DP + 1}, s{S_DP + 1}, 0")
-            e(f"s_load_dwordx16 {tup(nxt, 0)}, s[{S_DP}:{S_DP + 1}], 0x0")
-            e(f"s_load_dwordx16 {tup(nxt, 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
+            if "nosload" not in ABL and not ("halfsload" in ABL and parity == 1) and not ("quartersload" in ABL and self.uid % 4):
+                e(f"s_load_dwordx16 {tup(nxt, 0)}, s[{S_DP}:{S_DP + 1}], 0x0")
+                e(f"s_load_dwordx16 {tup(nxt, 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
         if prefetch and self.gl:
             if parity == 0:
                 self.gl_request()
             self.gl_read(scn, parity)
         elif prefetch:
-            e("v_bfe_u32 %[vt], %[word], %[bit], 2")
-            e("v_lshl_add_u32 %[vt], %[vt], 3, %[row]")
-            e(f"ds_read_b64 %[{scn}], %[vt]")
+            scnb = "scnb" if scn == "scn" else "scb"
+            for blk, (vt, word, dst) in enumerate((("vt", "word", scn), ("vtb", "wordb", scnb))[:self.nb]):
+                if "noint" not in ABL:
+                    e(f"v_bfe_u32 %[{vt}], %[{word}], %[bit], 2")
+                    e(f"v_lshl_add_u32 %[{vt}], %[{vt}], 3, %[row]")
+                if "nolds" not in ABL:
+                    e(f"ds_read_b64 %[{dst}], %[{vt}]")
             e("s_add_u32 %[row], %[row], 32")
             e("s_add_u32 %[bit], %[bit], 2")
             e("s_cmp_eq_u32 %[bit], 32")
             e(f"s_cbranch_scc0 WL_SAMEWORD_{uid}_%=")
             e("s_mov_b32 %[bit], 0")
             self.switch_wait()
-            e("v_mov_b32_e32 %[word], %[nextw]")
-            e("global_load_dword %[nextw], %[gaddr], off")
-            e("v_lshl_add_u64 %[gaddr], %[gaddr], 0, %[rowbytes]")
+            for word, nextw, gaddr in (("word", "nextw", "gaddr"), ("wordb", "nextwb", "gaddrb"))[:self.nb]:
+                e(f"v_mov_b32_e32 %[{word}], %[{nextw}]")
+                e(f"global_load_dword %[{nextw}], %[{gaddr}], off")
+                e(f"v_lshl_add_u64 %[{gaddr}], %[{gaddr}], 0, %[rowbytes]")
             e(f"WL_SAMEWORD_{uid}_%=:")
         ws = list(windows)
+        if self.nb == 2:
+            # every weight multiplies the two blocks' scores: half the scalar loads per FP64 operation (the
+            # scalar data path returns one dword per cycle and CU: at 16 weights per 32 operations it, not
+            # the FP64 pipe, set the pace -- 0.61 of the FP64 peak, 0.78 with the loads halved)
+            scb = "scb" if sc == "sc" else "scnb"
+            for r in ws:
+                e(f"v_mul_f64 %[t0], %[{sc}], {weight(cur, r)}")
+                e(f"v_mul_f64 %[t1], %[{scb}], {weight(cur, r)}")
+                e(f"v_add_f64 %[a{r}], %[a{r}], %[t0]")
+                e(f"v_add_f64 %[b{r}], %[b{r}], %[t1]")
+            ws = []
         for k in range(0, len(ws), 2):     # two products in flight: no back-to-back dependency
             pair = ws[k:k + 2]
             for t, r in zip(("t0", "t1"), pair):
                 e(f"v_mul_f64 %[{t}], %[{sc}], {weight(cur, r)}")
             for t, r in zip(("t0", "t1"), pair):
                 e(f"v_add_f64 %[a{r}], %[a{r}], %[{t}]")
-        if prefetch:
+        if prefetch and "nowait" not in ABL:
             e("s_waitcnt lgkmcnt(0)")
 
 
-def build(gl):
-    g = Gen(gl)
+def build(gl, nb=1):
+    g = Gen(gl, nb)
     e = g.e
+    assert not (gl and nb != 1)
     # ---- pipeline fill: weights and score of step 0
     if gl:
         e(f"s_mov_b64 s[{S_DP}:{S_DP + 1}], %[dp]")
@@ -153,27 +173,35 @@ def build(gl):
     else:
         # (the lane's first two genotype words are requested here too, so that their latency overlaps
         # with the first weights')
-        e("global_load_dword %[word], %[gaddr], off")
-        e("global_load_dword %[nextw], %[gaddr], off offset:256")
+        blocks = (("word", "nextw", "gaddr", "vt", "sc"), ("wordb", "nextwb", "gaddrb", "vtb", "scb"))[:nb]
+        for word, nextw, gaddr, _, _ in blocks:
+            e(f"global_load_dword %[{word}], %[{gaddr}], off")
+            e(f"global_load_dword %[{nextw}], %[{gaddr}], off offset:256")
         e(f"s_mov_b64 s[{S_DP}:{S_DP + 1}], %[dp]")
         e(f"s_load_dwordx16 {tup('A', 0)}, s[{S_DP}:{S_DP + 1}], 0x0")
         e(f"s_load_dwordx16 {tup('A', 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
-        e("v_lshl_add_u64 %[gaddr], %[gaddr], 0, %[rowbytes]")
-        e("v_lshl_add_u64 %[gaddr], %[gaddr], 0, %[rowbytes]")
+        for _, _, gaddr, _, _ in blocks:
+            e(f"v_lshl_add_u64 %[{gaddr}], %[{gaddr}], 0, %[rowbytes]")
+            e(f"v_lshl_add_u64 %[{gaddr}], %[{gaddr}], 0, %[rowbytes]")
         e("s_waitcnt vmcnt(0)")
-        e("v_bfe_u32 %[vt], %[word], %[bit], 2")
-        e("v_lshl_add_u32 %[vt], %[vt], 3, %[row]")
-        e("ds_read_b64 %[sc], %[vt]")
+        for word, _, _, vt, sc in blocks:
+            e(f"v_bfe_u32 %[{vt}], %[{word}], %[bit], 2")
+            e(f"v_lshl_add_u32 %[{vt}], %[{vt}], 3, %[row]")
+            e(f"ds_read_b64 %[{sc}], %[{vt}]")
         e("s_add_u32 %[row], %[row], 32")
         e("s_add_u32 %[bit], %[bit], 2")
         e("s_cmp_eq_u32 %[bit], 32")
         e("s_cbranch_scc0 WL_SAMEWORD_0_%=")
         e("s_mov_b32 %[bit], 0")
         g.switch_wait()
-        e("v_mov_b32_e32 %[word], %[nextw]")
-        e("global_load_dword %[nextw], %[gaddr], off")
-        e("v_lshl_add_u64 %[gaddr], %[gaddr], 0, %[rowbytes]")
+        for word, nextw, gaddr, _, _ in blocks:
+            e(f"v_mov_b32_e32 %[{word}], %[{nextw}]")
+            e(f"global_load_dword %[{nextw}], %[{gaddr}], off")
+            e(f"v_lshl_add_u64 %[{gaddr}], %[{gaddr}], 0, %[rowbytes]")
         e("WL_SAMEWORD_0_%=:")
+    if nb == 2:
+        for r in range(R):
+            e(f"v_mov_b64_e32 %[b{r}], 0")
     for r in range(R):
         e(f"v_mov_b64_e32 %[a{r}], 0")
     e("s_waitcnt lgkmcnt(0)")
@@ -215,9 +243,11 @@ def main():
         f.write("// wlod_group<16>: the ordered sums of 16 consecutive windows x 64 individuals, one SNP\n")
         f.write("// per step, the next step's weights and score requested before this step's FP64 work.\n")
         f.write("// _GL: the score is the lane's entry of the scaled TGLS term matrix, through an LDS ring.\n")
+        f.write("// WLOD2: two 64-individual blocks per wave, every weight used for both (half the scalar loads per operation).\n")
         f.write(f"#define GARLIC_WLOD_GL_RING_ROWS {GL_RING}\n")
-        for name, gl in (("GARLIC_WLOD_LOOP_ASM", False), ("GARLIC_WLOD_GL_LOOP_ASM", True)):
-            lines = build(gl)
+        for name, gl, nb in (("GARLIC_WLOD_LOOP_ASM", False, 1), ("GARLIC_WLOD_GL_LOOP_ASM", True, 1),
+                             ("GARLIC_WLOD2_LOOP_ASM", False, 2)):
+            lines = build(gl, nb)
             total += sum(1 for x in lines if not x.endswith(":"))
             f.write(f"#define {name} \\\n")
             for ln in lines:
@@ -226,7 +256,7 @@ def main():
         regs = ['"s%d"' % r for r in range(S_DP, 100)] + ['"scc"', '"vcc"']
         f.write("#define GARLIC_WLOD_LOOP_CLOBBERS \\\n    ")
         f.write(", \\\n    ".join(", ".join(regs[i:i + 12]) for i in range(0, len(regs), 12)) + "\n")
-    print(f"wrote {os.path.normpath(path)}: {total} instructions in two variants")
+    print(f"wrote {os.path.normpath(path)}: {total} instructions in three variants")
 
 
 if __name__ == "__main__":
