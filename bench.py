@@ -256,11 +256,11 @@ def leg_ns(ctx, dev, steps):
                                   "popcounts_per_call": float(nloci) * (W - 1) * 2 * ((nsub + 63) // 64)}}
     dt, k = timed_passes(ctx, lambda: panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU), steps, 1,
                          torch.cuda.synchronize)
-    res["wlod"] = dict(rate(k, dt), roofline=fp64_roofline("wlod_tile_kernel", win, W, k))
+    res["wlod"] = dict(rate(k, dt), roofline=fp64_roofline("wlod_tile2_kernel", win, W, k))
     panel.release_scratch()
     dt, k = timed_passes(ctx, lambda: panel.lod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, use_gl=True), steps, 1,
                          torch.cuda.synchronize)
-    res["tgls"] = dict(rate(k, dt), roofline=hbm_roofline("lod_chain_terms_kernel", BYTES_TGLS * win, k,
+    res["tgls"] = dict(rate(k, dt), roofline=hbm_roofline("lod_chain_ring_kernel", BYTES_TGLS * win, k,
                                                           note="term matrix built once per panel (gl_terms_kernel), not in the pass"))
     dt, k = timed_passes(ctx, lambda: panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU, use_gl=True),
                          steps, 1, torch.cuda.synchronize)
@@ -457,9 +457,9 @@ def main():
         if args.mode == "lod":
             roof = hbm_roofline("lod_chain_kernel", BYTES_LOD * win_rank, k_ms)
         elif args.mode == "tgls":
-            roof = hbm_roofline("lod_chain_terms_kernel", BYTES_TGLS * win_rank, k_ms)
+            roof = hbm_roofline("lod_chain_ring_kernel", BYTES_TGLS * win_rank, k_ms)
         else:
-            roof = fp64_roofline("wlod_tile_kernel", win_rank, W, k_ms)
+            roof = fp64_roofline("wlod_tile2_kernel", win_rank, W, k_ms)
         res = {
             "metric": "LOD-windows/sec (SNPs x inds / winsize)",
             "value": lod_windows_per_step * args.steps / elapsed,
