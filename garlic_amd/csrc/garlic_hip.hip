@@ -810,8 +810,9 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // per wave; it needs a block-aligned shard (a wave's 64 lanes = one block of the matrix)
     const bool wlod_gl_ring = wlod_gl && (ind_begin & (WAVE - 1)) == 0 && !getenv("GARLIC_WLOD_GL_NO_RING");
     const bool ring_patch = !getenv("GARLIC_WLOD_GL_NO_PATCH");
-    const size_t wlod_lds = wlod_gl_ring ? WLOD_GL_RING_OFF + (size_t)WLOD_WAVES * GARLIC_WLOD_GL_RING_ROWS * WAVE * 8
-                                         : wlod_rows + 16 + (wlod_use_patch ? wlod_patch : 0);   // 16: the patch lock
+    size_t wlod_lds = wlod_gl_ring ? WLOD_GL_RING_OFF + (size_t)WLOD_WAVES * GARLIC_WLOD_GL_RING_ROWS * WAVE * 8
+                                   : wlod_rows + 16 + (wlod_use_patch ? wlod_patch : 0);   // 16: the patch lock
+    if (const char *e = getenv("GARLIC_WLOD_LDS_MIN")) wlod_lds = std::max(wlod_lds, (size_t)atol(e));   // EXPERIMENT: occupancy
 
     // Host output: the device always computes into the padded layout the tuned kernels need; the
     // rows are copied out into the caller's (possibly dense) layout by strided D2H copies.

@@ -839,7 +839,7 @@ __device__ __forceinline__ void wlod_group2(const double *rows, const uint32_t *
     uint64_t gaddrb = reinterpret_cast<uint64_t>(packed + packed_index(G >> 4, colB, nwordrows));
     uint32_t bit = 2 * (uint32_t)(G & 15);
     double sc, scn, scb, scnb, t0, t1;
-    uint32_t vt, vtb, word, nextw, wordb, nextwb;
+    uint32_t vt, vtb, word, nextw, wordb, nextwb, vd;
     uint32_t n = (uint32_t)(W - (R - 1));
     uint32_t row = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) double *)rows);
     const double *dp = Ds - (R - 1);
@@ -856,8 +856,9 @@ __device__ __forceinline__ void wlod_group2(const double *rows, const uint32_t *
                    [sc] "=&v"(sc), [scn] "=&v"(scn), [scb] "=&v"(scb), [scnb] "=&v"(scnb), [t0] "=&v"(t0), [t1] "=&v"(t1),
                    [vt] "=&v"(vt), [vtb] "=&v"(vtb), [word] "=&v"(word), [nextw] "=&v"(nextw), [wordb] "=&v"(wordb),
                    [nextwb] "=&v"(nextwb), [gaddr] "+v"(gaddr), [gaddrb] "+v"(gaddrb), [bit] "+s"(bit),
-                   [row] "+s"(row), [n] "+s"(n)
-                 : [dp] "s"(dp), [stride] "s"(stride), [rowbytes] "s"((uint64_t)(WAVE * 4))
+                   [row] "+s"(row), [n] "+s"(n), [vd] "=&v"(vd)
+                 : [dp] "s"(dp), [stride] "s"(stride), [rowbytes] "s"((uint64_t)(WAVE * 4)), [vz] "v"((uint32_t)GARLIC_WLOD_PFW * stride),
+                   [pfon] "s"(__builtin_amdgcn_readfirstlane(W <= GARLIC_WLOD_PFW_MAX_W ? 1 : 0))
                  : GARLIC_WLOD_LOOP_CLOBBERS);
 }
 

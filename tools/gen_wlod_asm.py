@@ -31,6 +31,15 @@ declared as clobbers (inline asm cannot name a sub-register of a 512-bit operand
 import os
 
 ABL = os.environ.get("GARLIC_WLOD_ABLATE", "")   # experiments: nosload, nolds, nowait, noint (timing only, results wrong)
+# Two-block loop: the weights of step i + PFW are touched by plain vector loads (one dword per 64-B line, result
+# never read) so that the scalar loads of that step find their lines in L2: the weight table is streamed (every
+# weight is used once per pair of blocks), its first reader otherwise waits for HBM with nothing but the other
+# waves of the SIMD to cover it.  2M x 1280: W=50 11.6 -> 10.5 ms, W=100 18.2 -> 17.6, W=200 32.9 -> 32.2,
+# W=400 62.7 -> 64.3 (close to the FP64 bound the extra vector-memory instructions cost more than they save:
+# the wrapper switches the touches off through VCC for W > PFW_MAX_W).
+PFW = int(os.environ.get("GARLIC_WLOD_PFW", "4"))
+PFW_LOADS = int(os.environ.get("GARLIC_WLOD_PFW_LOADS", "2"))
+PFW_MAX_W = 300
 R = 16
 BASE = {"A": 36, "B": 68}
 S_DP = 34
@@ -59,7 +68,7 @@ def regs_of(parity):
 # vmcnt counts.  Operands instead of the genotype ones: [lane8b] = ring base + lane * 8 (VGPR),
 # [voff16] = lane * 16 (VGPR, advanced by 1 KB per request), [trow] = address of the block's row of SNP s (SGPR pair),
 # [rd] / [wr] = ring byte offsets of the next row to read / to fill (SGPRs), [rbase] = ring base.
-GL_RING = 8            # rows; the request for rows i+GL_AHEAD, +1 overwrites rows i-2, i-1
+GL_RING = int(os.environ.get("GARLIC_WLOD_GL_RING", "8"))   # rows; the request for rows i+GL_AHEAD, +1 overwrites rows i-2, i-1
 GL_AHEAD = GL_RING - 2
 GL_MASK = GL_RING * 512 - 1
 
@@ -77,7 +86,8 @@ class Gen:
         e("s_add_u32 m0, %[rbase], %[wr]")
         e("s_add_u32 %[wr], %[wr], 1024")
         e(f"s_and_b32 %[wr], %[wr], {GL_MASK}")              # (also the wait state M0 needs before the DMA)
-        e("global_load_lds_dwordx4 %[voff16], %[trow]")
+        if "nodma" not in ABL:
+            e("global_load_lds_dwordx4 %[voff16], %[trow]")
         e("v_add_u32_e32 %[voff16], 0x400, %[voff16]")
 
     def gl_read(self, dst, parity):
@@ -94,11 +104,21 @@ class Gen:
     def e(self, s):
         self.out.append(s)
 
-    def switch_wait(self):
-        """before nextw (requested 16 steps earlier) is consumed at a word switch"""
-        self.e("s_waitcnt vmcnt(0)")
+    def switch_wait(self, counted=False):
+        """before nextw (requested 16 steps earlier) is consumed at a word switch; `counted`: the 16 steps since
+        have each issued PFW_LOADS touches behind it (vector loads return in order) -- unless they are switched off"""
+        e = self.e
+        if counted:
+            self.uid += 1
+            e(f"s_cbranch_vccz WL_SW0_{self.uid}_%=")
+            e(f"s_waitcnt vmcnt({16 * PFW_LOADS})")
+            e(f"s_branch WL_SW1_{self.uid}_%=")
+            e(f"WL_SW0_{self.uid}_%=:")
+        e("s_waitcnt vmcnt(0)")
+        if counted:
+            e(f"WL_SW1_{self.uid}_%=:")
 
-    def step(self, parity, windows, prefetch=True):
+    def step(self, parity, windows, prefetch=True, pf=True):
         cur, nxt, sc, scn = regs_of(parity)
         e = self.e
         self.uid += 1
@@ -126,12 +146,17 @@ class Gen:
             e("s_cmp_eq_u32 %[bit], 32")
             e(f"s_cbranch_scc0 WL_SAMEWORD_{uid}_%=")
             e("s_mov_b32 %[bit], 0")
-            self.switch_wait()
+            self.switch_wait(counted=bool(PFW and self.nb == 2 and pf))
             for word, nextw, gaddr in (("word", "nextw", "gaddr"), ("wordb", "nextwb", "gaddrb"))[:self.nb]:
                 e(f"v_mov_b32_e32 %[{word}], %[{nextw}]")
                 e(f"global_load_dword %[{nextw}], %[{gaddr}], off")
                 e(f"v_lshl_add_u64 %[{gaddr}], %[{gaddr}], 0, %[rowbytes]")
             e(f"WL_SAMEWORD_{uid}_%=:")
+            if PFW and self.nb == 2 and pf:
+                e(f"s_cbranch_vccz WL_NOPF_{uid}_%=")
+                for off in (0, 64, 124)[:PFW_LOADS]:      # [vz] = PFW * stride: the weights PFW steps ahead of s[S_DP]
+                    e(f"global_load_dword %[vd], %[vz], s[{S_DP}:{S_DP + 1}] offset:{off}")
+                e(f"WL_NOPF_{uid}_%=:")
         ws = list(windows)
         if self.nb == 2:
             # every weight multiplies the two blocks' scores: half the scalar loads per FP64 operation (the
@@ -200,6 +225,9 @@ def build(gl, nb=1):
             e(f"v_lshl_add_u64 %[{gaddr}], %[{gaddr}], 0, %[rowbytes]")
         e("WL_SAMEWORD_0_%=:")
     if nb == 2:
+        if PFW:
+            e("s_cmp_lg_u32 %[pfon], 0")      # VCC (not used otherwise) all ones: touch the weights ahead; 0: do not
+            e("s_cselect_b64 vcc, -1, 0")
         for r in range(R):
             e(f"v_mov_b64_e32 %[b{r}], 0")
     for r in range(R):
@@ -223,7 +251,7 @@ def build(gl, nb=1):
         if label:
             e(label + ":")
         for d in range(R - 1):
-            g.step((first + d) % 2, range(d + 1, R), prefetch=(d < R - 2))
+            g.step((first + d) % 2, range(d + 1, R), prefetch=(d < R - 2), pf=False)
         if first == 1:
             e("s_branch WL_DONE_%=")
     e("WL_DONE_%=:")
@@ -245,6 +273,7 @@ def main():
         f.write("// _GL: the score is the lane's entry of the scaled TGLS term matrix, through an LDS ring.\n")
         f.write("// WLOD2: two 64-individual blocks per wave, every weight used for both (half the scalar loads per operation).\n")
         f.write(f"#define GARLIC_WLOD_GL_RING_ROWS {GL_RING}\n")
+        f.write(f"#define GARLIC_WLOD_PFW {PFW}\n#define GARLIC_WLOD_PFW_MAX_W {PFW_MAX_W}\n")
         for name, gl, nb in (("GARLIC_WLOD_LOOP_ASM", False, 1), ("GARLIC_WLOD_GL_LOOP_ASM", True, 1),
                              ("GARLIC_WLOD2_LOOP_ASM", False, 2)):
             lines = build(gl, nb)
