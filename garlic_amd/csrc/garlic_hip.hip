@@ -10,6 +10,7 @@
 #include "variant_kernels.hpp"
 #include "ld_kernels.hpp"
 #include "tgls_ring_kernel.hpp"
+#include "wlod_strip_kernel.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -207,6 +208,7 @@ struct garlic_panel {
     DevBuf<double> d_skew, d_wtab;
     DevBuf<uint8_t> d_valid;
     DevBuf<int2> d_tiles;
+    DevBuf<WlodStrip> d_strips;
     std::vector<double> h_tab, h_decay;            // host copies the score rows are built from
     bool wtab_valid = false;
     double wtab_error = 0.0, wtab_mu = 0.0;
@@ -226,10 +228,10 @@ struct garlic_panel {
         int mode = -1;
         int32_t W = 0, max_gap = 0, ind_begin = 0, ind_count = 0, pitch_align = 0;
         size_t n_items = 0, n_fill = 0;
-        bool wlod_fast = false;
+        bool wlod_fast = false, wlod_strip = false;
         int32_t thin_step = 0;
         uint64_t blocks_hash = 0;                  // 0: every 64-individual block; else a hash of the block subset
-        int32_t n_tiles = 0;
+        int32_t n_tiles = 0, n_strips = 0;
         int64_t n_runs = 0, n_valid = 0;
     } plan;
 };
@@ -810,9 +812,12 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // per wave; it needs a block-aligned shard (a wave's 64 lanes = one block of the matrix)
     const bool wlod_gl_ring = wlod_gl && (ind_begin & (WAVE - 1)) == 0 && !getenv("GARLIC_WLOD_GL_NO_RING");
     const bool ring_patch = !getenv("GARLIC_WLOD_GL_NO_PATCH");
-    size_t wlod_lds = wlod_gl_ring ? WLOD_GL_RING_OFF + (size_t)WLOD_WAVES * GARLIC_WLOD_GL_RING_ROWS * WAVE * 8
+    // ... and with windows narrow enough for WS_MAX_WAVES compute waves per workgroup the strip form: the
+    // blocks' term rows enter a CU once per strip (wlod_strip_kernel.hpp)
+    const int strip_waves = WS_MAX_WAVES;
+    const bool wlod_gl_strip = wlod_gl_ring && W + 15 - 16 * strip_waves <= 16 && !getenv("GARLIC_WLOD_GL_NO_STRIP");
+    const size_t wlod_lds = wlod_gl_ring ? WLOD_GL_RING_OFF + (size_t)WLOD_WAVES * GARLIC_WLOD_GL_RING_ROWS * WAVE * 8
                                    : wlod_rows + 16 + (wlod_use_patch ? wlod_patch : 0);   // 16: the patch lock
-    if (const char *e = getenv("GARLIC_WLOD_LDS_MIN")) wlod_lds = std::max(wlod_lds, (size_t)atol(e));   // EXPERIMENT: occupancy
 
     // Host output: the device always computes into the padded layout the tuned kernels need; the
     // rows are copied out into the caller's (possibly dense) layout by strided D2H copies.
@@ -832,7 +837,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     const bool reuse = p->plan.valid && p->plan.blocks_hash == blocks_hash && p->plan.mode == (int)mode && p->plan.W == W &&
                        p->plan.max_gap == max_gap && p->plan.ind_begin == ind_begin &&
                        p->plan.ind_count == ind_count && p->plan.pitch_align == pitch_align &&
-                       p->plan.wlod_fast == wlod_fast && p->plan.thin_step == thin_step;
+                       p->plan.wlod_fast == wlod_fast && p->plan.thin_step == thin_step && p->plan.wlod_strip == wlod_gl_strip;
     const int nblk = (ind_count + WAVE - 1) / WAVE;
     std::vector<Run> runs;
     std::vector<FillItem> fill;
@@ -881,6 +886,24 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         if ((rc = p->d_valid.reserve(valid.size()))) return rc;
         if ((rc = p->d_tiles.reserve(tiles.size()))) return rc;
     }
+    std::vector<WlodStrip> strips;
+    if (wlod_gl_strip && !reuse) {
+        // strips of 16-window groups: long enough that filling and draining the workgroup's pipeline (~ 8 groups)
+        // stays a few percent, short enough for a few thousand work items
+        int64_t total_groups = 0;
+        for (int c = 0; c < p->nchr; c++) total_groups += (p->chr_nloci[c] + WLOD_R - 1) / WLOD_R;
+        const int64_t pairs = (nblk + 1) / 2;
+        int64_t per = total_groups * pairs / 8192;
+        per = std::min<int64_t>(256, std::max<int64_t>(64, per)) & ~(int64_t)1;
+        if (const char *e = getenv("GARLIC_WLOD_STRIP_GROUPS")) per = std::max<int64_t>(1, atol(e));   // tests: many short strips
+        for (int c = 0; c < p->nchr; c++) {
+            const int ng = (p->chr_nloci[c] + WLOD_R - 1) / WLOD_R;
+            for (int g0 = 0; g0 < ng; g0 += (int)per)
+                strips.push_back(WlodStrip{c, g0 * WLOD_R, std::min<int>((int)per, ng - g0), 0});
+        }
+        p->plan.n_strips = (int32_t)strips.size();
+        if ((rc = p->d_strips.reserve(strips.size()))) return rc;
+    }
     // Persistent workgroups (4 waves each: CHAIN, POST, PRE, COMB), one per CU; items are pulled longest
     // first, so the short runs pack behind the long ones instead of competing with them for HBM
     // bandwidth.
@@ -914,6 +937,9 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                                    ctx->stream));
             HIP_TRY(hipMemcpyAsync(p->d_tiles.p, tiles.data(), sizeof(int2) * tiles.size(),
                                    hipMemcpyHostToDevice, ctx->stream));
+            if (!strips.empty())
+                HIP_TRY(hipMemcpyAsync(p->d_strips.p, strips.data(), sizeof(WlodStrip) * strips.size(),
+                                       hipMemcpyHostToDevice, ctx->stream));
         }
     }
     if (thin_step > 0) {          // small matrix: MISSING everywhere, the chain kernel overwrites the scored samples
@@ -951,7 +977,21 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                                                   : (const void *)wlod_tile_kernel<WLOD_R, false>);
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlod_lds));
         }
-        if (wlod_gl_ring && aligned16)
+        if (wlod_gl_strip) {
+            const int n_pairs = (nblk + 1) / 2;
+            WlodStripArgs sa{p->d_valid.p, p->d_chrs.p, p->d_strips.p, p->d_glterms.p, a_skew, d_out,
+                             (int64_t)(GOFF + p->nloci + GPAD_BACK), ind_begin, ind_count, W, strip_waves, n_pairs,
+                             ring_patch ? 1 : 0, (uint32_t)((int64_t)p->plan.n_strips * n_pairs)};
+            const unsigned grid = (sa.n_work + 7u) / 8u * 8u;
+            const void *fn = aligned16 ? (const void *)wlod_strip_gl_kernel<true> : (const void *)wlod_strip_gl_kernel<false>;
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES));
+            if (aligned16)
+                hipLaunchKernelGGL(wlod_strip_gl_kernel<true>, dim3(grid), dim3((strip_waves + 1) * WAVE), WS_LDS_BYTES,
+                                   ctx->stream, sa);
+            else
+                hipLaunchKernelGGL(wlod_strip_gl_kernel<false>, dim3(grid), dim3((strip_waves + 1) * WAVE), WS_LDS_BYTES,
+                                   ctx->stream, sa);
+        } else if (wlod_gl_ring && aligned16)
             hipLaunchKernelGGL((wlod_tile_glring_kernel<WLOD_R, true>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
                                a_packed, a_wtab, a_skew, d_out, a);
         else if (wlod_gl_ring)
@@ -1065,7 +1105,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     p->plan.valid = true;
     p->plan.mode = (int)mode; p->plan.W = W; p->plan.max_gap = max_gap; p->plan.ind_begin = ind_begin;
     p->plan.ind_count = ind_count; p->plan.pitch_align = pitch_align;
-    p->plan.wlod_fast = wlod_fast; p->plan.thin_step = thin_step; p->plan.blocks_hash = blocks_hash;
+    p->plan.wlod_fast = wlod_fast; p->plan.wlod_strip = wlod_gl_strip; p->plan.thin_step = thin_step; p->plan.blocks_hash = blocks_hash;
     p->plan.n_items = n_items; p->plan.n_fill = n_fill; p->plan.n_runs = n_runs; p->plan.n_valid = n_valid;
     st.n_valid_windows = n_valid;
     st.n_missing = p->nloci - n_valid;
@@ -1219,7 +1259,7 @@ int garlic_panel_destroy(garlic_panel *p)
     p->d_blk_offsets.release(); p->d_total.release(); p->d_boundaries.release();
     p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release(); p->d_row_counts.release(); p->d_codes.release(); p->d_tabgl.release();
     p->d_rld.release(); p->d_decay.release(); p->d_stage64.release(); p->d_phase.release(); p->lds.release();
-    p->d_glterms.release(); p->d_glval.release(); p->d_freq.release(); p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release();
+    p->d_glterms.release(); p->d_glval.release(); p->d_freq.release(); p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release(); p->d_strips.release();
     p->d_out.release(); p->d_feed.release();
     delete p;
     return GARLIC_OK;

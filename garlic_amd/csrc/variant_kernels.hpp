@@ -695,8 +695,8 @@ __device__ __forceinline__ void wlod_group_scores(const double *tcol, int64_t G,
 // straight from registers left 0.45 ms of L2 write-back work per 1.6 GB).  The host enables the patch
 // while score rows + patch still allow 8 waves per SIMD; otherwise (wide windows, dense / unaligned
 // layouts) each lane writes its own row.
-template <int R, bool ALIGNED16>
-__device__ __forceinline__ void wlod_write_group(double (&acc)[R], uint32_t gm, const ChrDev &c, const WlodArgs &p,
+template <int R, bool ALIGNED16, class Args>
+__device__ __forceinline__ void wlod_write_group(double (&acc)[R], uint32_t gm, const ChrDev &c, const Args &p,
                                                  double *__restrict__ out, double *patch, int *patch_lock,
                                                  int ind0, int s0, int grp, int lane)
 {

@@ -1,0 +1,222 @@
+// wLOD with per-genotype likelihoods (src/garlic-roh.cpp:204-277 with USE_GL, :245), strip form.
+//
+// wlod_tile_glring_kernel gives every wave its own 16 windows x 64 individuals and its own copy of the term
+// rows they need: a 512-B row of the term matrix enters a CU (W+15)/16 times (57 B per window at W = 100), the
+// kernel's time is what HBM needs for the re-reads that miss L2 (115 of 147 GB at 2M x 1280) plus what the
+// scalar data path needs for one block's weights.  Here a workgroup owns ONE strip of consecutive windows of a
+// chromosome for TWO 64-individual blocks:
+//
+//   * N = 7 compute waves; wave k takes the 16-window groups k, k+N, k+2N, .. of the strip.  A group starting at
+//     row 16 g (rows = SNPs, strip-relative) reads rows 16 g .. 16 g + W + 14, a wave's next group starts at row
+//     16 (g + N): with W + 15 <= 16 N + 16 it starts at most 16 rows below the row its last one ended at, and all
+//     waves move forward through the strip's rows together, within the rings' reach of each other.  (N + the
+//     loader = 8 waves: two workgroups fit a CU.  With 8 + 1 waves only one did -- 96 VGPRs allow 5 waves per SIMD
+//     and both workgroups put three on the same one --, and a loader wave that is not needed is not free either:
+//     2M x 1280, W = 100: 9 waves 23.4 ms, 8 waves 21.7; narrower windows leave a wave idle between its groups
+//     and are still faster with 7 waves than with ceil((W + 15) / 16): W = 50 13.0 against 14.0 ms.)
+//   * one loader wave streams the two blocks' rows ONCE (LDS-DMA, 1 KB = 2 rows per request and block) into
+//     two rings of WS_RING rows in LDS, never further ahead than the slowest compute wave allows
+//     (need[k] = next row wave k reads, published every other step), and publishes how many rows have landed;
+//   * a compute wave's loop is the two-block loop of wlod_tile2_kernel (every scalar-loaded weight multiplies
+//     both blocks' scores; tools/gen_wlod_asm.py, GARLIC_WLOD_GLS_LOOP_ASM) with the scores read from the rings.
+//
+// HBM traffic: 8 B of terms per window and individual, once (+ W / strip length), instead of 57 B.
+// Arithmetic and write-out are those of the tile kernels: bit-identical output.
+//
+// Progress: the compute wave with the smallest need[] only ever waits for rows need, need + 1; the loader may
+// always issue them (3 <= WS_RING), and while it has no room it keeps retiring and publishing what it has in
+// flight.  Waits are bounded all the same (a spent budget traps instead of hanging the GPU).
+#pragma once
+#include "tgls_ring_kernel.hpp"
+#include "variant_kernels.hpp"
+
+namespace garlic {
+
+constexpr int WS_MAX_WAVES = 7;                         // compute waves per workgroup (+ the loader: 8 waves, two workgroups per CU)
+constexpr int WS_RING = GARLIC_WLOD_GLS_RING_ROWS;      // rows per ring (power of two)
+constexpr int WS_DEPTH = 6;                             // loader: row pairs (per block) in flight
+constexpr int WS_NEVER = 0x7fffffff;
+constexpr uint32_t WS_RING_BYTES = (uint32_t)WS_RING * WAVE * 8u;
+// dynamic LDS: ring A, ring B (1-KB aligned), patch lock (16 B), patch [64][WT_PITCH], landed (16 B), need[8]
+constexpr uint32_t WS_LOCK_OFF = 2u * WS_RING_BYTES;
+constexpr uint32_t WS_PATCH_OFF = WS_LOCK_OFF + 16u;
+constexpr uint32_t WS_FLAGS_OFF = (WS_PATCH_OFF + (uint32_t)(WAVE * WT_PITCH * 8) + 31u) & ~31u;
+constexpr uint32_t WS_LDS_BYTES = WS_FLAGS_OFF + 64u;
+
+struct WlodStrip {
+    int32_t chr, s_begin, n_groups, pad;               // windows s_begin .. s_begin + 16 * n_groups - 1 of the chromosome
+};
+
+struct WlodStripArgs {
+    const uint8_t *valid;      // per SNP: a scored window starts here
+    const ChrDev *chrs;
+    const WlodStrip *strips;
+    const double *terms;       // scaled term matrix [blk][term_rows][64]
+    const double *D;           // skewed reciprocal weights (+ SKEW_FRONT)
+    double *out;
+    int64_t term_rows;
+    int32_t ind_begin, ind_count, winsize, n_waves, n_pairs, use_patch;
+    uint32_t n_work;           // strips x pairs
+};
+
+typedef int ws_int4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int ws_min_need(const int *need)
+{
+    const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) int *)need;
+    ws_int4 x, y;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x), "=&v"(y) : "v"(a) : "memory");
+    const int m = min(min(min(x.x, x.y), min(x.z, x.w)), min(min(y.x, y.y), min(y.z, y.w)));
+    return __builtin_amdgcn_readfirstlane(m);
+}
+
+// the two-block loop over one 16-window group, scores from the rings (see tools/gen_wlod_asm.py)
+__device__ __forceinline__ void wlod_group_gls(uint32_t lane8b, uint32_t vflag, uint32_t vneed, const double *Ds, int W,
+                                               uint32_t row0, uint32_t nextrow, uint32_t &landed, uint32_t &polls,
+                                               double (&acc)[WLOD_R], double (&bcc)[WLOD_R])
+{
+    constexpr int R = WLOD_R;
+    static_assert(R == 16, "the hand-scheduled loop keeps 16 weights per step in SGPRs");
+    double sc, scn, scb, scnb, t0, t1;
+    uint32_t vt, vtmp, vd, stmp;
+    uint32_t n = (uint32_t)(W - (R - 1));
+    uint32_t rown = row0, rd = (row0 & (uint32_t)(WS_RING - 1)) * 512u;
+    const double *dp = Ds - (R - 1);
+    const uint32_t stride = (uint32_t)(W + 1) * 8u;
+    asm volatile(GARLIC_WLOD_GLS_LOOP_ASM
+                 : [a0] "=&v"(acc[0]), [a1] "=&v"(acc[1]), [a2] "=&v"(acc[2]), [a3] "=&v"(acc[3]),
+                   [a4] "=&v"(acc[4]), [a5] "=&v"(acc[5]), [a6] "=&v"(acc[6]), [a7] "=&v"(acc[7]),
+                   [a8] "=&v"(acc[8]), [a9] "=&v"(acc[9]), [a10] "=&v"(acc[10]), [a11] "=&v"(acc[11]),
+                   [a12] "=&v"(acc[12]), [a13] "=&v"(acc[13]), [a14] "=&v"(acc[14]), [a15] "=&v"(acc[15]),
+                   [b0] "=&v"(bcc[0]), [b1] "=&v"(bcc[1]), [b2] "=&v"(bcc[2]), [b3] "=&v"(bcc[3]),
+                   [b4] "=&v"(bcc[4]), [b5] "=&v"(bcc[5]), [b6] "=&v"(bcc[6]), [b7] "=&v"(bcc[7]),
+                   [b8] "=&v"(bcc[8]), [b9] "=&v"(bcc[9]), [b10] "=&v"(bcc[10]), [b11] "=&v"(bcc[11]),
+                   [b12] "=&v"(bcc[12]), [b13] "=&v"(bcc[13]), [b14] "=&v"(bcc[14]), [b15] "=&v"(bcc[15]),
+                   [sc] "=&v"(sc), [scn] "=&v"(scn), [scb] "=&v"(scb), [scnb] "=&v"(scnb), [t0] "=&v"(t0), [t1] "=&v"(t1),
+                   [vt] "=&v"(vt), [vtmp] "=&v"(vtmp), [vd] "=&v"(vd), [rd] "+s"(rd), [rown] "+s"(rown),
+                   [landed] "+s"(landed), [polls] "+s"(polls), [n] "+s"(n), [stmp] "=&s"(stmp)
+                 : [nextrow] "s"(nextrow), [dp] "s"(dp), [stride] "s"(stride), [lane8b] "v"(lane8b), [vflag] "v"(vflag), [vneed] "v"(vneed),
+                   [vz] "v"((uint32_t)GARLIC_WLOD_PFW * stride),
+                   [pfon] "s"(__builtin_amdgcn_readfirstlane(W <= GARLIC_WLOD_PFW_MAX_W ? 1 : 0))
+                 : GARLIC_WLOD_LOOP_CLOBBERS, "memory");
+}
+
+// waits until at most `pairs` of the loader's row pairs (two requests each) are still in flight
+__device__ __forceinline__ void ws_wait_pairs(int pairs)
+{
+    static_assert(WS_DEPTH <= 8, "one s_waitcnt per possible count");
+    switch (pairs) {          // requests retire in issue order; the count is an immediate
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    }
+}
+
+// loader wave: rows 0 .. n_rows-1 (n_rows even) of both blocks into the rings, two rows per request
+__device__ __forceinline__ void ws_loader(const double *srcA, const double *srcB, int n_rows, uint32_t ring_lds,
+                                          const int *need, int *landed, int lane)
+{
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    uint32_t slot_off = 0;
+    int inflight = 0, published = 0, min_need = 0;
+    for (int r = 0; r < n_rows; r += 2) {
+        if (r + 2 - min_need > WS_RING) {
+            // no room: meanwhile retire and publish what is in flight, oldest first (a compute wave may be waiting
+            // for exactly those rows -- never block with unpublished rows)
+            int budget = 1 << 22;
+            while (r + 2 - (min_need = ws_min_need(need)) > WS_RING) {
+                if (inflight > 0) {
+                    ws_wait_pairs(--inflight);
+                    published += 2;
+                    tg_flag_write(landed, published);
+                } else {
+                    if (--budget == 0) __builtin_trap();
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(ring_lds + slot_off), "v"(lane16), "s"(srcA) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(ring_lds + WS_RING_BYTES + slot_off), "v"(lane16), "s"(srcB) : "memory");
+        slot_off = (slot_off + 1024u) & (WS_RING_BYTES - 1u);
+        srcA += 2 * WAVE;
+        srcB += 2 * WAVE;
+        if (++inflight == WS_DEPTH) {       // the oldest pair has landed
+            ws_wait_pairs(--inflight);
+            published += 2;
+            tg_flag_write(landed, published);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tg_flag_write(landed, n_rows);
+}
+
+template <bool ALIGNED16>
+__global__ void __launch_bounds__((WS_MAX_WAVES + 1) * WAVE, 5)   // 5 waves per SIMD: at most 96 VGPRs
+wlod_strip_gl_kernel(WlodStripArgs p)
+{
+    extern __shared__ __attribute__((aligned(1024))) char ws_lds[];
+    const int lane = threadIdx.x & (WAVE - 1), W = p.winsize;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = p.n_waves;                              // blockDim.x = (N + 1) * 64
+    int *patch_lock = reinterpret_cast<int *>(ws_lds + WS_LOCK_OFF);
+    double *patch = reinterpret_cast<double *>(ws_lds + WS_PATCH_OFF);
+    int *landed = reinterpret_cast<int *>(ws_lds + WS_FLAGS_OFF);
+    int *need = reinterpret_cast<int *>(ws_lds + WS_FLAGS_OFF + 32);
+    // one contiguous range of the work per XCD (one L2 each): the pairs of a strip share its weights
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned v = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (v >= p.n_work) return;
+    const WlodStrip st = p.strips[v / (unsigned)p.n_pairs];
+    const int pair = (int)(v % (unsigned)p.n_pairs);
+    const ChrDev c = p.chrs[st.chr];
+    if (threadIdx.x == 0) {
+        *patch_lock = 0;
+        *landed = 0;
+    }
+    if (threadIdx.x < 8) need[threadIdx.x] = ((int)threadIdx.x < N && (int)threadIdx.x < st.n_groups) ? 16 * (int)threadIdx.x : WS_NEVER;
+    __syncthreads();
+    const int ind0A = pair * 2 * WAVE, ind0B = ind0A + WAVE;
+    const bool activeB = ind0B < p.ind_count;
+    const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)ws_lds;
+    const int64_t blkA = ((int64_t)p.ind_begin + ind0A) >> 6;          // block-aligned shard (host-checked)
+    const int64_t G0 = c.loc_base + GOFF + st.s_begin;                  // padded row of the strip's row 0
+    if (wave == N) {
+        const double *srcA = p.terms + (blkA * p.term_rows + G0) * WAVE;
+        const double *srcB = activeB ? srcA + p.term_rows * WAVE : srcA;   // no second block: the first one again
+        const int n_rows = (16 * (st.n_groups - 1) + W + 15 + 1) & ~1;
+        __builtin_amdgcn_s_setprio(3);     // few instructions, and everybody waits for them
+        ws_loader(srcA, srcB, n_rows, ring_lds, need, landed, lane);
+        return;
+    }
+    const uint32_t lane8b = ring_lds + (uint32_t)lane * 8u;
+    const uint32_t vflag = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int *)landed;
+    const uint32_t vneed = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int *)(need + wave);
+    uint32_t landed_seen = 0;
+#pragma unroll 1
+    for (int g = wave; g < st.n_groups; g += N) {
+        const int s = st.s_begin + 16 * g;
+        const bool has = lane < WLOD_R && s + lane < c.nloci && p.valid[c.loc_base + s + lane] != 0;
+        const uint32_t gm = (uint32_t)__ballot(has) & 0xffffu;
+        double acc[WLOD_R], bcc[WLOD_R];
+        const int next_row = g + N < st.n_groups ? 16 * (g + N) : WS_NEVER;
+        if (gm != 0) {
+            uint32_t polls = 1u << 20;
+            wlod_group_gls(lane8b, vflag, vneed, p.D + (c.loc_base + s) * (int64_t)W, W, (uint32_t)(16 * g),
+                           (uint32_t)next_row, landed_seen, polls, acc, bcc);
+            if (polls == 0) __builtin_trap();
+        }
+        tg_flag_write(need + wave, next_row);
+        wlod_write_group<WLOD_R, ALIGNED16>(acc, gm, c, p, p.out, patch, patch_lock, ind0A, s, 0, lane);
+        if (activeB) wlod_write_group<WLOD_R, ALIGNED16>(bcc, gm, c, p, p.out, patch, patch_lock, ind0B, s, 0, lane);
+    }
+}
+
+} // namespace garlic

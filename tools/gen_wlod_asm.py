@@ -179,6 +179,113 @@ class Gen:
             e("s_waitcnt lgkmcnt(0)")
 
 
+# Strip form of the GL variant (wlod_strip_gl_kernel): the compute waves of a workgroup walk ONE strip of
+# windows of two 64-individual blocks in step -- wave k the 16-window groups k, k+N, .. -- and read the blocks'
+# term rows from two rings in LDS that a loader wave fills once (LDS-DMA), so a row enters the CU once per strip
+# instead of (W+15)/16 times.  Two blocks per wave as in the plain two-block loop.  Per step, instead of the
+# genotype look-ups:  every other step publish the next row this wave reads ([vneed]);  if that row has not
+# landed ([rown] >= [landed], the wave's copy of the loader's counter) poll the counter ([vflag]), at most
+# [polls] times;  two ds_read_b64 (ring A at [lane8b] + [rd], ring B GLS_RING * 512 bytes above).
+GLS_RING = int(os.environ.get("GARLIC_WLOD_GLS_RING", "64"))     # rows per ring
+GLS_MASK = GLS_RING * 512 - 1
+
+
+class StripGen(Gen):
+    def __init__(self):
+        super().__init__(gl=False, nb=2)
+
+    def read_next(self, dst, dstb, uid):
+        e = self.e
+        e("s_cmp_lt_u32 %[rown], %[landed]")
+        e(f"s_cbranch_scc1 WS_OK_{uid}_%=")
+        if "nopoll" in ABL:
+            e(f"s_branch WS_OK_{uid}_%=")
+        e(f"WS_POLL_{uid}_%=:")
+        e("ds_read_b32 %[vtmp], %[vflag]")
+        e("s_waitcnt lgkmcnt(0)")
+        e("v_readfirstlane_b32 %[landed], %[vtmp]")
+        e("s_cmp_lt_u32 %[rown], %[landed]")
+        e(f"s_cbranch_scc1 WS_OK_{uid}_%=")
+        e("s_sub_u32 %[polls], %[polls], 1")
+        e("s_cmp_eq_u32 %[polls], 0")
+        e(f"s_cbranch_scc1 WS_OK_{uid}_%=")          # budget spent: go on (the caller traps)
+        e("s_sleep 1")
+        e(f"s_branch WS_POLL_{uid}_%=")
+        e(f"WS_OK_{uid}_%=:")
+        e("v_add_u32_e32 %[vt], %[rd], %[lane8b]")
+        e(f"ds_read_b64 %[{dst}], %[vt]")
+        e(f"ds_read_b64 %[{dstb}], %[vt] offset:{GLS_RING * 512}")
+        e("s_add_u32 %[rd], %[rd], 512")
+        e(f"s_and_b32 %[rd], %[rd], {GLS_MASK}")
+        e("s_add_u32 %[rown], %[rown], 1")
+
+    def step(self, parity, windows, prefetch=True, pf=True):
+        cur, nxt, sc, scn = regs_of(parity)
+        e = self.e
+        self.uid += 1
+        uid = self.uid
+        if prefetch:
+            e(f"s_add_u32 s{S_DP}, s{S_DP}, %[stride]")
+            e(f"s_addc_u32 s{S_DP + 1}, s{S_DP + 1}, 0")
+            e(f"s_load_dwordx16 {tup(nxt, 0)}, s[{S_DP}:{S_DP + 1}], 0x0")
+            e(f"s_load_dwordx16 {tup(nxt, 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
+            if parity == 0:
+                e("s_min_u32 %[stmp], %[rown], %[nextrow]")      # the wave's next group may start below this one's end
+                e("v_mov_b32_e32 %[vtmp], %[stmp]")
+                e("ds_write_b32 %[vneed], %[vtmp]")
+            self.read_next(scn, "scnb" if scn == "scn" else "scb", uid)
+            if PFW and pf:
+                e(f"s_cbranch_vccz WL_NOPF_{uid}_%=")
+                for off in (0, 64, 124)[:PFW_LOADS]:
+                    e(f"global_load_dword %[vd], %[vz], s[{S_DP}:{S_DP + 1}] offset:{off}")
+                e(f"WL_NOPF_{uid}_%=:")
+        scb = "scb" if sc == "sc" else "scnb"
+        for r in windows:
+            e(f"v_mul_f64 %[t0], %[{sc}], {weight(cur, r)}")
+            e(f"v_mul_f64 %[t1], %[{scb}], {weight(cur, r)}")
+            e(f"v_add_f64 %[a{r}], %[a{r}], %[t0]")
+            e(f"v_add_f64 %[b{r}], %[b{r}], %[t1]")
+        if prefetch:
+            e("s_waitcnt lgkmcnt(0)")
+
+
+def build_strip():
+    g = StripGen()
+    e = g.e
+    e(f"s_mov_b64 s[{S_DP}:{S_DP + 1}], %[dp]")
+    e(f"s_load_dwordx16 {tup('A', 0)}, s[{S_DP}:{S_DP + 1}], 0x0")
+    e(f"s_load_dwordx16 {tup('A', 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
+    g.read_next("sc", "scb", 0)                       # row 0 of the group
+    e("s_cmp_lg_u32 %[pfon], 0")
+    e("s_cselect_b64 vcc, -1, 0")
+    for r in range(R):
+        e(f"v_mov_b64_e32 %[b{r}], 0")
+    for r in range(R):
+        e(f"v_mov_b64_e32 %[a{r}], 0")
+    e("s_waitcnt lgkmcnt(0)")
+    for i in range(R - 1):
+        g.step(i % 2, range(0, i + 1))
+    e("WL_LOOP_%=:")
+    g.step(1, range(R))
+    e("s_sub_u32 %[n], %[n], 1")
+    e("s_cmp_eq_u32 %[n], 0")
+    e("s_cbranch_scc1 WL_TAIL_EVEN_%=")
+    g.step(0, range(R))
+    e("s_sub_u32 %[n], %[n], 1")
+    e("s_cmp_lg_u32 %[n], 0")
+    e("s_cbranch_scc1 WL_LOOP_%=")
+    for first, label in ((1, None), (0, "WL_TAIL_EVEN_%=")):
+        if label:
+            e(label + ":")
+        for d in range(R - 1):
+            g.step((first + d) % 2, range(d + 1, R), prefetch=(d < R - 2), pf=False)
+        if first == 1:
+            e("s_branch WL_DONE_%=")
+    e("WL_DONE_%=:")
+    e("s_waitcnt vmcnt(0)")                            # the touches' results (never read) have landed
+    return g.out
+
+
 def build(gl, nb=1):
     g = Gen(gl, nb)
     e = g.e
@@ -274,9 +381,10 @@ def main():
         f.write("// WLOD2: two 64-individual blocks per wave, every weight used for both (half the scalar loads per operation).\n")
         f.write(f"#define GARLIC_WLOD_GL_RING_ROWS {GL_RING}\n")
         f.write(f"#define GARLIC_WLOD_PFW {PFW}\n#define GARLIC_WLOD_PFW_MAX_W {PFW_MAX_W}\n")
+        f.write(f"#define GARLIC_WLOD_GLS_RING_ROWS {GLS_RING}\n")
         for name, gl, nb in (("GARLIC_WLOD_LOOP_ASM", False, 1), ("GARLIC_WLOD_GL_LOOP_ASM", True, 1),
-                             ("GARLIC_WLOD2_LOOP_ASM", False, 2)):
-            lines = build(gl, nb)
+                             ("GARLIC_WLOD2_LOOP_ASM", False, 2), ("GARLIC_WLOD_GLS_LOOP_ASM", None, 2)):
+            lines = build_strip() if gl is None else build(gl, nb)
             total += sum(1 for x in lines if not x.endswith(":"))
             f.write(f"#define {name} \\\n")
             for ln in lines:
@@ -285,7 +393,7 @@ def main():
         regs = ['"s%d"' % r for r in range(S_DP, 100)] + ['"scc"', '"vcc"']
         f.write("#define GARLIC_WLOD_LOOP_CLOBBERS \\\n    ")
         f.write(", \\\n    ".join(", ".join(regs[i:i + 12]) for i in range(0, len(regs), 12)) + "\n")
-    print(f"wrote {os.path.normpath(path)}: {total} instructions in three variants")
+    print(f"wrote {os.path.normpath(path)}: {total} instructions in four variants")
 
 
 if __name__ == "__main__":
