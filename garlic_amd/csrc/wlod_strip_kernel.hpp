@@ -37,11 +37,14 @@ constexpr int WS_RING = GARLIC_WLOD_GLS_RING_ROWS;      // rows per ring (power 
 constexpr int WS_DEPTH = 6;                             // loader: row pairs (per block) in flight
 constexpr int WS_NEVER = 0x7fffffff;
 constexpr uint32_t WS_RING_BYTES = (uint32_t)WS_RING * WAVE * 8u;
-// dynamic LDS: ring A, ring B (1-KB aligned), patch lock (16 B), patch [64][WT_PITCH], landed (16 B), need[8]
-constexpr uint32_t WS_LOCK_OFF = 2u * WS_RING_BYTES;
+// dynamic LDS: ring A, ring B (1-KB aligned), the loader's counter (one 512-B row: every lane reads its own copy,
+// at its ring address + an immediate offset -- no address register), need[8] (eight such rows), patch lock
+// (16 B), patch [64][WT_PITCH]
+constexpr uint32_t WS_LANDED_OFF = 2u * WS_RING_BYTES;
+constexpr uint32_t WS_NEED_OFF = WS_LANDED_OFF + 512u;
+constexpr uint32_t WS_LOCK_OFF = WS_NEED_OFF + 8u * 512u;
 constexpr uint32_t WS_PATCH_OFF = WS_LOCK_OFF + 16u;
-constexpr uint32_t WS_FLAGS_OFF = (WS_PATCH_OFF + (uint32_t)(WAVE * WT_PITCH * 8) + 31u) & ~31u;
-constexpr uint32_t WS_LDS_BYTES = WS_FLAGS_OFF + 64u;
+constexpr uint32_t WS_LDS_BYTES = WS_PATCH_OFF + (uint32_t)(WAVE * WT_PITCH * 8);
 
 struct WlodStrip {
     int32_t chr, s_begin, n_groups, pad;               // windows s_begin .. s_begin + 16 * n_groups - 1 of the chromosome
@@ -59,27 +62,36 @@ struct WlodStripArgs {
     uint32_t n_work;           // strips x pairs
 };
 
-typedef int ws_int4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ int ws_min_need(const int *need)
+// flag rows: lane i's copy at row + 8 i
+__device__ __forceinline__ void ws_row_write(uint32_t lane8b, uint32_t off, int v)
 {
-    const uint32_t a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) int *)need;
-    ws_int4 x, y;
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(x), "=&v"(y) : "v"(a) : "memory");
-    const int m = min(min(min(x.x, x.y), min(x.z, x.w)), min(min(y.x, y.y), min(y.z, y.w)));
+    asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(lane8b + off), "v"(v) : "memory");
+}
+__device__ __forceinline__ int ws_min_need(uint32_t lane8b)
+{
+    int x[WS_MAX_WAVES];
+    const uint32_t a = lane8b + WS_NEED_OFF;
+    asm volatile("ds_read_b32 %0, %7\n\tds_read_b32 %1, %7 offset:512\n\tds_read_b32 %2, %7 offset:1024\n\t"
+                 "ds_read_b32 %3, %7 offset:1536\n\tds_read_b32 %4, %7 offset:2048\n\tds_read_b32 %5, %7 offset:2560\n\t"
+                 "ds_read_b32 %6, %7 offset:3072\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]) : "v"(a) : "memory");
+    static_assert(WS_MAX_WAVES == 7, "seven rows of need[] are read");
+    const int m = min(min(min(x[0], x[1]), min(x[2], x[3])), min(min(x[4], x[5]), x[6]));
     return __builtin_amdgcn_readfirstlane(m);
 }
 
 // the two-block loop over one 16-window group, scores from the rings (see tools/gen_wlod_asm.py)
-__device__ __forceinline__ void wlod_group_gls(uint32_t lane8b, uint32_t vflag, uint32_t vneed, const double *Ds, int W,
+__device__ __forceinline__ void wlod_group_gls(uint32_t lane8b, uint32_t needoff, const double *Ds, int W,
                                                uint32_t row0, uint32_t nextrow, uint32_t &landed, uint32_t &polls,
                                                double (&acc)[WLOD_R], double (&bcc)[WLOD_R])
 {
     constexpr int R = WLOD_R;
     static_assert(R == 16, "the hand-scheduled loop keeps 16 weights per step in SGPRs");
     double sc, scn, scb, scnb, t0, t1;
-    uint32_t vt, vtmp, vd, stmp;
+    uint32_t vt, vtmp, stmp;
+#if GARLIC_WLOD_GLS_PFW
+    uint32_t vd;
+#endif
     uint32_t n = (uint32_t)(W - (R - 1));
     uint32_t rown = row0, rd = (row0 & (uint32_t)(WS_RING - 1)) * 512u;
     const double *dp = Ds - (R - 1);
@@ -94,11 +106,16 @@ __device__ __forceinline__ void wlod_group_gls(uint32_t lane8b, uint32_t vflag, 
                    [b8] "=&v"(bcc[8]), [b9] "=&v"(bcc[9]), [b10] "=&v"(bcc[10]), [b11] "=&v"(bcc[11]),
                    [b12] "=&v"(bcc[12]), [b13] "=&v"(bcc[13]), [b14] "=&v"(bcc[14]), [b15] "=&v"(bcc[15]),
                    [sc] "=&v"(sc), [scn] "=&v"(scn), [scb] "=&v"(scb), [scnb] "=&v"(scnb), [t0] "=&v"(t0), [t1] "=&v"(t1),
-                   [vt] "=&v"(vt), [vtmp] "=&v"(vtmp), [vd] "=&v"(vd), [rd] "+s"(rd), [rown] "+s"(rown),
+                   [vt] "=&v"(vt), [vtmp] "=&v"(vtmp), [rd] "+s"(rd), [rown] "+s"(rown),
                    [landed] "+s"(landed), [polls] "+s"(polls), [n] "+s"(n), [stmp] "=&s"(stmp)
-                 : [nextrow] "s"(nextrow), [dp] "s"(dp), [stride] "s"(stride), [lane8b] "v"(lane8b), [vflag] "v"(vflag), [vneed] "v"(vneed),
-                   [vz] "v"((uint32_t)GARLIC_WLOD_PFW * stride),
+#if GARLIC_WLOD_GLS_PFW
+                   , [vd] "=&v"(vd)
+#endif
+                 : [nextrow] "s"(nextrow), [dp] "s"(dp), [stride] "s"(stride), [lane8b] "v"(lane8b), [needoff] "s"(needoff)
+#if GARLIC_WLOD_GLS_PFW
+                   , [vz] "v"((uint32_t)GARLIC_WLOD_PFW * stride),
                    [pfon] "s"(__builtin_amdgcn_readfirstlane(W <= GARLIC_WLOD_PFW_MAX_W ? 1 : 0))
+#endif
                  : GARLIC_WLOD_LOOP_CLOBBERS, "memory");
 }
 
@@ -119,10 +136,9 @@ __device__ __forceinline__ void ws_wait_pairs(int pairs)
 }
 
 // loader wave: rows 0 .. n_rows-1 (n_rows even) of both blocks into the rings, two rows per request
-__device__ __forceinline__ void ws_loader(const double *srcA, const double *srcB, int n_rows, uint32_t ring_lds,
-                                          const int *need, int *landed, int lane)
+__device__ __forceinline__ void ws_loader(const double *srcA, const double *srcB, int n_rows, uint32_t ring_lds, int lane)
 {
-    const uint32_t lane16 = (uint32_t)lane * 16u;
+    const uint32_t lane16 = (uint32_t)lane * 16u, lane8b = ring_lds + (uint32_t)lane * 8u;
     uint32_t slot_off = 0;
     int inflight = 0, published = 0, min_need = 0;
     for (int r = 0; r < n_rows; r += 2) {
@@ -130,11 +146,11 @@ __device__ __forceinline__ void ws_loader(const double *srcA, const double *srcB
             // no room: meanwhile retire and publish what is in flight, oldest first (a compute wave may be waiting
             // for exactly those rows -- never block with unpublished rows)
             int budget = 1 << 22;
-            while (r + 2 - (min_need = ws_min_need(need)) > WS_RING) {
+            while (r + 2 - (min_need = ws_min_need(lane8b)) > WS_RING) {
                 if (inflight > 0) {
                     ws_wait_pairs(--inflight);
                     published += 2;
-                    tg_flag_write(landed, published);
+                    ws_row_write(lane8b, WS_LANDED_OFF, published);
                 } else {
                     if (--budget == 0) __builtin_trap();
                     __builtin_amdgcn_s_sleep(2);
@@ -151,15 +167,15 @@ __device__ __forceinline__ void ws_loader(const double *srcA, const double *srcB
         if (++inflight == WS_DEPTH) {       // the oldest pair has landed
             ws_wait_pairs(--inflight);
             published += 2;
-            tg_flag_write(landed, published);
+            ws_row_write(lane8b, WS_LANDED_OFF, published);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    tg_flag_write(landed, n_rows);
+    ws_row_write(lane8b, WS_LANDED_OFF, n_rows);
 }
 
 template <bool ALIGNED16>
-__global__ void __launch_bounds__((WS_MAX_WAVES + 1) * WAVE, 5)   // 5 waves per SIMD: at most 96 VGPRs
+__global__ void __launch_bounds__((WS_MAX_WAVES + 1) * WAVE, 5)   // 5 waves per SIMD: at most 96 VGPRs (at 80 -- 6 waves, three workgroups per CU -- hipcc does not finish allocating registers around the loop)
 wlod_strip_gl_kernel(WlodStripArgs p)
 {
     extern __shared__ __attribute__((aligned(1024))) char ws_lds[];
@@ -168,8 +184,8 @@ wlod_strip_gl_kernel(WlodStripArgs p)
     const int N = p.n_waves;                              // blockDim.x = (N + 1) * 64
     int *patch_lock = reinterpret_cast<int *>(ws_lds + WS_LOCK_OFF);
     double *patch = reinterpret_cast<double *>(ws_lds + WS_PATCH_OFF);
-    int *landed = reinterpret_cast<int *>(ws_lds + WS_FLAGS_OFF);
-    int *need = reinterpret_cast<int *>(ws_lds + WS_FLAGS_OFF + 32);
+    int *landed = reinterpret_cast<int *>(ws_lds + WS_LANDED_OFF);     // [64][2]: a copy per lane
+    int *need = reinterpret_cast<int *>(ws_lds + WS_NEED_OFF);         // [8][64][2]
     // one contiguous range of the work per XCD (one L2 each): the pairs of a strip share its weights
     const unsigned per_xcd = gridDim.x >> 3;
     const unsigned v = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
@@ -177,11 +193,9 @@ wlod_strip_gl_kernel(WlodStripArgs p)
     const WlodStrip st = p.strips[v / (unsigned)p.n_pairs];
     const int pair = (int)(v % (unsigned)p.n_pairs);
     const ChrDev c = p.chrs[st.chr];
-    if (threadIdx.x == 0) {
-        *patch_lock = 0;
-        *landed = 0;
-    }
-    if (threadIdx.x < 8) need[threadIdx.x] = ((int)threadIdx.x < N && (int)threadIdx.x < st.n_groups) ? 16 * (int)threadIdx.x : WS_NEVER;
+    if (threadIdx.x == 0) *patch_lock = 0;
+    if (wave == 0) landed[2 * lane] = 0;
+    if (wave < WS_MAX_WAVES) need[(wave * WAVE + lane) * 2] = (wave < N && wave < st.n_groups) ? 16 * wave : WS_NEVER;
     __syncthreads();
     const int ind0A = pair * 2 * WAVE, ind0B = ind0A + WAVE;
     const bool activeB = ind0B < p.ind_count;
@@ -193,12 +207,11 @@ wlod_strip_gl_kernel(WlodStripArgs p)
         const double *srcB = activeB ? srcA + p.term_rows * WAVE : srcA;   // no second block: the first one again
         const int n_rows = (16 * (st.n_groups - 1) + W + 15 + 1) & ~1;
         __builtin_amdgcn_s_setprio(3);     // few instructions, and everybody waits for them
-        ws_loader(srcA, srcB, n_rows, ring_lds, need, landed, lane);
+        ws_loader(srcA, srcB, n_rows, ring_lds, lane);
         return;
     }
     const uint32_t lane8b = ring_lds + (uint32_t)lane * 8u;
-    const uint32_t vflag = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int *)landed;
-    const uint32_t vneed = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int *)(need + wave);
+    const uint32_t needoff = WS_NEED_OFF + (uint32_t)wave * 512u;
     uint32_t landed_seen = 0;
 #pragma unroll 1
     for (int g = wave; g < st.n_groups; g += N) {
@@ -209,11 +222,11 @@ wlod_strip_gl_kernel(WlodStripArgs p)
         const int next_row = g + N < st.n_groups ? 16 * (g + N) : WS_NEVER;
         if (gm != 0) {
             uint32_t polls = 1u << 20;
-            wlod_group_gls(lane8b, vflag, vneed, p.D + (c.loc_base + s) * (int64_t)W, W, (uint32_t)(16 * g),
+            wlod_group_gls(lane8b, needoff, p.D + (c.loc_base + s) * (int64_t)W, W, (uint32_t)(16 * g),
                            (uint32_t)next_row, landed_seen, polls, acc, bcc);
             if (polls == 0) __builtin_trap();
         }
-        tg_flag_write(need + wave, next_row);
+        ws_row_write(lane8b, needoff, next_row);
         wlod_write_group<WLOD_R, ALIGNED16>(acc, gm, c, p, p.out, patch, patch_lock, ind0A, s, 0, lane);
         if (activeB) wlod_write_group<WLOD_R, ALIGNED16>(bcc, gm, c, p, p.out, patch, patch_lock, ind0B, s, 0, lane);
     }

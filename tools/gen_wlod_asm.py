@@ -186,7 +186,8 @@ class Gen:
 # genotype look-ups:  every other step publish the next row this wave reads ([vneed]);  if that row has not
 # landed ([rown] >= [landed], the wave's copy of the loader's counter) poll the counter ([vflag]), at most
 # [polls] times;  two ds_read_b64 (ring A at [lane8b] + [rd], ring B GLS_RING * 512 bytes above).
-GLS_RING = int(os.environ.get("GARLIC_WLOD_GLS_RING", "64"))     # rows per ring
+GLS_RING = int(os.environ.get("GARLIC_WLOD_GLS_RING", "32"))     # rows per ring
+GLS_PFW = int(os.environ.get("GARLIC_WLOD_GLS_PFW", "1"))        # weight touches in the strip loop (2 more VGPRs)
 GLS_MASK = GLS_RING * 512 - 1
 
 
@@ -201,7 +202,7 @@ class StripGen(Gen):
         if "nopoll" in ABL:
             e(f"s_branch WS_OK_{uid}_%=")
         e(f"WS_POLL_{uid}_%=:")
-        e("ds_read_b32 %[vtmp], %[vflag]")
+        e(f"ds_read_b32 %[vtmp], %[lane8b] offset:{2 * GLS_RING * 512}")    # the lane's copy of the loader's counter
         e("s_waitcnt lgkmcnt(0)")
         e("v_readfirstlane_b32 %[landed], %[vtmp]")
         e("s_cmp_lt_u32 %[rown], %[landed]")
@@ -231,10 +232,11 @@ class StripGen(Gen):
             e(f"s_load_dwordx16 {tup(nxt, 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
             if parity == 0:
                 e("s_min_u32 %[stmp], %[rown], %[nextrow]")      # the wave's next group may start below this one's end
+                e("v_add_u32_e32 %[vt], %[needoff], %[lane8b]")  # the lane's copy of this wave's row of need[]
                 e("v_mov_b32_e32 %[vtmp], %[stmp]")
-                e("ds_write_b32 %[vneed], %[vtmp]")
+                e("ds_write_b32 %[vt], %[vtmp]")
             self.read_next(scn, "scnb" if scn == "scn" else "scb", uid)
-            if PFW and pf:
+            if GLS_PFW and pf:
                 e(f"s_cbranch_vccz WL_NOPF_{uid}_%=")
                 for off in (0, 64, 124)[:PFW_LOADS]:
                     e(f"global_load_dword %[vd], %[vz], s[{S_DP}:{S_DP + 1}] offset:{off}")
@@ -256,8 +258,9 @@ def build_strip():
     e(f"s_load_dwordx16 {tup('A', 0)}, s[{S_DP}:{S_DP + 1}], 0x0")
     e(f"s_load_dwordx16 {tup('A', 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
     g.read_next("sc", "scb", 0)                       # row 0 of the group
-    e("s_cmp_lg_u32 %[pfon], 0")
-    e("s_cselect_b64 vcc, -1, 0")
+    if GLS_PFW:
+        e("s_cmp_lg_u32 %[pfon], 0")
+        e("s_cselect_b64 vcc, -1, 0")
     for r in range(R):
         e(f"v_mov_b64_e32 %[b{r}], 0")
     for r in range(R):
@@ -282,7 +285,8 @@ def build_strip():
         if first == 1:
             e("s_branch WL_DONE_%=")
     e("WL_DONE_%=:")
-    e("s_waitcnt vmcnt(0)")                            # the touches' results (never read) have landed
+    if GLS_PFW:
+        e("s_waitcnt vmcnt(0)")                        # the touches' results (never read) have landed
     return g.out
 
 
@@ -381,7 +385,7 @@ def main():
         f.write("// WLOD2: two 64-individual blocks per wave, every weight used for both (half the scalar loads per operation).\n")
         f.write(f"#define GARLIC_WLOD_GL_RING_ROWS {GL_RING}\n")
         f.write(f"#define GARLIC_WLOD_PFW {PFW}\n#define GARLIC_WLOD_PFW_MAX_W {PFW_MAX_W}\n")
-        f.write(f"#define GARLIC_WLOD_GLS_RING_ROWS {GLS_RING}\n")
+        f.write(f"#define GARLIC_WLOD_GLS_RING_ROWS {GLS_RING}\n#define GARLIC_WLOD_GLS_PFW {GLS_PFW}\n")
         for name, gl, nb in (("GARLIC_WLOD_LOOP_ASM", False, 1), ("GARLIC_WLOD_GL_LOOP_ASM", True, 1),
                              ("GARLIC_WLOD2_LOOP_ASM", False, 2), ("GARLIC_WLOD_GLS_LOOP_ASM", None, 2)):
             lines = build_strip() if gl is None else build(gl, nb)
