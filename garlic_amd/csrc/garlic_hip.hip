@@ -1791,7 +1791,16 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
             e = hipMemcpyAsync(d_pair.p, pair_counts, sizeof(int32_t) * n * 2, hipMemcpyHostToDevice, s);
         loc = d_loc.p; pair = d_pair.p;
     }
-    if ((rc = d_hf.reserve(p->nloci)) || (rc = d_fwd.reserve(n)) || (rc = d_bwd.reserve(n))) return done(rc);
+    // ordered sums: LDS-tiled kernel (one thread per column of the LD row) unless the window is too wide
+    const bool tiled = winsize <= LD_SUM_MAX_W && !getenv("GARLIC_LD_SUM_L2");
+    // ... thread = SNP of the window, accumulators = window starts (ld_sum_col_kernel) unless switched off
+    const int col_threads = (winsize + 16 + WAVE - 1) / WAVE * WAVE;
+    const bool by_snp = tiled && winsize > LD_COL_B && col_threads <= LD_COL_MAX_THREADS && !getenv("GARLIC_LD_SUM_BY_COLUMN");
+    const int sum_b = by_snp ? std::min(LD_COL_B, col_threads - winsize + 1) : LD_SUM_B;
+    // (the SNP-per-thread kernel reads one combined row of 2W doubles per SNP, in d_fwd; + 1 KB the last row's
+    // last request may run over)
+    if ((rc = d_hf.reserve(p->nloci)) || (rc = d_fwd.reserve(by_snp ? 2 * n + 256 : n)) || (!by_snp && (rc = d_bwd.reserve(n))))
+        return done(rc);
     double *ld = ld_out;
     if (where == GARLIC_HOST || !ld_out) {
         if ((rc = d_ld.reserve(n))) return done(rc);
@@ -1806,21 +1815,23 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
         hipLaunchKernelGGL(ld_homfreq_kernel, dim3((unsigned)((p->nloci + 255) / 256)), dim3(256), 0, s, loc,
                            p->nloci, d_hf.p);
     }
-    // ordered sums: LDS-tiled kernel (one thread per column of the LD row) unless the window is too wide
-    const bool tiled = winsize <= LD_SUM_MAX_W && !getenv("GARLIC_LD_SUM_L2");
     std::vector<LdSumChr> sum_chrs;
     int64_t sum_blocks = 0;
     for (int c = 0; tiled && c < p->nchr; c++) {
         const int64_t nstarts = p->chr_off[c + 1] - p->chr_off[c] - winsize + 1;
         if (nstarts < 1) continue;
         sum_chrs.push_back(LdSumChr{p->chr_off[c], nstarts, sum_blocks});
-        sum_blocks += (nstarts + LD_SUM_B - 1) / LD_SUM_B;
+        sum_blocks += (nstarts + sum_b - 1) / sum_b;
     }
     if (tiled && (rc = d_sum_chrs.reserve(std::max<size_t>(sum_chrs.size(), 1)))) return done(rc);
     for (int c = 0; c < p->nchr; c++) {
         const int64_t lo = p->chr_off[c], hi = p->chr_off[c + 1];
-        hipLaunchKernelGGL(ld_hr2_kernel, dim3((unsigned)(hi - lo)), dim3(256), 0, s, pair, d_hf.p, lo, hi,
-                           winsize, d_fwd.p, d_bwd.p);
+        if (by_snp)
+            hipLaunchKernelGGL(ld_hr2_kernel<true>, dim3((unsigned)(hi - lo)), dim3(128), 0, s, pair, d_hf.p, lo, hi,
+                               winsize, d_fwd.p, (double *)nullptr);
+        else
+            hipLaunchKernelGGL(ld_hr2_kernel<false>, dim3((unsigned)(hi - lo)), dim3(256), 0, s, pair, d_hf.p, lo, hi,
+                               winsize, d_fwd.p, d_bwd.p);
         if (hi - lo >= winsize && !tiled)
             hipLaunchKernelGGL(ld_sum_kernel, dim3((unsigned)(hi - lo - winsize + 1)), dim3(256), 0, s, d_fwd.p, d_bwd.p,
                                lo, winsize, ld);
@@ -1828,10 +1839,15 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
     if (tiled && !sum_chrs.empty()) {   // all chromosomes in one grid, after every hr2 value exists
         e = hipMemcpyAsync(d_sum_chrs.p, sum_chrs.data(), sizeof(LdSumChr) * sum_chrs.size(), hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
-        const int threads = (winsize + WAVE - 1) / WAVE * WAVE;
-        hipLaunchKernelGGL(ld_sum_tiled_kernel, dim3((unsigned)sum_blocks), dim3(threads),
-                           sizeof(double) * 2 * (2 * (size_t)winsize - 1 + 128 + threads), s, d_fwd.p, d_bwd.p, d_sum_chrs.p,
-                           (int)sum_chrs.size(), winsize, ld);
+        const int threads = by_snp ? col_threads : (winsize + WAVE - 1) / WAVE * WAVE;
+        const size_t lds = by_snp ? sizeof(double) * (32 + (size_t)LD_COL_RING * 2 * winsize + threads + 160)
+                                  : sizeof(double) * 2 * (2 * (size_t)winsize - 1 + 128 + threads);
+        if (by_snp)
+            hipLaunchKernelGGL(ld_sum_col_kernel, dim3((unsigned)sum_blocks), dim3(threads), lds, s, d_fwd.p,
+                               d_sum_chrs.p, (int)sum_chrs.size(), winsize, sum_b, ld);
+        else
+            hipLaunchKernelGGL(ld_sum_tiled_kernel, dim3((unsigned)sum_blocks), dim3(threads), lds, s, d_fwd.p, d_bwd.p,
+                               d_sum_chrs.p, (int)sum_chrs.size(), winsize, ld);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));

@@ -273,19 +273,28 @@ __device__ __forceinline__ double hr2_from_counts(double HA, double HB, int32_t 
 }
 
 // fwd[i * W + d] = hr2(i, i + d);  bwd[(i + d) * W + d] = hr2(i + d, i)      (d = 1 .. W-1)
+// COMBINED (for ld_sum_col_kernel): one row of 2W doubles per SNP in `fwd`,
+//     C[i][W-1 + d] = hr2(i, i + d), d in (-W, W): the value of the pair (i, i+d) as SNP i's term; C[i][W-1] = 1.0
+template <bool COMBINED>
 __global__ void __launch_bounds__(256)
 ld_hr2_kernel(const int32_t *__restrict__ pair, const double *__restrict__ hf, int64_t lo, int64_t hi,
               int W, double *__restrict__ fwd, double *__restrict__ bwd)
 {
     const int64_t i = lo + blockIdx.x;
     const double HA = hf[i];
+    if (COMBINED && threadIdx.x == 0) fwd[i * 2 * W + W - 1] = 1.0;
     for (int d = 1 + threadIdx.x; d < W; d += blockDim.x) {
         const int64_t j = i + d;
         if (j >= hi) continue;
         const int32_t tot = pair[(i * W + d) * 2], hab = pair[(i * W + d) * 2 + 1];
         const double HB = hf[j];
-        fwd[i * W + d] = hr2_from_counts(HA, HB, hab, tot);
-        bwd[j * W + d] = hr2_from_counts(HB, HA, hab, tot);
+        if (COMBINED) {
+            fwd[i * 2 * W + W - 1 + d] = hr2_from_counts(HA, HB, hab, tot);
+            fwd[j * 2 * W + W - 1 - d] = hr2_from_counts(HB, HA, hab, tot);
+        } else {
+            fwd[i * W + d] = hr2_from_counts(HA, HB, hab, tot);
+            bwd[j * W + d] = hr2_from_counts(HB, HA, hab, tot);
+        }
     }
 }
 
@@ -396,6 +405,134 @@ ld_sum_tiled_kernel(const double *__restrict__ fwd, const double *__restrict__ b
 #pragma unroll
         for (int q = 0; q < LD_SUM_B; q++)
             if (q < ns) ld[(s0 + q) * W + k] = x86_nan_if_nan(acc[q]);
+    }
+}
+
+// The ordered sums once more, transposed: thread = the window's SNP t = s + k, accumulators = the window
+// starts.  ld_sum_tiled_kernel's thread owns the column k of LD_SUM_B window starts, so each of its adds
+// takes a different element of the staged row (SNP t = s0 + q + k differs with q): one 8-B LDS read per add,
+// and the kernel runs at the pace of the LDS (32.5 ms of an 86-ms LD call at 10M SNPs x 1250, W = 100).  With a
+// thread per SNP t the term hr2(i, t) of step i is the SAME for every window start whose window contains i
+// and t: one LDS read per step and thread, up to LD_COL_B adds on it.  Thread tl (t = s0 + tl) holds
+// acc[q] = LD[s0 + q][tl - q] for the starts q with 0 <= tl - q < W (the other accumulators collect values that
+// are never stored); every accumulator still receives its terms in the order i = s .. s+W-1 from 0.0
+// (garlic-data.cpp:521-527).  Threads: W + B - 1 SNPs rounded up to whole waves -- the host picks
+// B = min(32, threads - W + 1) so that few lanes idle (W = 100: 128 threads, 29 starts per workgroup).
+// The rows come from ld_hr2_kernel<true>'s combined table (one contiguous row of 2W doubles per SNP).
+constexpr int LD_COL_B = 32;
+constexpr int LD_COL_MAX_THREADS = 320;
+constexpr int LD_COL_RING = 8;       // rows in the LDS ring
+constexpr int LD_COL_AHEAD = 6;      // rows requested ahead of the step that reads them (<= LD_COL_RING - 2)
+constexpr int LD_COL_MAX_PIECES = 4; // 1-KB requests per row: W <= 256
+
+// waits until at most n of the wave's vector-memory requests are outstanding (n wave-uniform, 0 .. 20)
+__device__ __forceinline__ void ld_col_wait(int n)
+{
+    static_assert((LD_COL_AHEAD - 1) * LD_COL_MAX_PIECES <= 20, "one s_waitcnt per count below");
+    switch (n) {
+#define LD_COL_WAIT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+        LD_COL_WAIT_CASE(0) LD_COL_WAIT_CASE(1) LD_COL_WAIT_CASE(2) LD_COL_WAIT_CASE(3) LD_COL_WAIT_CASE(4)
+        LD_COL_WAIT_CASE(5) LD_COL_WAIT_CASE(6) LD_COL_WAIT_CASE(7) LD_COL_WAIT_CASE(8) LD_COL_WAIT_CASE(9)
+        LD_COL_WAIT_CASE(10) LD_COL_WAIT_CASE(11) LD_COL_WAIT_CASE(12) LD_COL_WAIT_CASE(13) LD_COL_WAIT_CASE(14)
+        LD_COL_WAIT_CASE(15) LD_COL_WAIT_CASE(16) LD_COL_WAIT_CASE(17) LD_COL_WAIT_CASE(18) LD_COL_WAIT_CASE(19)
+        LD_COL_WAIT_CASE(20)
+#undef LD_COL_WAIT_CASE
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// acc[q] += h for q = first .. 31 (ASCENDING) or q = 31 - first .. 0 (descending), `first` wave-uniform: the 32
+// adds are laid out in that order and the wave jumps over the first `first` of them (8 bytes each) -- one computed
+// branch per step where a test per accumulator costs two scalar instructions each and, written in C++, made
+// hipcc copy every accumulator every step.
+#define LD_COL_ADD(q) "v_add_f64 %[a" #q "], %[a" #q "], %[h]\n\t"
+#define LD_COL_OPS(a)                                                                                              \
+    [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]), [a4] "+v"(a[4]), [a5] "+v"(a[5]),          \
+    [a6] "+v"(a[6]), [a7] "+v"(a[7]), [a8] "+v"(a[8]), [a9] "+v"(a[9]), [a10] "+v"(a[10]), [a11] "+v"(a[11]),      \
+    [a12] "+v"(a[12]), [a13] "+v"(a[13]), [a14] "+v"(a[14]), [a15] "+v"(a[15]), [a16] "+v"(a[16]),                 \
+    [a17] "+v"(a[17]), [a18] "+v"(a[18]), [a19] "+v"(a[19]), [a20] "+v"(a[20]), [a21] "+v"(a[21]),                 \
+    [a22] "+v"(a[22]), [a23] "+v"(a[23]), [a24] "+v"(a[24]), [a25] "+v"(a[25]), [a26] "+v"(a[26]),                 \
+    [a27] "+v"(a[27]), [a28] "+v"(a[28]), [a29] "+v"(a[29]), [a30] "+v"(a[30]), [a31] "+v"(a[31])
+// s_getpc_b64 yields the address of the instruction behind it; three 4-byte instructions follow before the adds
+#define LD_COL_JUMP "s_getpc_b64 s[98:99]\n\ts_add_u32 s98, s98, %[off]\n\ts_addc_u32 s99, s99, 0\n\ts_setpc_b64 s[98:99]\n\t"
+// one block for both orders (two blocks on the same accumulators in an if / else made hipcc copy all of them at the
+// join): the descending sequence, a branch over the ascending one, the ascending sequence
+__device__ __forceinline__ void ld_col_adds(double (&a)[LD_COL_B], double h, bool ascending, int first)
+{
+    static_assert(LD_COL_B == 32, "32 adds are written out");
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane(first * 8 + (ascending ? 12 + 32 * 8 + 4 : 12));
+    asm volatile(LD_COL_JUMP
+                 LD_COL_ADD(31) LD_COL_ADD(30) LD_COL_ADD(29) LD_COL_ADD(28) LD_COL_ADD(27) LD_COL_ADD(26)
+                 LD_COL_ADD(25) LD_COL_ADD(24) LD_COL_ADD(23) LD_COL_ADD(22) LD_COL_ADD(21) LD_COL_ADD(20)
+                 LD_COL_ADD(19) LD_COL_ADD(18) LD_COL_ADD(17) LD_COL_ADD(16) LD_COL_ADD(15) LD_COL_ADD(14)
+                 LD_COL_ADD(13) LD_COL_ADD(12) LD_COL_ADD(11) LD_COL_ADD(10) LD_COL_ADD(9) LD_COL_ADD(8) LD_COL_ADD(7)
+                 LD_COL_ADD(6) LD_COL_ADD(5) LD_COL_ADD(4) LD_COL_ADD(3) LD_COL_ADD(2) LD_COL_ADD(1) LD_COL_ADD(0)
+                 "s_branch LD_COL_END_%=\n\t"
+                 LD_COL_ADD(0) LD_COL_ADD(1) LD_COL_ADD(2) LD_COL_ADD(3) LD_COL_ADD(4) LD_COL_ADD(5)
+                 LD_COL_ADD(6) LD_COL_ADD(7) LD_COL_ADD(8) LD_COL_ADD(9) LD_COL_ADD(10) LD_COL_ADD(11) LD_COL_ADD(12)
+                 LD_COL_ADD(13) LD_COL_ADD(14) LD_COL_ADD(15) LD_COL_ADD(16) LD_COL_ADD(17) LD_COL_ADD(18)
+                 LD_COL_ADD(19) LD_COL_ADD(20) LD_COL_ADD(21) LD_COL_ADD(22) LD_COL_ADD(23) LD_COL_ADD(24)
+                 LD_COL_ADD(25) LD_COL_ADD(26) LD_COL_ADD(27) LD_COL_ADD(28) LD_COL_ADD(29) LD_COL_ADD(30)
+                 LD_COL_ADD(31)
+                 "LD_COL_END_%=:\n\t"
+                 : LD_COL_OPS(a) : [h] "v"(h), [off] "s"(off) : "s98", "s99", "scc");
+}
+__global__ void __launch_bounds__(LD_COL_MAX_THREADS)
+ld_sum_col_kernel(const double *__restrict__ C, const LdSumChr *__restrict__ chrs, int nchr, int W, int B,
+                  double *__restrict__ ld)
+{
+    // LDS: 32 doubles of slack, a ring of LD_COL_RING rows of 2W doubles, slack again: a thread's look-up
+    // x = W-1 + tl - j lies in [-(B-1), W-1 + blockDim) -- outside [0, 2W-1) it lands in a neighbouring row or the
+    // slack and feeds an accumulator that is never stored
+    extern __shared__ double ld_rows[];
+    const int tl = threadIdx.x, P = 2 * W;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int c = 0;
+    while (c + 1 < nchr && (int64_t)blockIdx.x >= chrs[c + 1].block0) c++;
+    const int64_t s0 = chrs[c].lo + ((int64_t)blockIdx.x - chrs[c].block0) * B;
+    const int ns = (int)min<int64_t>(B, chrs[c].lo + chrs[c].nstarts - s0);
+    const int nsteps = ns + W - 1;
+    // the rows of the SNPs s0 .. s0 + nsteps - 1 are one contiguous piece of C: wave 0 streams them into the ring by
+    // LDS-DMA, `pieces` requests of 1 KB per row (the last one runs into the next row: the same bytes that row's own
+    // requests bring, or slack), LD_COL_AHEAD rows ahead, no registers in between
+    const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)ld_rows + 32u * 8u;
+    const uint32_t row_bytes = (uint32_t)P * 8u;
+    const int pieces = (int)((row_bytes + 1023u) / 1024u);
+    const uint32_t lane16 = (uint32_t)(tl & 63) * 16u;
+    const char *src = reinterpret_cast<const char *>(C + s0 * P);
+    auto request = [&](int j) {                               // row j of the strip -> ring slot j % LD_COL_RING
+        const uint32_t dst = ring + (uint32_t)(j % LD_COL_RING) * row_bytes;
+        const char *g = src + (int64_t)j * row_bytes;
+        for (int q = 0; q < pieces; q++)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(dst + (uint32_t)q * 1024u), "v"(lane16), "s"(g + q * 1024) : "memory");
+    };
+    if (wave == 0)
+        for (int j = 0; j < min(LD_COL_AHEAD, nsteps); j++) request(j);
+    double acc[LD_COL_B];
+#pragma unroll
+    for (int q = 0; q < LD_COL_B; q++) acc[q] = 0.0;
+    for (int j = 0; j < nsteps; j++) {
+        if (wave == 0) {
+            // requests retire in order: all but the rows j+1 .. issued so far have landed
+            const int behind = min(LD_COL_AHEAD - 1, nsteps - 1 - j) * pieces;   // requests issued after row j's
+            ld_col_wait(behind);
+        }
+        __syncthreads();       // row j is in the ring; everybody is done with row j - 1 (its slot is written next at the earliest)
+        if (wave == 0 && j + LD_COL_AHEAD < nsteps) request(j + LD_COL_AHEAD);
+        double h;              // hr2(s0 + j, s0 + tl)
+        {
+            const uint32_t a = ring + (uint32_t)(j % LD_COL_RING) * row_bytes + (uint32_t)((W - 1 + tl - j) * 8);
+            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(h) : "v"(a) : "memory");
+        }
+        const bool leaving = j >= W;
+        ld_col_adds(acc, h, leaving,                                     // entering: q = min(j, 31) .. 0
+                    leaving ? j - W + 1 : (j < LD_COL_B - 1 ? LD_COL_B - 1 - j : 0));   // leaving: q = j-W+1 .. 31
+    }
+#pragma unroll
+    for (int q = 0; q < LD_COL_B; q++) {
+        const int k = tl - q;
+        if (q < ns && k >= 0 && k < W) ld[(s0 + q) * W + k] = x86_nan_if_nan(acc[q]);
     }
 }
 

@@ -243,16 +243,22 @@ def test_phased_ld_sharded(gpu_ctx):
         panel.close()
 
 
-@pytest.mark.parametrize("W", [63, 64, 65, 200, 256, 257])
-def test_ld_wide_windows_and_kernel_switch(gpu_ctx, W):
-    """the LDS-tiled ordered sums serve W <= 256 (one thread per column, 64 window starts per
-    workgroup: W around the wave size and the group size), the plain kernel everything wider"""
+@pytest.mark.parametrize("W", [32, 33, 34, 63, 64, 65, 200, 256, 257])
+def test_ld_wide_windows_and_kernel_switch(gpu_ctx, W, monkeypatch):
+    """the ordered sums: 33 <= W <= 256 one thread per SNP of the window (ld_sum_col_kernel, the combined hr2 rows
+    streamed by LDS-DMA; W around the wave size, the accumulator count and the widest it takes), below that and
+    when switched off one thread per column (ld_sum_tiled_kernel), wider windows the plain kernel"""
     rng = np.random.default_rng(W)
     nind = 24
-    sizes = [W + 70, W, W - 1, 2 * W + 3]
+    sizes = [W + 70, W, W - 1, 2 * W + 3, 5 * W + 1]
     chroms = [ol.random_panel(rng, n, nind, max_gap=10 ** 9, gaps=0, miss=0.1) for n in sizes]
+    want = oracle_ld(chroms, W)
     with make_panel(gpu_ctx, chroms, nind) as panel:
-        assert same(panel.compute_ld(W), oracle_ld(chroms, W))
+        assert same(panel.compute_ld(W), want)
+        monkeypatch.setenv("GARLIC_LD_SUM_BY_COLUMN", "1")
+        assert same(panel.compute_ld(W), want)
+        monkeypatch.setenv("GARLIC_LD_SUM_L2", "1")
+        assert same(panel.compute_ld(W), want)
 
 
 def test_phased_ld_golden_from_the_reference_build(gpu_ctx):
