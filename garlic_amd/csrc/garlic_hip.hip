@@ -185,7 +185,7 @@ struct garlic_panel {
     bool dfreq_valid = false;
     int gl_terms_by = 0;                           // who built the current terms: 1 device log10, 2 host libm
     // wLOD
-    bool have_ld = false, wlod_use_gl = false;
+    bool have_ld = false, wlod_use_gl = false, rld_valid = false;
     int32_t ld_winsize = 0;
     DevBuf<double> d_rld, d_decay, d_stage64;
     DevBuf<uint64_t> d_phase;                      // HapData::firstCopy as bit planes [blk][nloci] (--phased LD)
@@ -235,6 +235,8 @@ struct garlic_panel {
         int64_t n_runs = 0, n_valid = 0;
     } plan;
 };
+
+static int ensure_rld(garlic_panel *p);   // plain reciprocals of the LD weights, made when the generic wLOD kernel needs them
 
 namespace {
 
@@ -802,6 +804,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     bool wlod_fast = (wlod_shape_ok && !use_gl) || wlod_gl;                 // tile kernel, either variant
     if (wlod_fast && !wlod_gl && sizeof(double) * (size_t)(W + TILE) * 4 + 16 > 150 * 1024) wlod_fast = false;
     if (wlod_fast && !wlod_gl && (rc = ensure_score_rows(p, error, M, mu, W))) return rc;
+    if (mode == MODE_WLOD && !wlod_fast && (rc = ensure_rld(p))) return rc;
     // continuous likelihoods have no code table: the generic kernel takes its terms from the raw matrix
     if (mode == MODE_WLOD && use_gl && p->gl_cont && !wlod_fast && (rc = ensure_gl_terms(p))) return rc;
     // transposed write-out patch only while rows + patch keep 8 workgroups (32 waves) on a CU
@@ -1615,27 +1618,49 @@ int garlic_panel_set_phase(garlic_panel *p, const uint8_t *first_copy, int64_t l
 }
 
 // reciprocals of device-resident LD weights, plain and skewed (what the wLOD kernels read)
-static int install_ld(garlic_panel *p, int32_t winsize, const double *src)
+// the skewed reciprocals D[l][j] = 1 / LD[l - j][j]: the weights SNP l has in the windows that contain it as one
+// contiguous row (tuned wLOD kernels); rows past the panel stay 0 (SKEW_FRONT doubles of zero padding in front:
+// the kernels' first steps read up to 15 elements before a row)
+static int reserve_skew(garlic_panel *p, int32_t winsize)
+{
+    int rc;
+    const size_t nskew = SKEW_FRONT + ((size_t)p->nloci + winsize + 64) * winsize;
+    if ((rc = p->d_skew.reserve(nskew))) return rc;
+    HIP_TRY(hipMemsetAsync(p->d_skew.p, 0, sizeof(double) * nskew, p->ctx->stream));
+    return GARLIC_OK;
+}
+
+// skew_done: the LD kernels have written D themselves (ld_sum_col_kernel)
+static int install_ld(garlic_panel *p, int32_t winsize, const double *src, bool skew_done = false)
 {
     int rc;
     hipStream_t s = p->ctx->stream;
-    const size_t n = (size_t)p->nloci * winsize;
-    if ((rc = p->d_rld.reserve(n))) return rc;
-    hipLaunchKernelGGL(reciprocal_kernel, dim3(2048), dim3(256), 0, s, src, p->d_rld.p, (int64_t)n);
-    // the same reciprocals, skewed: the weights SNP l has in the windows that contain it become
-    // one contiguous row (tuned wLOD kernel); rows past the panel stay 0
-    // (SKEW_FRONT doubles of zero padding in front: the kernel's first steps read up to 15
-    // elements before a row)
-    const size_t nskew = SKEW_FRONT + ((size_t)p->nloci + winsize + 64) * winsize;
-    if ((rc = p->d_skew.reserve(nskew))) return rc;
-    HIP_TRY(hipMemsetAsync(p->d_skew.p, 0, sizeof(double) * nskew, s));
-    for (int c = 0; c < p->nchr; c++)
-        hipLaunchKernelGGL(skew_reciprocal_kernel, dim3(1024), dim3(256), 0, s, src,
-                           p->d_skew.p + SKEW_FRONT, p->chr_off[c], p->chr_off[c + 1], winsize);
+    if (!skew_done) {
+        if ((rc = reserve_skew(p, winsize))) return rc;
+        for (int c = 0; c < p->nchr; c++)
+            hipLaunchKernelGGL(skew_reciprocal_kernel, dim3(1024), dim3(256), 0, s, src,
+                               p->d_skew.p + SKEW_FRONT, p->chr_off[c], p->chr_off[c + 1], winsize);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
+    p->d_rld.release();          // the plain reciprocals (generic wLOD kernel) are made from D when they are asked for
+    p->rld_valid = false;
     p->have_ld = true;
     p->ld_winsize = winsize;
+    return GARLIC_OK;
+}
+
+static int ensure_rld(garlic_panel *p)
+{
+    if (p->rld_valid) return GARLIC_OK;
+    int rc;
+    const int32_t W = p->ld_winsize;
+    if ((rc = p->d_rld.reserve((size_t)p->nloci * W))) return rc;
+    for (int c = 0; c < p->nchr; c++)
+        hipLaunchKernelGGL(unskew_kernel, dim3(1024), dim3(256), 0, p->ctx->stream, p->d_skew.p + SKEW_FRONT, p->d_rld.p,
+                           p->chr_off[c], p->chr_off[c + 1], W);
+    HIP_TRY(hipGetLastError());
+    p->rld_valid = true;
     return GARLIC_OK;
 }
 
@@ -1824,6 +1849,7 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
         sum_blocks += (nstarts + sum_b - 1) / sum_b;
     }
     if (tiled && (rc = d_sum_chrs.reserve(std::max<size_t>(sum_chrs.size(), 1)))) return done(rc);
+    if (by_snp && (rc = reserve_skew(p, winsize))) return done(rc);      // the sum kernel writes the wLOD weights as well
     for (int c = 0; c < p->nchr; c++) {
         const int64_t lo = p->chr_off[c], hi = p->chr_off[c + 1];
         if (by_snp)
@@ -1844,14 +1870,14 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
                                   : sizeof(double) * 2 * (2 * (size_t)winsize - 1 + 128 + threads);
         if (by_snp)
             hipLaunchKernelGGL(ld_sum_col_kernel, dim3((unsigned)sum_blocks), dim3(threads), lds, s, d_fwd.p,
-                               d_sum_chrs.p, (int)sum_chrs.size(), winsize, sum_b, ld);
+                               d_sum_chrs.p, (int)sum_chrs.size(), winsize, sum_b, ld, p->d_skew.p + SKEW_FRONT);
         else
             hipLaunchKernelGGL(ld_sum_tiled_kernel, dim3((unsigned)sum_blocks), dim3(threads), lds, s, d_fwd.p, d_bwd.p,
                                d_sum_chrs.p, (int)sum_chrs.size(), winsize, ld);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
-    if ((rc = install_ld(p, winsize, ld))) return done(rc);
+    if ((rc = install_ld(p, winsize, ld, by_snp))) return done(rc);
     if (where == GARLIC_HOST && ld_out) {
         e = hipMemcpyAsync(ld_out, ld, sizeof(double) * n, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);

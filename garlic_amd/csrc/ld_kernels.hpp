@@ -30,6 +30,7 @@
 #pragma once
 #include "lod_kernels.hpp"
 #include "tgls_math.hpp"
+#include "variant_kernels.hpp"   // reciprocal_x86
 
 namespace garlic {
 
@@ -479,7 +480,7 @@ __device__ __forceinline__ void ld_col_adds(double (&a)[LD_COL_B], double h, boo
 }
 __global__ void __launch_bounds__(LD_COL_MAX_THREADS)
 ld_sum_col_kernel(const double *__restrict__ C, const LdSumChr *__restrict__ chrs, int nchr, int W, int B,
-                  double *__restrict__ ld)
+                  double *__restrict__ ld, double *__restrict__ D)
 {
     // LDS: 32 doubles of slack, a ring of LD_COL_RING rows of 2W doubles, slack again: a thread's look-up
     // x = W-1 + tl - j lies in [-(B-1), W-1 + blockDim) -- outside [0, 2W-1) it lands in a neighbouring row or the
@@ -532,7 +533,13 @@ ld_sum_col_kernel(const double *__restrict__ C, const LdSumChr *__restrict__ chr
 #pragma unroll
     for (int q = 0; q < LD_COL_B; q++) {
         const int k = tl - q;
-        if (q < ns && k >= 0 && k < W) ld[(s0 + q) * W + k] = x86_nan_if_nan(acc[q]);
+        if (q < ns && k >= 0 && k < W) {
+            const double v = x86_nan_if_nan(acc[q]);
+            ld[(s0 + q) * W + k] = v;
+            // ... and the weight the tuned wLOD kernels read, D[l][k] = 1 / LD[l - k][k] (skew_reciprocal_kernel):
+            // SNP l = s0 + tl is this thread's, its row takes the thread's values back to front
+            if (D) D[(s0 + tl) * W + k] = reciprocal_x86(v);
+        }
     }
 }
 

@@ -941,6 +941,19 @@ __global__ void skew_reciprocal_kernel(const double *__restrict__ ld, double *__
     }
 }
 
+// ... and back: rld[s][j] = D[s + j][j] for the generic wLOD kernel, when it is needed (narrow windows, unaligned
+// shards); windows running over the chromosome's end are never scored
+__global__ void unskew_kernel(const double *__restrict__ D, double *__restrict__ rld, int64_t lo, int64_t hi, int W)
+{
+    const int64_t n = (hi - lo) * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t s = lo + i / W;
+        const int j = (int)(i % W);
+        rld[s * W + j] = (s + j < hi) ? D[(s + j) * W + j] : 0.0;
+    }
+}
+
 // ---- KDE feed: ordered compaction of every step-th scored window (garlic-data.cpp:2026-2069).
 // One wavefront per (chromosome, individual) row; lanes walk the sampled loci 64 at a time and
 // rank the keepers with a ballot (integer work: exact whatever the order).
