@@ -1852,7 +1852,11 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
     if (by_snp && (rc = reserve_skew(p, winsize))) return done(rc);      // the sum kernel writes the wLOD weights as well
     for (int c = 0; c < p->nchr; c++) {
         const int64_t lo = p->chr_off[c], hi = p->chr_off[c + 1];
-        if (by_snp)
+        if (by_snp && !getenv("GARLIC_LD_HR2_PLAIN"))
+            hipLaunchKernelGGL(ld_hr2_tile_kernel, dim3((unsigned)((hi - lo + LD_HR2_T - 1) / LD_HR2_T)), dim3(256),
+                               sizeof(double) * (LD_HR2_T + winsize + (size_t)LD_HR2_T * (winsize + 1)), s, pair, d_hf.p, lo, hi,
+                               winsize, d_fwd.p);
+        else if (by_snp)
             hipLaunchKernelGGL(ld_hr2_kernel<true>, dim3((unsigned)(hi - lo)), dim3(128), 0, s, pair, d_hf.p, lo, hi,
                                winsize, d_fwd.p, (double *)nullptr);
         else

@@ -299,6 +299,55 @@ ld_hr2_kernel(const int32_t *__restrict__ pair, const double *__restrict__ hf, i
     }
 }
 
+// The combined table from LDS tiles.  ld_hr2_kernel<true> writes hr2(i + d, i) into row i + d with one 8-B store
+// per pair, every lane to another row (14.5 ms of the LD call at 10M SNPs x 1250, W = 100, for 24 GB of traffic).
+// Here a workgroup owns LD_HR2_T consecutive SNPs i: the pair counts are read and the values of row i written
+// along d as before; the values for the partner rows go through an LDS tile [i][d] and leave as pieces of
+// LD_HR2_T consecutive doubles per row (C[j][W-1 - (j - i)], i ascending).  The two values of a pair share
+// HAB / total and H * H -- the same operations in the same order as two calls of hr2_from_counts.
+constexpr int LD_HR2_T = 32;
+__global__ void __launch_bounds__(256)
+ld_hr2_tile_kernel(const int32_t *__restrict__ pair, const double *__restrict__ hf, int64_t lo, int64_t hi,
+                   int W, double *__restrict__ C)
+{
+    extern __shared__ double hr2_lds[];               // hf of the SNPs i0 .. i0 + T + W - 2, then the tile [T][pitch]
+    const int pitch = W + (W & 1);                    // odd distance between the lanes' reads of the second pass
+    double *hfl = hr2_lds, *tile = hr2_lds + LD_HR2_T + W;
+    const int64_t i0 = lo + (int64_t)blockIdx.x * LD_HR2_T;
+    for (int e = threadIdx.x; e < LD_HR2_T + W - 1; e += blockDim.x) hfl[e] = (i0 + e < hi) ? hf[i0 + e] : 0.0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < LD_HR2_T * W; e += blockDim.x) {
+        const int ii = e / W, d = e - ii * W;
+        const int64_t i = i0 + ii, j = i + d;
+        if (j >= hi) continue;                        // (i <= j)
+        if (d == 0) { C[i * 2 * W + W - 1] = 1.0; continue; }
+        const int2 cnt = *reinterpret_cast<const int2 *>(pair + (i * W + d) * 2);     // {total, HAB}
+        const double HA = hfl[ii], HB = hfl[ii + d];
+        double f = 0.0, b = 0.0;
+        if (HA > 0 && HA < 1 && HB > 0 && HB < 1) {   // hr2_from_counts(HA, HB, ..) and (HB, HA, ..)
+            double HAB = (double)cnt.y;
+            HAB /= (double)cnt.x;
+            const double H = HAB - HA * HB, HH = H * H;   // (HB * HA is the same product)
+            const double vf = HH / (HA * (1 - HA) * HB * (1 - HB));
+            const double vb = HH / (HB * (1 - HB) * HA * (1 - HA));
+            f = (vf > 1) ? 1.0 : x86_nan_if_nan(vf);
+            b = (vb > 1) ? 1.0 : x86_nan_if_nan(vb);
+        }
+        C[i * 2 * W + W - 1 + d] = f;
+        tile[ii * pitch + d] = b;
+    }
+    __syncthreads();
+    // row j = i0 + 1 + jj takes tile[ii][j - i] for the SNPs i = i0 + ii of the tile with 1 <= j - i < W
+    const int nrows = LD_HR2_T + W - 2;
+    for (int e = threadIdx.x; e < nrows * LD_HR2_T; e += blockDim.x) {
+        const int jj = e / LD_HR2_T, ii = e - jj * LD_HR2_T;
+        const int d = jj + 1 - ii;
+        const int64_t j = i0 + 1 + jj;
+        if (d < 1 || d >= W || j >= hi) continue;
+        C[j * 2 * W + W - 1 - d] = tile[ii * pitch + d];
+    }
+}
+
 // LD[s][k], one workgroup per window start s (threads over k), s <= hi - W
 __global__ void __launch_bounds__(256)
 ld_sum_kernel(const double *__restrict__ fwd, const double *__restrict__ bwd, int64_t lo, int W,

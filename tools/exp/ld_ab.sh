@@ -1,6 +1,6 @@
 #!/bin/bash
-timeout -k 10 900 python3 -m pytest tests/test_gpu_ld.py tests/test_gpu_variants.py tests/test_gpu_wlod_strip.py tests/test_gpu_host_tool.py tests/test_gpu_tgls_continuous.py -x -q 2>&1 | tail -3
-for e in GARLIC_X=1 GARLIC_LD_SUM_BY_COLUMN=1; do
+timeout -k 10 900 python3 -m pytest tests/test_gpu_ld.py tests/test_gpu_host_tool.py -x -q 2>&1 | tail -3
+for e in GARLIC_X=1 GARLIC_LD_HR2_PLAIN=1; do
   env $e timeout -k 10 300 python3 tools/bench_variants.py --snps 10000000 --inds 1250 --winsize 100 --modes ld --steps 3 2>/dev/null | python3 -c "
 import json,sys
 for ln in sys.stdin:
