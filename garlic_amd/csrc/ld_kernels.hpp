@@ -43,6 +43,13 @@ __device__ __forceinline__ double x86_nan_if_nan(double v)
     return v != v ? f64_from_bits(X86_DEFAULT_NAN) : v;
 }
 
+// lane `lane` of `old` := the wave-uniform value v (v_writelane_b32)
+__device__ __forceinline__ uint32_t ld_writelane(uint32_t v, int lane, uint32_t old)
+{
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(v), "n"(lane));     // (lane: a constant after unrolling)
+    return old;
+}
+
 // One workgroup per genotype word row (16 SNPs); wave w takes the 64-individual blocks w, w+4, ...
 // planes: [blk][nloci] 64-bit masks, bit = individual of the block;  M = non-missing and in the LD
 // subsample, H = M and homozygous.  counts: [nloci][2] = {homozygous, non-missing} over every
@@ -73,25 +80,38 @@ ld_planes_kernel(const uint32_t *__restrict__ packed, int64_t nwordrows, int nbl
             if (blk >= nblk) break;
             const uint32_t word = words[u];
             const uint64_t sub = submask[blk];
+            // the 16 SNPs' masks (wave-uniform ballots) go to lanes 0 .. 15 of four registers, then leave as ONE
+            // 128-B store per plane (a store per SNP from its own lane: 32 single-lane stores per word, and the
+            // kernel ran at the pace of those -- 13.5 ms at 10M SNPs x 1250)
+            uint32_t mlo = 0, mhi = 0, hlo = 0, hhi = 0, olo = 0, ohi = 0, tlo = 0, thi = 0;
 #pragma unroll
             for (int q = 0; q < 16; q++) {
                 const uint32_t code = (word >> (2 * q)) & 3u;
                 const uint64_t m = __ballot(code != 3u);
                 const uint64_t h = __ballot(code == 0u || code == 2u);
-                const int64_t l = l0 + q;
-                if (lane == q) {
-                    hom += __popcll(h);
-                    tot += __popcll(m);
-                    if (l >= 0 && l < nloci) {
-                        planeM[(int64_t)blk * nloci + l] = m & sub;
-                        if (!PHASED) planeH[(int64_t)blk * nloci + l] = h & sub;
-                    }
-                }
+                mlo = ld_writelane((uint32_t)m, q, mlo);
+                mhi = ld_writelane((uint32_t)(m >> 32), q, mhi);
+                hlo = ld_writelane((uint32_t)h, q, hlo);
+                hhi = ld_writelane((uint32_t)(h >> 32), q, hhi);
                 if (PHASED) {
                     const uint64_t two = __ballot(code == 2u), one = __ballot(code == 1u);
-                    if (lane == q && l >= 0 && l < nloci) {
-                        planeH[(int64_t)blk * nloci + l] = two & sub;
-                        planeO[(int64_t)blk * nloci + l] = one & sub;
+                    tlo = ld_writelane((uint32_t)two, q, tlo);
+                    thi = ld_writelane((uint32_t)(two >> 32), q, thi);
+                    olo = ld_writelane((uint32_t)one, q, olo);
+                    ohi = ld_writelane((uint32_t)(one >> 32), q, ohi);
+                }
+            }
+            if (lane < 16) {
+                const uint64_t m = ((uint64_t)mhi << 32) | mlo, h = ((uint64_t)hhi << 32) | hlo;
+                hom += __popcll(h);
+                tot += __popcll(m);
+                const int64_t l = l0 + lane;
+                if (l >= 0 && l < nloci) {
+                    planeM[(int64_t)blk * nloci + l] = m & sub;
+                    if (!PHASED) planeH[(int64_t)blk * nloci + l] = h & sub;
+                    if (PHASED) {
+                        planeH[(int64_t)blk * nloci + l] = (((uint64_t)thi << 32) | tlo) & sub;
+                        planeO[(int64_t)blk * nloci + l] = (((uint64_t)ohi << 32) | olo) & sub;
                     }
                 }
             }
