@@ -247,9 +247,10 @@ def leg_ns(ctx, dev, steps):
         nsub = nind if sub is None else 500
         adds = float(nloci) * W * W
         res[name] = {"call_ms": t * 1e3, "snps_per_s": nloci / t,
-                     "roofline": {"bound": "fp64 valu adds + LDS reads (W^2 ordered adds per window start: one v_add_f64 and one "
-                                           "8-B LDS read each); the counts are AND + popcount over the subsample's bit planes",
-                                  "kernel": "ld_* (planes, pair counts, hr2, ordered sums, reciprocals) -- the whole call",
+                     "roofline": {"bound": "fp64 valu adds (W^2 ordered adds per window start, ld_sum_col_kernel: one LDS read per "
+                                           "up to 32 of them); the counts are AND + popcount over the subsample's bit planes, "
+                                           "hr2 two FP64 divisions per SNP pair",
+                                  "kernel": "ld_* (planes, pair counts, hr2 table, ordered sums + wLOD weights) -- the whole call",
                                   "achieved": adds / t / 1e12, "peak": FP64_PEAK_TFLOPS / 2, "unit": "TFLOP/s (adds only)",
                                   "frac": adds / t / 1e12 / (FP64_PEAK_TFLOPS / 2), "traffic": None,
                                   "ordered_adds_per_call": adds,

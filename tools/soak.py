@@ -71,8 +71,17 @@ def main():
             if [len(w) for w in want] != list(per_chr) or not ol.bits_equal(feed, np.concatenate(want) if want else feed):
                 fails += 1
                 print("FAIL feed", step, tag)
+            # the subset feed (--kde-subsample): drawn individuals in drawn order
+            if nind > 1:
+                idx = rng.choice(nind, size=int(rng.integers(1, min(nind, 40) + 1)), replace=False).astype(np.int32)
+                feed, per_chr = panel.lod_feed(W, err, mg, step, ind_idx=idx)
+                want = [ol.oracle_flatten_subset(x, step, idx) for x in lod]
+                checks += 1
+                if [len(w) for w in want] != list(per_chr) or not ol.bits_equal(feed, np.concatenate(want) if want else feed):
+                    fails += 1
+                    print("FAIL subset feed", step, tag)
             # LD weights, unphased and phased, with a subsample; wLOD from them
-            if W <= 64 and sum(sizes) <= 3000:
+            if W <= 130 and sum(sizes) * W <= 250000:
                 sub = None if rng.integers(0, 2) else np.sort(rng.choice(nind, size=int(rng.integers(1, nind + 1)), replace=False)).astype(np.int32)
                 ld = panel.compute_ld(W, sub_idx=sub)
                 want_ld = np.concatenate([ol.oracle_hr2_ld(c[0], W, idx=sub) for c in chroms], axis=0)
@@ -100,7 +109,16 @@ def main():
                 if not ol.bits_equal(np.ascontiguousarray(out[c]), ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, err, mg, 1e-9, 7)):
                     fails += 1
                     print("FAIL wlod", c, tag)
-            gl = [rng.choice([1e-16, 1e-3, 0.01, 0.2, 1.0], size=c[0].shape) for c in chroms]
+            if rng.integers(0, 2):       # a dictionary of likelihood values ...
+                gl = [rng.choice([1e-16, 1e-3, 0.01, 0.2, 1.0], size=c[0].shape) for c in chroms]
+            else:                        # ... or any doubles (continuous mode: lod() on the device)
+                gl = [np.where(rng.random(c[0].shape) < 0.02, rng.choice([0.0, 1.0, 1e-300, 0.5], size=c[0].shape),
+                               10.0 ** rng.uniform(-9, 0, size=c[0].shape)) for c in chroms]
+            # many short strips for the strip form of the GL-weighted kernel, now and then
+            if rng.integers(0, 2):
+                os.environ["GARLIC_WLOD_STRIP_GROUPS"] = str(int(rng.integers(1, 12)))
+            else:
+                os.environ.pop("GARLIC_WLOD_STRIP_GROUPS", None)
             panel.set_gl(np.concatenate(gl, axis=0))
             out = panel.lod_windows(W, err, mg, use_gl=True, pitch_align=32)
             for c, (g, f, p, cs, ce) in enumerate(chroms):
