@@ -172,7 +172,7 @@ def leg_c3(ctx, dev, steps):
     spec = synth.PanelSpec(nloci, seed=20260101 + 2, max_gap=MAX_GAP)
     panel, _ = load_panel(ctx, spec, nind, dev)
     base, pitch, total = panel.out_layout(32, nind)
-    out = torch.empty(total, dtype=torch.float64, device=dev)
+    out = ctx.alloc_scores(total)
     torch.cuda.synchronize()
     res = {"workload": "synthetic 5M SNPs x 5k inds, --winsize-multi 50 100 200 300 (config 3), one resident panel",
            "snps": nloci, "inds": nind, "winsizes": sizes}
@@ -189,7 +189,7 @@ def leg_c3(ctx, dev, steps):
         "sliding_windows_per_s": 4 * nloci * nind / (t_all * 1e-3),
         "roofline": hbm_roofline("lod_chain_kernel", 4 * BYTES_LOD * nloci * nind, k_all,
                                  note="the four launches of one --winsize-multi call together")}
-    del out
+    out.free()
     torch.cuda.empty_cache()
     for W in sizes:
         panel.lod_feed(W, ERROR, MAX_GAP, W, copy=False)             # plan + scratch
@@ -221,7 +221,7 @@ def leg_ns(ctx, dev, steps):
     spec = synth.PanelSpec(nloci, seed=20260101 + 3, max_gap=MAX_GAP)
     panel, _ = load_panel(ctx, spec, nind, dev, gq=True)
     base, pitch, total = panel.out_layout(32, nind)
-    out = torch.empty(total, dtype=torch.float64, device=dev)
+    out = ctx.alloc_scores(total)
     torch.cuda.synchronize()
     win = nloci * nind
     res = {"workload": "synthetic 10M SNPs x 1250 inds (one GPU's shard of the 10M x 10k panel of configs 4 and 5), --winsize 100",
@@ -265,9 +265,9 @@ def leg_ns(ctx, dev, steps):
                                                           note="term matrix built once per panel (gl_terms_kernel), not in the pass"))
     dt, k = timed_passes(ctx, lambda: panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU, use_gl=True),
                          steps, 1, torch.cuda.synchronize)
-    res["wlod_gl"] = dict(rate(k, dt), roofline=fp64_roofline("wlod_tile_glring_kernel", win, W, k))
+    res["wlod_gl"] = dict(rate(k, dt), roofline=fp64_roofline("wlod_strip_gl_kernel", win, W, k))
     panel.close()
-    del out
+    out.free()
     torch.cuda.empty_cache()
     return res
 
@@ -320,8 +320,9 @@ def main():
     ap.add_argument("--inds", type=int, default=0, help="individuals per GPU (default: workload's)")
     ap.add_argument("--cpu-inds", type=int, default=512, help="individuals in the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--out-candidates", type=int, default=4,
-                    help="score buffers to try for the timed passes (placement in VRAM changes the kernel time)")
+    ap.add_argument("--out-candidates", type=int, default=3,
+                    help="plain score buffers timed for comparison with the library's allocation (placement in VRAM "
+                         "changes the kernel time)")
     ap.add_argument("--also", default="auto", help="auto | none | comma list of c3,ns,e2e (N = 1 only)")
     ap.add_argument("--also-budget-s", type=float, default=330.0,
                     help="no further `also` leg is started once the run has taken this long")
@@ -365,33 +366,37 @@ def main():
 
     PITCH_ALIGN = 32
     base, pitch, total = panel.out_layout(PITCH_ALIGN, nind)
-    # Where the driver puts the score buffer in VRAM changes the chain kernel's time by up to 18 % (same
+    # Where a plain allocation puts the score buffer in VRAM changes the chain kernel's time by up to 18 % (same
     # code, same virtual layout, same box: 1.36 .. 1.64 ms at C2 -- DESIGN.md section 4, "placement").  A plain
     # streaming fill runs equally fast on every allocation; what differs is how the kernel's few HBM reads mix
-    # with its write stream.  A caller that keeps its score buffer (GARLIC's sweep over window sizes does) can
-    # pick a good one once: while they fit, a few candidate buffers are allocated side by side, each is timed
-    # on three passes, the fastest is kept and the others are freed.  Every candidate's time is reported.
+    # with its write stream.  The library's own allocator for score matrices (garlic_device_alloc: a virtual
+    # range backed by physical chunks of its own) has been in the fast mode every time it was measured; the timed
+    # passes write into a buffer from there.  For the record a few plain (torch / hipMalloc) buffers are timed on
+    # three passes each beforehand and reported next to it.
     placement = None
-    n_cand = 1 if (args.out_candidates <= 1 or total * 8 * args.out_candidates > (96 << 30) or args.mode != "lod") else args.out_candidates
-    if n_cand > 1:
+    out_buf = ctx.alloc_scores(total)
+    out = out_buf.tensor()
+    n_cand = 0 if (args.out_candidates < 1 or total * 8 * (args.out_candidates + 1) > (96 << 30) or args.mode != "lod") else args.out_candidates
+
+    def three_passes(ptr):
+        for _ in range(2):
+            panel.lod_windows_device(ptr, W, ERROR, MAX_GAP, pitch_align=PITCH_ALIGN)
+        ctx.synchronize()
+        for _ in range(3):
+            panel.lod_windows_device(ptr, W, ERROR, MAX_GAP, pitch_align=PITCH_ALIGN)
+        return float(np.mean(ctx.recent_kernel_ms(3)))
+
+    if n_cand > 0:
         cands = [torch.empty(total, dtype=torch.float64, device=dev) for _ in range(n_cand)]
         torch.cuda.synchronize()
-        times = []
-        for c in cands:
-            for _ in range(2):
-                panel.lod_windows_device(c.data_ptr(), W, ERROR, MAX_GAP, pitch_align=PITCH_ALIGN)
-            ctx.synchronize()
-            for _ in range(3):
-                panel.lod_windows_device(c.data_ptr(), W, ERROR, MAX_GAP, pitch_align=PITCH_ALIGN)
-            times.append(float(np.mean(ctx.recent_kernel_ms(3))))
-        best = int(np.argmin(times))
-        out = cands[best]
-        placement = {"candidates_kernel_ms": times, "kept": best,
-                     "note": "score buffers allocated side by side, 3 timed passes each, fastest kept"}
-        del cands, c
+        times = [three_passes(c.data_ptr()) for c in cands]
+        placement = {"allocator": "garlic_device_alloc (HIP virtual memory management, 1-GB physical chunks)",
+                     "library_buffer_kernel_ms": three_passes(out.data_ptr()),
+                     "candidates_kernel_ms": times,
+                     "note": "candidates: plain torch (hipMalloc) buffers allocated side by side, 3 timed passes each, "
+                             "for comparison only -- the timed region writes into the library's buffer"}
+        del cands
         torch.cuda.empty_cache()
-    else:
-        out = torch.empty(total, dtype=torch.float64, device=dev)
     setup = {}
     if args.mode == "wlod":
         # LD weights (calcLDData) from --ld-subsample 500 of the WHOLE panel: every rank counts over its own
@@ -508,6 +513,7 @@ def main():
             res["cpu_baseline"] = None
     panel.close()
     del out, geno_sample
+    out_buf.free()
     torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and args.also != "none":

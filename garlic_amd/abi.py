@@ -29,6 +29,7 @@ SYMBOLS = [
     "garlic_panel_release_scratch",
     "garlic_lod_feed", "garlic_ctx_set_async",
     "garlic_recent_kernel_ms", "garlic_panel_tgls_mode", "garlic_lod_feed_subset",
+    "garlic_device_alloc", "garlic_device_free",
 ]
 
 
@@ -51,7 +52,7 @@ _i64p = C.POINTER(C.c_int64)
 _f64p = C.POINTER(C.c_double)
 
 
-ABI_VERSION = 3   # GARLIC_HIP_ABI_VERSION of include/garlic_hip.h these bindings were written against
+ABI_VERSION = 4   # GARLIC_HIP_ABI_VERSION of include/garlic_hip.h these bindings were written against
 
 
 def lib():
@@ -72,6 +73,8 @@ def lib():
     L.garlic_ctx_destroy.argtypes = [_vp]
     L.garlic_ctx_synchronize.argtypes = [_vp]
     L.garlic_ctx_set_async.argtypes = [_vp, C.c_int32]
+    L.garlic_device_alloc.argtypes = [_vp, C.c_int64, C.POINTER(_vp)]
+    L.garlic_device_free.argtypes = [_vp, _vp]
     L.garlic_recent_kernel_ms.argtypes = [_vp, C.POINTER(C.c_float), C.c_int32, _i32p]
     L.garlic_panel_create.argtypes = [_vp, C.c_int32, _i32p, C.c_int32, C.POINTER(_vp)]
     L.garlic_panel_destroy.argtypes = [_vp]
@@ -142,6 +145,10 @@ class Context:
         """device-output calls that repeat the previous call's arguments only enqueue (see garlic_hip.h)"""
         check(lib().garlic_ctx_set_async(self.handle, int(on)))
 
+    def alloc_scores(self, n_doubles):
+        """device memory for a score matrix through garlic_device_alloc (reproducible placement, see garlic_hip.h)"""
+        return DeviceBuffer(self, int(n_doubles) * 8)
+
     def close(self):
         if self.handle:
             lib().garlic_ctx_destroy(self.handle)
@@ -152,6 +159,39 @@ class Context:
 
     def __exit__(self, *exc):
         self.close()
+
+
+class DeviceBuffer:
+    """garlic_device_alloc / garlic_device_free; `.ptr` for the device-output calls, `.tensor()` to look at it"""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = _vp()
+        check(lib().garlic_device_alloc(ctx.handle, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def data_ptr(self):
+        return self.ptr
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes // 8,), "typestr": "<f8", "data": (self.ptr, False), "version": 2, "strides": None}
+
+    def tensor(self):
+        """a float64 torch tensor over the same memory (valid while this object lives)"""
+        import torch
+        return torch.as_tensor(self, device=f"cuda:{self.ctx.device}")
+
+    def free(self):
+        if self.ptr:
+            check(lib().garlic_device_free(self.ctx.handle, _vp(self.ptr)))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Panel:

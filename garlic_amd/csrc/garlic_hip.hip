@@ -13,6 +13,7 @@
 #include "wlod_strip_kernel.hpp"
 
 #include <algorithm>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -2188,6 +2189,95 @@ int garlic_recent_kernel_ms(garlic_ctx *ctx, float *ms, int32_t n, int32_t *got)
         (void)hipEventElapsedTime(&ms[k], ctx->hist0[call % garlic_ctx::HIST], ctx->hist1[call % garlic_ctx::HIST]);
     }
     *got = (int32_t)have;
+    return GARLIC_OK;
+}
+
+// Score buffers.  Where a plain hipMalloc puts 8 GB of scores decides between two speeds of lod_chain_kernel at
+// 1M SNPs x 1000 individuals (1.36 and 1.62 ms: DESIGN.md section 4, "placement"); a virtual range backed by
+// physical chunks of its own (HIP virtual memory management, 1 GB each) was in the fast mode every time (33 of
+// 33 allocations on two boxes, a third of the plain ones on the same boxes slow).  Falls back to hipMalloc where
+// the driver has no virtual memory management.
+struct ScoreAlloc { void *ptr; size_t size; std::vector<hipMemGenericAllocationHandle_t> handles; };
+static std::mutex g_score_mutex;
+static std::vector<ScoreAlloc> g_score_allocs;
+
+// keep_range: the virtual range stays reserved, so that no later allocation gets the same addresses.  Measured on
+// ROCm 7.2 / MI355X: a range that is unmapped, freed and handed out again by hipMemAddressReserve with new
+// physical memory behind it loses part of the first kernel's writes (stale translations) -- fresh addresses do
+// not.  An unmapped reservation costs address space only.
+static void release_score_alloc(ScoreAlloc &a, size_t mapped, bool keep_range)
+{
+    if (mapped) (void)hipMemUnmap(a.ptr, mapped);
+    for (auto h : a.handles) (void)hipMemRelease(h);
+    if (a.ptr && !keep_range) (void)hipMemAddressFree(a.ptr, a.size);
+}
+
+int garlic_device_alloc(garlic_ctx *ctx, int64_t bytes, void **out)
+{
+    if (!ctx || !out || bytes < 1) return fail(GARLIC_ERR_INVALID, "context, size and result pointer are required");
+    int rc;
+    if ((rc = set_device(ctx))) return rc;
+    *out = nullptr;
+    int vmm = 0;
+    (void)hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, ctx->device);
+    if (vmm && !getenv("GARLIC_ALLOC_PLAIN")) {
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = ctx->device;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran) {
+            const size_t chunk = (((size_t)1 << 30) + gran - 1) / gran * gran;
+            const size_t size = ((size_t)bytes + gran - 1) / gran * gran;
+            ScoreAlloc a{nullptr, size, {}};
+            size_t mapped = 0;
+            bool ok = hipMemAddressReserve(&a.ptr, size, 0, nullptr, 0) == hipSuccess;
+            for (size_t off = 0; ok && off < size; off += chunk) {
+                const size_t n = std::min(chunk, size - off);
+                hipMemGenericAllocationHandle_t h;
+                ok = hipMemCreate(&h, n, &prop, 0) == hipSuccess;
+                if (!ok) break;
+                a.handles.push_back(h);
+                ok = hipMemMap((char *)a.ptr + off, n, 0, h, 0) == hipSuccess;
+                if (ok) mapped = off + n;
+            }
+            if (ok) {
+                hipMemAccessDesc acc{};
+                acc.location = prop.location;
+                acc.flags = hipMemAccessFlagsProtReadWrite;
+                ok = hipMemSetAccess(a.ptr, size, &acc, 1) == hipSuccess;
+            }
+            if (ok) {
+                *out = a.ptr;
+                std::lock_guard<std::mutex> lock(g_score_mutex);
+                g_score_allocs.push_back(std::move(a));
+                return GARLIC_OK;
+            }
+            release_score_alloc(a, mapped, mapped != 0);
+            (void)hipGetLastError();
+        }
+    }
+    HIP_TRY(hipMalloc(out, (size_t)bytes));
+    return GARLIC_OK;
+}
+
+int garlic_device_free(garlic_ctx *ctx, void *ptr)
+{
+    if (!ctx) return fail(GARLIC_ERR_INVALID, "context is required");
+    if (!ptr) return GARLIC_OK;
+    int rc;
+    if ((rc = set_device(ctx))) return rc;
+    {
+        std::lock_guard<std::mutex> lock(g_score_mutex);
+        for (size_t k = 0; k < g_score_allocs.size(); k++)
+            if (g_score_allocs[k].ptr == ptr) {
+                HIP_TRY(hipDeviceSynchronize());
+                release_score_alloc(g_score_allocs[k], g_score_allocs[k].size, true);
+                g_score_allocs.erase(g_score_allocs.begin() + k);
+                return GARLIC_OK;
+            }
+    }
+    HIP_TRY(hipFree(ptr));
     return GARLIC_OK;
 }
 

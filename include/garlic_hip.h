@@ -40,7 +40,7 @@ extern "C" {
 /* 2: the LD functions take `phased`; garlic_panel_set_phase
  * 3: likelihoods may be continuous (no 256-value limit), garlic_panel_tgls_mode; an LD subsample may be
  *    empty (sub_idx != NULL, n_sub = 0); garlic_lod_feed_subset */
-#define GARLIC_HIP_ABI_VERSION 3
+#define GARLIC_HIP_ABI_VERSION 4
 
 #define GARLIC_OK 0
 #define GARLIC_ERR_INVALID 1  /* bad argument (e.g. winsize <= 1: src/garlic-cli.cpp:433-442) */
@@ -76,6 +76,16 @@ int garlic_ctx_synchronize(garlic_ctx *ctx);
  * garlic_last_call_stats, or any synchronous call) waits.  For callers that issue passes back to
  * back (benchmarks, pipelines that consume the scores on the same stream). */
 int garlic_ctx_set_async(garlic_ctx *ctx, int32_t on);
+
+/* Device memory for score matrices (the `out` of garlic_lod_windows & co. with GARLIC_DEVICE).  Any device
+ * pointer works as `out`; one from here additionally makes the unweighted kernel's speed reproducible: where a
+ * plain hipMalloc places 8 GB of scores decides between 1.36 and 1.62 ms per pass at 1M SNPs x 1000 individuals
+ * (a property of the allocation), a virtual range backed by its own physical chunks (HIP
+ * virtual memory management) was in the fast mode every time it was measured.  GARLIC itself has no counterpart
+ * (WinData rows are host memory, garlic-data.cpp:1690); keep the buffer across window sizes as GARLIC keeps its
+ * WinData.  Falls back to hipMalloc when the driver offers no virtual memory management. */
+int garlic_device_alloc(garlic_ctx *ctx, int64_t bytes, void **out);
+int garlic_device_free(garlic_ctx *ctx, void *ptr);
 /* HIP-event durations (ms) of the dominant kernel of the context's most recent window-score calls,
  * oldest first, at most 32: lets a caller time asynchronous passes without waiting for each.  Waits
  * for the stream.  *got = number of values written (<= n). */

@@ -200,11 +200,12 @@ def test_5M_by_5k_four_window_sizes(gpu_ctx):
     dev = torch.device("cuda", 0)
     sample = [0, 63, 64, 1342, 1344, 2559, 4991, 4992, 4999]     # row 1343 of chromosome 1's block starts beyond 4 GB
     panel, geno_s, _ = load_panel(gpu_ctx, spec, nind, sample)
-    out = None
+    out = buf = None
     try:
         base, pitch, total = panel.out_layout(32, nind)
         assert max(int(p) for p in pitch) * 8 * 1344 > (1 << 32)
-        out = torch.empty(total, dtype=torch.float64, device=dev)
+        buf = gpu_ctx.alloc_scores(total)          # 200 GB from the library's allocator (garlic_device_alloc)
+        out = buf.tensor()
         for W in (50, 100, 200, 300):
             out.fill_(float("nan"))
             torch.cuda.synchronize()
@@ -225,4 +226,6 @@ def test_5M_by_5k_four_window_sizes(gpu_ctx):
     finally:
         panel.close()
         del out
+        if buf is not None:
+            buf.free()
         torch.cuda.empty_cache()

@@ -11,7 +11,7 @@ INDS=${3:-1250}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
-rm -rf $OUT/${TAG}_variants $OUT/${TAG}_tgls_fetch $OUT/${TAG}_tgls_write
+rm -rf $OUT/${TAG}_variants $OUT/${TAG}_tgls_fetch $OUT/${TAG}_tgls_write $OUT/${TAG}_wlodgl_fetch
 ARGS="tools/bench_variants.py --snps $SNPS --inds $INDS --modes ld,feed,lod,tgls,wlod,wlodgl --steps 3"
 python3 $ARGS > $OUT/${TAG}_variants_plain.json 2> $OUT/${TAG}_variants.err
 echo "plain done"
@@ -20,5 +20,7 @@ echo "trace done"
 TG="tools/bench_variants.py --snps $SNPS --inds $INDS --modes tgls --steps 3"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_tgls_fetch -- python3 $TG > $OUT/${TAG}_tgls_fetch.json 2>> $OUT/${TAG}_variants.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_tgls_write -- python3 $TG > $OUT/${TAG}_tgls_write.json 2>> $OUT/${TAG}_variants.err
+WG="tools/bench_variants.py --snps $SNPS --inds $INDS --modes wlodgl --steps 3"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_wlodgl_fetch -- python3 $WG > $OUT/${TAG}_wlodgl_fetch.json 2>> $OUT/${TAG}_variants.err
 echo "pmc done"
 find $OUT/${TAG}_variants -name "*_kernel_stats.csv"

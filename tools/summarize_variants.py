@@ -67,6 +67,27 @@ def main():
     }
     with open(os.path.join(PROF, f"{TAG}_tgls_pmc_traffic.json"), "w") as f:
         json.dump(doc, f, indent=1)
+    # GL-weighted wLOD, strip form: the term rows enter the CUs once per strip
+    kern2 = "wlod_strip_gl_kernel"
+    if glob.glob(os.path.join(OUT, f"{TAG}_wlodgl_fetch/**/*_counter_collection.csv"), recursive=True):
+        f2, n3 = pmc(f"{TAG}_wlodgl_fetch", "FETCH_SIZE", kern2)
+        wg = [l for l in plain if l["mode"] == "wlodgl"][0]
+        tr2 = [r for r in rows if kern2 in r["Name"]][0]
+        doc2 = {
+            "command": "rocprofv3 --pmc FETCH_SIZE -- python3 tools/bench_variants.py --modes wlodgl (tools/profile_variants.sh)",
+            "workload": shape + ", --weighted with per-genotype likelihoods", "kernel": "garlic::" + kern2,
+            "FETCH_SIZE_KiB_per_launch": f2, "launches": n3,
+            "correction": "gfx950: FETCH_SIZE counts 128-B read requests as 64 B -> doubled",
+            "fetch_bytes_per_launch": 2.0 * f2 * 1024.0,
+            "terms_bytes_once": 8.0 * win, "weights_bytes_once": 8.0 * wg["snps"] * wg["winsize"],
+            "tile_form_row_bytes_into_cus": 8.0 * win * (wg["winsize"] + 15) / 16.0,
+            "fetch_over_terms_once": 2.0 * f2 * 1024.0 / (8.0 * win),
+            "kernel_trace_avg_ns": float(tr2["AverageNs"]), "bench_kernel_ms_hip_events_plain_run": wg["kernel_ms"],
+            "roofline_frac_plain_run": wg["roofline"]["frac"],
+        }
+        with open(os.path.join(PROF, f"{TAG}_wlodgl_pmc_traffic.json"), "w") as f:
+            json.dump(doc2, f, indent=1)
+        print(f"GL-weighted wLOD strip kernel: trace {float(tr2['AverageNs']) / 1e6:.2f} ms, fetch x2 = {doc2['fetch_over_terms_once']:.3f} x terms once")
     print(f"wrote {os.path.normpath(dst)}: {len(rows)} kernels; TGLS ring kernel: trace {float(trace['AverageNs']) / 1e6:.2f} ms, "
           f"fetch x2 = {doc['fetch_over_terms_once']:.3f} x terms once, HBM {doc['hbm_bytes_per_launch'] / 1e9:.1f} GB "
           f"vs algorithmic {doc['algorithmic_bytes_per_launch'] / 1e9:.1f} GB")
