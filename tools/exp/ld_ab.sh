@@ -1,8 +1,12 @@
 #!/bin/bash
-timeout -k 10 900 python3 -m pytest tests/test_gpu_ld.py tests/test_gpu_host_tool.py -x -q 2>&1 | tail -3
-for e in GARLIC_X=1 GARLIC_LD_HR2_PLAIN=1; do
-  env $e timeout -k 10 300 python3 tools/bench_variants.py --snps 10000000 --inds 1250 --winsize 100 --modes ld --steps 3 2>/dev/null | python3 -c "
-import json,sys
-for ln in sys.stdin:
-    d=json.loads(ln); print('$e', {k:(round(v,2) if isinstance(v,float) else v) for k,v in d.items() if k!='roofline'})"
-done
+timeout -k 10 900 python3 -m pytest tests/test_gpu_ld.py -x -q 2>&1 | tail -2
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ldprof3 -o ld -- python3 tools/bench_variants.py --snps 10000000 --inds 1250 --winsize 100 --modes ld --steps 3 > gpurun_out/ldprof3.log 2>&1
+python3 - <<'PY'
+import csv,glob
+f=sorted(glob.glob('gpurun_out/ldprof3/**/*kernel_stats.csv', recursive=True))[-1]
+for r in csv.DictReader(open(f)):
+    if 'garlic::ld' in r['Name'] or 'rocclr' in r['Name']:
+        print(r['Name'][:50], r['Calls'], round(float(r['TotalDurationNs'])/1e6/4,2))
+PY
+grep call_ms gpurun_out/ldprof3.log | head -2 | cut -c1-120
