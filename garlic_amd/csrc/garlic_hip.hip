@@ -798,8 +798,9 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // generic kernel
     const bool exact = mode != MODE_WLOD && lod_exact_needed(p, mode, W);
     if (exact && thin_step > 0) return fail(GARLIC_ERR_INVALID, "internal: thinned output with the exact chain");
-    const bool wlod_shape_ok = mode == MODE_WLOD && W >= WLOD_R && W + 64 <= GPAD_BACK &&
-                               !getenv("GARLIC_WLOD_GENERIC");
+    const bool wlod_shape_ok = mode == MODE_WLOD && W + 64 <= GPAD_BACK && !getenv("GARLIC_WLOD_GENERIC") &&
+                               (W >= WLOD_R || !getenv("GARLIC_WLOD_SMALL_GENERIC"));
+    const bool wlod_small = W < WLOD_R;      // narrower than a window group: wlod_group_small (compiler-scheduled)
     if (wlod_shape_ok && use_gl && (rc = ensure_gl_terms(p, true, M, mu))) return rc;
     const bool wlod_gl = wlod_shape_ok && use_gl && p->glterms_valid && p->glterms_scaled;   // scores from the term matrix
     bool wlod_fast = (wlod_shape_ok && !use_gl) || wlod_gl;                 // tile kernel, either variant
@@ -814,7 +815,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     const bool wlod_use_patch = wlod_rows + 16 + wlod_patch <= 160 * 1024 / 8;
     // term-matrix variant: the hand-scheduled loop stages the block's term rows through one LDS ring
     // per wave; it needs a block-aligned shard (a wave's 64 lanes = one block of the matrix)
-    const bool wlod_gl_ring = wlod_gl && (ind_begin & (WAVE - 1)) == 0 && !getenv("GARLIC_WLOD_GL_NO_RING");
+    const bool wlod_gl_ring = wlod_gl && !wlod_small && (ind_begin & (WAVE - 1)) == 0 && !getenv("GARLIC_WLOD_GL_NO_RING");
     const bool ring_patch = !getenv("GARLIC_WLOD_GL_NO_PATCH");
     // ... and with windows narrow enough for WS_MAX_WAVES compute waves per workgroup the strip form: the
     // blocks' term rows enter a CU once per strip (wlod_strip_kernel.hpp)
@@ -961,7 +962,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     if (wlod_fast) {
         // plain --error scores: two blocks per wave (every scalar-loaded weight used twice); the per-genotype
         // variants keep one block per wave (their term rows, not the weights, set their pace)
-        const bool two_blocks = !wlod_gl && !getenv("GARLIC_WLOD_ONE_BLOCK");
+        const bool two_blocks = !wlod_gl && !wlod_small && !getenv("GARLIC_WLOD_ONE_BLOCK");
         const int per_wg = two_blocks ? WLOD2_BLOCKS : WLOD_WAVES;
         const int nquad = (nblk + per_wg - 1) / per_wg;
         WlodArgs a{p->d_valid.p, p->d_chrs.p, p->d_tiles.p, p->nwordrows, p->nchr, ind_begin, ind_count, W, nquad,
@@ -981,7 +982,14 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                                                   : (const void *)wlod_tile_kernel<WLOD_R, false>);
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlod_lds));
         }
-        if (wlod_gl_strip) {
+        if (wlod_small) {
+            const void *fn = wlod_gl ? (aligned16 ? (const void *)wlod_tile_small_gl_kernel<WLOD_R, true>
+                                                  : (const void *)wlod_tile_small_gl_kernel<WLOD_R, false>)
+                                     : (aligned16 ? (const void *)wlod_tile_small_kernel<WLOD_R, true>
+                                                  : (const void *)wlod_tile_small_kernel<WLOD_R, false>);
+            void *kargs[] = {(void *)&a_packed, (void *)&a_wtab, (void *)&a_skew, (void *)&d_out, (void *)&a};
+            HIP_TRY(hipLaunchKernel(fn, dim3(wl_grid), wl_block, kargs, wlod_lds, ctx->stream));
+        } else if (wlod_gl_strip) {
             const int n_pairs = (nblk + 1) / 2;
             WlodStripArgs sa{p->d_valid.p, p->d_chrs.p, p->d_strips.p, p->d_glterms.p, a_skew, d_out,
                              (int64_t)(GOFF + p->nloci + GPAD_BACK), ind_begin, ind_count, W, strip_waves, n_pairs,

@@ -688,6 +688,52 @@ __device__ __forceinline__ void wlod_group_scores(const double *tcol, int64_t G,
     }
 }
 
+// Windows narrower than the group (W < R: GARLIC's default --winsize is 10): no step has all R windows active,
+// so the hand-scheduled loops above (R-1 steps of windows entering, W-(R-1) full steps, R-1 leaving) do not apply.
+// Step i (SNP s+i, i = 0 .. W+R-2) serves the windows r with 0 <= i-r < W, weight D[s+i][i-r]; with W a template
+// argument everything is unrolled and the compiler schedules it.  These shapes are bound by their output (8 B
+// per window against 2 W flops), not by the loop; the generic one-wave-per-run kernel they replace took 151 ms
+// for 2M SNPs x 1280 individuals at W = 15, the tile kernel 7.5 ms at W = 16.
+template <int R, int WC, class ScoreFn>
+__device__ __forceinline__ void wlod_group_small_w(ScoreFn score, const double *Ds, double (&acc)[R])
+{
+    const const_f64_ptr Dg = (const_f64_ptr)(uintptr_t)Ds;      // wave-uniform weights: scalar loads
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = 0.0;
+    double sc[WC + R - 1];
+#pragma unroll
+    for (int i = 0; i < WC + R - 1; i++) sc[i] = score(i);
+#pragma unroll
+    for (int i = 0; i < WC + R - 1; i++) {
+        const const_f64_ptr Dr = Dg + (int64_t)i * WC;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (i - r >= 0 && i - r < WC) acc[r] += sc[i] * Dr[i - r];      // ascending j = i - r per window, from +0.0
+    }
+}
+
+template <int R, class ScoreFn>
+__device__ __forceinline__ void wlod_group_small(ScoreFn score, const double *Ds, int W, double (&acc)[R])
+{
+    static_assert(R == 16, "one case per window size below the group size");
+    switch (W) {
+    case 2: wlod_group_small_w<R, 2>(score, Ds, acc); break;
+    case 3: wlod_group_small_w<R, 3>(score, Ds, acc); break;
+    case 4: wlod_group_small_w<R, 4>(score, Ds, acc); break;
+    case 5: wlod_group_small_w<R, 5>(score, Ds, acc); break;
+    case 6: wlod_group_small_w<R, 6>(score, Ds, acc); break;
+    case 7: wlod_group_small_w<R, 7>(score, Ds, acc); break;
+    case 8: wlod_group_small_w<R, 8>(score, Ds, acc); break;
+    case 9: wlod_group_small_w<R, 9>(score, Ds, acc); break;
+    case 10: wlod_group_small_w<R, 10>(score, Ds, acc); break;
+    case 11: wlod_group_small_w<R, 11>(score, Ds, acc); break;
+    case 12: wlod_group_small_w<R, 12>(score, Ds, acc); break;
+    case 13: wlod_group_small_w<R, 13>(score, Ds, acc); break;
+    case 14: wlod_group_small_w<R, 14>(score, Ds, acc); break;
+    default: wlod_group_small_w<R, 15>(score, Ds, acc); break;
+    }
+}
+
 // Write-out of one group of R windows x 64 individuals (accumulators in registers): windows without a
 // score become MISSING (garlic-roh.cpp:232); then 128 contiguous bytes per row and instruction,
 // non-temporal, transposed through ONE LDS patch [64][WT_PITCH] per workgroup that its waves take turns
@@ -748,7 +794,7 @@ __device__ __forceinline__ void wlod_write_group(double (&acc)[R], uint32_t gm, 
     }
 }
 
-template <int R, bool ALIGNED16, bool FROM_SCORES, bool GL_RING = false>
+template <int R, bool ALIGNED16, bool FROM_SCORES, bool GL_RING = false, bool SMALLW = false>
 __device__ __forceinline__ void
 wlod_tile_body(const uint32_t *__restrict__ packed,
                const double *__restrict__ wtab,   // [GOFF + nloci + pad][4]; FROM_SCORES: term matrix [blk][rows][64]
@@ -796,7 +842,20 @@ wlod_tile_body(const uint32_t *__restrict__ packed,
         double acc[R];
         const uint32_t gm = (vm >> (grp * R)) & ((1u << R) - 1u);
         if (gm != 0) {
-            if (GL_RING) {
+            if (SMALLW) {          // W < R
+                const double *Dp = D + (c.loc_base + s0 + grp * R) * (int64_t)W;
+                const int64_t G = G0 + grp * R;
+                if (FROM_SCORES) {
+                    const double *tp = wtab + ((col >> 6) * p.score_rows + G) * WAVE + (col & 63);
+                    wlod_group_small<R>([&](int i) -> double { return tp[i * WAVE]; }, Dp, W, acc);
+                } else {
+                    const double *rw = rows + grp * R * 4;
+                    wlod_group_small<R>([&](int i) -> double {
+                        const uint32_t word = gcol[((G + i) >> 4) * WAVE];
+                        return rw[i * 4 + ((word >> (2 * (uint32_t)((G + i) & 15))) & 3u)];
+                    }, Dp, W, acc);
+                }
+            } else if (GL_RING) {
                 // block-aligned shard (host-checked): the wave's 64 lanes are one block of the matrix
                 const int64_t blk = ((int64_t)p.ind_begin + ind0) >> 6;
                 const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)dyn +
@@ -823,6 +882,23 @@ wlod_tile_kernel(const uint32_t *__restrict__ packed, const double *__restrict__
                  const double *__restrict__ D, double *__restrict__ out, WlodArgs p)
 {
     wlod_tile_body<R, ALIGNED16, false>(packed, wtab, D, out, p);
+}
+
+// windows narrower than the group (wlod_group_small): plain scores / term matrix
+template <int R, bool ALIGNED16>
+__global__ void __launch_bounds__(WLOD_WAVES * WAVE)
+wlod_tile_small_kernel(const uint32_t *__restrict__ packed, const double *__restrict__ wtab,
+                       const double *__restrict__ D, double *__restrict__ out, WlodArgs p)
+{
+    wlod_tile_body<R, ALIGNED16, false, false, true>(packed, wtab, D, out, p);
+}
+
+template <int R, bool ALIGNED16>
+__global__ void __launch_bounds__(WLOD_WAVES * WAVE)
+wlod_tile_small_gl_kernel(const uint32_t *__restrict__ packed, const double *__restrict__ terms,
+                          const double *__restrict__ D, double *__restrict__ out, WlodArgs p)
+{
+    wlod_tile_body<R, ALIGNED16, true, false, true>(packed, terms, D, out, p);
 }
 
 // Two 64-individual blocks per wave (GARLIC_WLOD2_LOOP_ASM): the 16 weights of a step multiply both blocks'

@@ -116,9 +116,10 @@ def test_wlod_wide_window(gpu_ctx):
         assert all((o == ol.MISSING).all() for o in out)
 
 
-@pytest.mark.parametrize("W", [15, 16, 17, 31, 100, 250])
+@pytest.mark.parametrize("W", [2, 3, 7, 10, 15, 16, 17, 31, 100, 250])
 def test_wlod_tile_kernel_shapes(gpu_ctx, W):
-    """tuned wLOD kernel (W >= 16; 15 takes the generic one): chromosomes shorter than / equal to /
+    """tuned wLOD kernels (W >= 16 the hand-scheduled loops, narrower windows -- GARLIC's default is 10 -- the
+    unrolled wlod_group_small of the same tile kernel): chromosomes shorter than / equal to /
     just above the window, gaps and centromeres inside tiles, ragged individual counts, unaligned
     sub-ranges, dense and padded output layouts"""
     rng = np.random.default_rng(900 + W)
