@@ -1826,10 +1826,11 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
         loc = d_loc.p; pair = d_pair.p;
     }
     // ordered sums: LDS-tiled kernel (one thread per column of the LD row) unless the window is too wide
-    const bool tiled = winsize <= LD_SUM_MAX_W && !getenv("GARLIC_LD_SUM_L2");
-    // ... thread = SNP of the window, accumulators = window starts (ld_sum_col_kernel) unless switched off
+    // ... thread = SNP of the window, accumulators = window starts (ld_sum_col_kernel: 32 < W <= 512) unless switched off
     const int col_threads = (winsize + 16 + WAVE - 1) / WAVE * WAVE;
-    const bool by_snp = tiled && winsize > LD_COL_B && col_threads <= LD_COL_MAX_THREADS && !getenv("GARLIC_LD_SUM_BY_COLUMN");
+    const bool by_snp = winsize > LD_COL_B && winsize <= 512 && col_threads <= LD_COL_MAX_THREADS && !getenv("GARLIC_LD_SUM_BY_COLUMN") &&
+                        !getenv("GARLIC_LD_SUM_L2");
+    const bool tiled = by_snp || (winsize <= LD_SUM_MAX_W && !getenv("GARLIC_LD_SUM_L2"));
     const int sum_b = by_snp ? std::min(LD_COL_B, col_threads - winsize + 1) : LD_SUM_B;
     // (the SNP-per-thread kernel reads one combined row of 2W doubles per SNP, in d_fwd; + 1 KB the last row's
     // last request may run over)
@@ -1861,10 +1862,10 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
     if (by_snp && (rc = reserve_skew(p, winsize))) return done(rc);      // the sum kernel writes the wLOD weights as well
     for (int c = 0; c < p->nchr; c++) {
         const int64_t lo = p->chr_off[c], hi = p->chr_off[c + 1];
-        if (by_snp && !getenv("GARLIC_LD_HR2_PLAIN"))
+        const size_t hr2_lds = sizeof(double) * (LD_HR2_T + winsize + (size_t)LD_HR2_T * (winsize + 1));
+        if (by_snp && hr2_lds <= 64 * 1024 && !getenv("GARLIC_LD_HR2_PLAIN"))
             hipLaunchKernelGGL(ld_hr2_tile_kernel, dim3((unsigned)((hi - lo + LD_HR2_T - 1) / LD_HR2_T)), dim3(256),
-                               sizeof(double) * (LD_HR2_T + winsize + (size_t)LD_HR2_T * (winsize + 1)), s, pair, d_hf.p, lo, hi,
-                               winsize, d_fwd.p);
+                               hr2_lds, s, pair, d_hf.p, lo, hi, winsize, d_fwd.p);
         else if (by_snp)
             hipLaunchKernelGGL(ld_hr2_kernel<true>, dim3((unsigned)(hi - lo)), dim3(128), 0, s, pair, d_hf.p, lo, hi,
                                winsize, d_fwd.p, (double *)nullptr);
@@ -1881,6 +1882,10 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
         const int threads = by_snp ? col_threads : (winsize + WAVE - 1) / WAVE * WAVE;
         const size_t lds = by_snp ? sizeof(double) * (32 + (size_t)LD_COL_RING * 2 * winsize + threads + 160)
                                   : sizeof(double) * 2 * (2 * (size_t)winsize - 1 + 128 + threads);
+        if (by_snp && lds > 48 * 1024) {
+            e = hipFuncSetAttribute((const void *)ld_sum_col_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
+        }
         if (by_snp)
             hipLaunchKernelGGL(ld_sum_col_kernel, dim3((unsigned)sum_blocks), dim3(threads), lds, s, d_fwd.p,
                                d_sum_chrs.p, (int)sum_chrs.size(), winsize, sum_b, ld, p->d_skew.p + SKEW_FRONT);

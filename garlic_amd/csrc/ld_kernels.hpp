@@ -490,22 +490,26 @@ ld_sum_tiled_kernel(const double *__restrict__ fwd, const double *__restrict__ b
 // B = min(32, threads - W + 1) so that few lanes idle (W = 100: 128 threads, 29 starts per workgroup).
 // The rows come from ld_hr2_kernel<true>'s combined table (one contiguous row of 2W doubles per SNP).
 constexpr int LD_COL_B = 32;
-constexpr int LD_COL_MAX_THREADS = 320;
+constexpr int LD_COL_MAX_THREADS = 576;      // W + B - 1 SNPs in whole waves: W <= 512
 constexpr int LD_COL_RING = 8;       // rows in the LDS ring
 constexpr int LD_COL_AHEAD = 6;      // rows requested ahead of the step that reads them (<= LD_COL_RING - 2)
-constexpr int LD_COL_MAX_PIECES = 4; // 1-KB requests per row: W <= 256
+constexpr int LD_COL_MAX_PIECES = 8; // 1-KB requests per row (16 W bytes): W <= 512
 
-// waits until at most n of the wave's vector-memory requests are outstanding (n wave-uniform, 0 .. 20)
+// waits until at most n of the wave's vector-memory requests are outstanding (n wave-uniform, 0 .. 40)
 __device__ __forceinline__ void ld_col_wait(int n)
 {
-    static_assert((LD_COL_AHEAD - 1) * LD_COL_MAX_PIECES <= 20, "one s_waitcnt per count below");
+    static_assert((LD_COL_AHEAD - 1) * LD_COL_MAX_PIECES <= 40, "one s_waitcnt per count below");
     switch (n) {
 #define LD_COL_WAIT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
         LD_COL_WAIT_CASE(0) LD_COL_WAIT_CASE(1) LD_COL_WAIT_CASE(2) LD_COL_WAIT_CASE(3) LD_COL_WAIT_CASE(4)
         LD_COL_WAIT_CASE(5) LD_COL_WAIT_CASE(6) LD_COL_WAIT_CASE(7) LD_COL_WAIT_CASE(8) LD_COL_WAIT_CASE(9)
         LD_COL_WAIT_CASE(10) LD_COL_WAIT_CASE(11) LD_COL_WAIT_CASE(12) LD_COL_WAIT_CASE(13) LD_COL_WAIT_CASE(14)
         LD_COL_WAIT_CASE(15) LD_COL_WAIT_CASE(16) LD_COL_WAIT_CASE(17) LD_COL_WAIT_CASE(18) LD_COL_WAIT_CASE(19)
-        LD_COL_WAIT_CASE(20)
+        LD_COL_WAIT_CASE(20) LD_COL_WAIT_CASE(21) LD_COL_WAIT_CASE(22) LD_COL_WAIT_CASE(23) LD_COL_WAIT_CASE(24)
+        LD_COL_WAIT_CASE(25) LD_COL_WAIT_CASE(26) LD_COL_WAIT_CASE(27) LD_COL_WAIT_CASE(28) LD_COL_WAIT_CASE(29)
+        LD_COL_WAIT_CASE(30) LD_COL_WAIT_CASE(31) LD_COL_WAIT_CASE(32) LD_COL_WAIT_CASE(33) LD_COL_WAIT_CASE(34)
+        LD_COL_WAIT_CASE(35) LD_COL_WAIT_CASE(36) LD_COL_WAIT_CASE(37) LD_COL_WAIT_CASE(38) LD_COL_WAIT_CASE(39)
+        LD_COL_WAIT_CASE(40)
 #undef LD_COL_WAIT_CASE
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }

@@ -243,9 +243,9 @@ def test_phased_ld_sharded(gpu_ctx):
         panel.close()
 
 
-@pytest.mark.parametrize("W", [32, 33, 34, 63, 64, 65, 200, 256, 257])
+@pytest.mark.parametrize("W", [32, 33, 34, 63, 64, 65, 200, 256, 257, 300, 512, 513])
 def test_ld_wide_windows_and_kernel_switch(gpu_ctx, W, monkeypatch):
-    """the ordered sums: 33 <= W <= 256 one thread per SNP of the window (ld_sum_col_kernel, the combined hr2 rows
+    """the ordered sums: 33 <= W <= 512 one thread per SNP of the window (ld_sum_col_kernel, the combined hr2 rows
     streamed by LDS-DMA; W around the wave size, the accumulator count and the widest it takes), below that and
     when switched off one thread per column (ld_sum_tiled_kernel), wider windows the plain kernel"""
     rng = np.random.default_rng(W)
