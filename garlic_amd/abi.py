@@ -29,7 +29,7 @@ SYMBOLS = [
     "garlic_panel_release_scratch",
     "garlic_lod_feed", "garlic_ctx_set_async",
     "garlic_recent_kernel_ms", "garlic_panel_tgls_mode", "garlic_lod_feed_subset",
-    "garlic_device_alloc", "garlic_device_free",
+    "garlic_device_alloc", "garlic_device_free", "garlic_panel_chain_kind",
 ]
 
 
@@ -106,6 +106,7 @@ def lib():
     L.garlic_lod_feed_subset.argtypes = [_vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_double, C.c_int32, _i32p, C.c_int32, _vp, C.c_int64, _i64p, _i64p]
     L.garlic_panel_tgls_mode.argtypes = [_vp, _i32p, _i32p]
+    L.garlic_panel_chain_kind.argtypes = [_vp, _i32p]
     for name in SYMBOLS:
         f = getattr(L, name)
         if f.restype is C.c_int and name not in ("garlic_hip_abi_version",):
@@ -436,6 +437,12 @@ class Panel:
                                            step, _ptr(idx, _i32p), 0 if idx is None else n_rows,
                                            _vp(feed.ctypes.data), cap, C.byref(n), _ptr(per_chr, _i64p)))
         return (feed[: n.value].copy() if copy else feed[: n.value]), per_chr
+
+    def chain_kind(self):
+        """0 tuned chain, 1 tuned chain + scan for the value -9999.0 (none found), 2 by-value chain (garlic_hip.h)"""
+        k = C.c_int32()
+        check(lib().garlic_panel_chain_kind(self.handle, C.byref(k)))
+        return k.value
 
     def tgls_mode(self):
         """(mode, terms_by): mode 0 none / 1 dictionary codes / 2 continuous values; terms_by 0 tabulated or

@@ -187,6 +187,7 @@ struct garlic_panel {
     int gl_terms_by = 0;                           // who built the current terms: 1 device log10, 2 host libm
     // wLOD
     bool have_ld = false, wlod_use_gl = false, rld_valid = false;
+    int32_t last_chain_kind = 0;                   // garlic_panel_chain_kind
     int32_t ld_winsize = 0;
     DevBuf<double> d_rld, d_decay, d_stage64;
     DevBuf<uint64_t> d_phase;                      // HapData::firstCopy as bit planes [blk][nloci] (--phased LD)
@@ -381,7 +382,7 @@ enum Mode { MODE_LOD, MODE_LOD_GL, MODE_WLOD };
 // the sums).  Otherwise the exact kernel runs (lod_chain_exact_kernel).  Tables / terms must be current.
 bool lod_exact_needed(const garlic_panel *p, Mode mode, int32_t W)
 {
-    if (getenv("GARLIC_EXACT_CHAIN")) return true;
+    if (getenv("GARLIC_EXACT_CHAIN") || getenv("GARLIC_EXACT_CHAIN_ONLY")) return true;
     const double tmin = mode == MODE_LOD ? p->tab_min : (p->gl_cont ? p->glterms_min : p->tabgl_min);
     return (double)W * tmin <= -9990.0;
 }
@@ -796,8 +797,12 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // tuned wLOD kernels: 16 window accumulators per lane; scores from one LDS row per SNP (plain
     // --error) or from the TGLS score matrix (use_gl); very narrow / very wide windows keep the
     // generic kernel
-    const bool exact = mode != MODE_WLOD && lod_exact_needed(p, mode, W);
-    if (exact && thin_step > 0) return fail(GARLIC_ERR_INVALID, "internal: thinned output with the exact chain");
+    // A window sum of exactly -9999.0 is possible (lod_exact_needed): the tuned chain runs first, its scored windows
+    // are scanned for that value, and only if one is there the chain that follows the reference to the letter
+    // (11-17 x slower) runs instead.  GARLIC_EXACT_CHAIN_ONLY: that chain straight away.
+    const bool exact_possible = mode != MODE_WLOD && lod_exact_needed(p, mode, W);
+    bool exact = exact_possible && getenv("GARLIC_EXACT_CHAIN_ONLY") != nullptr;
+    if (exact_possible && thin_step > 0) return fail(GARLIC_ERR_INVALID, "internal: thinned output with the exact chain");
     const bool wlod_shape_ok = mode == MODE_WLOD && W + 64 <= GPAD_BACK && !getenv("GARLIC_WLOD_GENERIC") &&
                                (W >= WLOD_R || !getenv("GARLIC_WLOD_SMALL_GENERIC"));
     const bool wlod_small = W < WLOD_R;      // narrower than a window group: wlod_group_small (compiler-scheduled)
@@ -876,7 +881,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         if ((rc = p->d_chrs.reserve(chrs.size()))) return rc;
         if ((rc = p->d_items.reserve(std::max<size_t>(n_items, 1)))) return rc;
         if ((rc = p->d_fill.reserve(std::max<size_t>(n_fill, 1)))) return rc;
-        if ((rc = p->d_counter.reserve(2))) return rc;
+        if ((rc = p->d_counter.reserve(4))) return rc;      // [0], [1]: the chain kernel's queue; [2]: sentinel_scan_kernel's flag
         p->plan.valid = false;
     }
     std::vector<uint8_t> valid;
@@ -1097,6 +1102,20 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     return GARLIC_OK;
     };   // enqueue
     if ((rc = enqueue())) return rc;
+    p->last_chain_kind = exact ? 2 : 0;
+    if (exact_possible && !exact && n_items) {
+        int32_t found = 0;
+        HIP_TRY(hipMemsetAsync(p->d_counter.p + 2, 0, sizeof(int32_t), ctx->stream));
+        hipLaunchKernelGGL(sentinel_scan_kernel, dim3((unsigned)n_items), dim3(256), 0, ctx->stream, p->d_items.p, p->d_chrs.p,
+                           d_out, ind_count, p->d_counter.p + 2);
+        HIP_TRY(hipMemcpyAsync(&found, p->d_counter.p + 2, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        p->last_chain_kind = found ? 2 : 1;
+        if (found) {
+            exact = true;
+            if ((rc = enqueue())) return rc;
+        }
+    }
     if (where == GARLIC_HOST)
         for (int c = 0; c < p->nchr; c++)
             HIP_TRY(hipMemcpy2DAsync(out + Lhost.base[c], sizeof(double) * Lhost.pitch[c], d_out + L.base[c],
@@ -2291,6 +2310,13 @@ int garlic_device_free(garlic_ctx *ctx, void *ptr)
             }
     }
     HIP_TRY(hipFree(ptr));
+    return GARLIC_OK;
+}
+
+int garlic_panel_chain_kind(garlic_panel *p, int32_t *kind)
+{
+    if (!p || !kind) return fail(GARLIC_ERR_INVALID, "panel and kind are required");
+    *kind = p->last_chain_kind;
     return GARLIC_OK;
 }
 

@@ -1030,6 +1030,26 @@ __global__ void unskew_kernel(const double *__restrict__ D, double *__restrict__
     }
 }
 
+// Is any SCORED window exactly -9999.0?  (The tuned chains and the reference's by-value test of
+// garlic-roh.cpp:79 differ only from such a window on; everything up to the first one is identical, so the
+// tuned chain's own output answers the question.)  One workgroup per (run, 64-individual block) item.
+__global__ void __launch_bounds__(256)
+sentinel_scan_kernel(const ChainItem *__restrict__ items, const ChrDev *__restrict__ chrs,
+                     const double *__restrict__ out, int ind_count, int *__restrict__ flag)
+{
+    const ChainItem it = items[blockIdx.x];
+    if (it.chr < 0) return;
+    const ChrDev c = chrs[it.chr];
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    const int rows = min(WAVE, ind_count - it.ind0);
+    bool found = false;
+    for (int r = wave; r < rows; r += 4) {
+        const double *row = out + c.out_base + (int64_t)(it.ind0 + r) * c.out_pitch;
+        for (int s = it.a + lane; s <= it.b; s += WAVE) found |= (row[s] == MISSING_D);
+    }
+    if (__any(found) && lane == 0) atomicOr(flag, 1);
+}
+
 // ---- KDE feed: ordered compaction of every step-th scored window (garlic-data.cpp:2026-2069).
 // One wavefront per (chromosome, individual) row; lanes walk the sampled loci 64 at a time and
 // rank the keepers with a ballot (integer work: exact whatever the order).

@@ -292,6 +292,13 @@ typedef struct garlic_call_stats {
 } garlic_call_stats;
 int garlic_last_call_stats(garlic_panel *panel, garlic_call_stats *stats);
 
+/* Which rolling-sum chain the last unweighted / TGLS score call ran.  The reference decides "the previous window
+ * holds no score" by VALUE (garlic-roh.cpp:79), so a scored window that sums to exactly -9999.0 restarts the sum.
+ * 0: such a sum is impossible for this panel and window size (W x the most negative term stays above -9999): the
+ * tuned chain; 1: possible -- the tuned chain ran, its scored windows were scanned, none was -9999.0; 2: one was
+ * (or the environment forces it): the chain that follows the reference to the letter ran (11-17 x slower). */
+int garlic_panel_chain_kind(garlic_panel *panel, int32_t *kind);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,7 +234,8 @@ def test_a_window_sum_of_exactly_minus_9999(gpu_ctx):
     exactly -9999.0 makes the next one a fresh left-to-right sum instead of (previous - leaving) + entering.
     Constructed here: 40 heterozygous SNPs at frequency 0.5 (lod = log10(error)) with per-genotype errors
     near 1e-250, the last one chosen so that the left-to-right sum of the run's first window is -9999.0 to
-    the bit.  The library notices that W * (most negative term) can reach -9999 and runs its exact chain."""
+    the bit.  The library notices that W * (most negative term) can reach -9999, scans the tuned chain's scored
+    windows for the value, finds it and runs its by-value chain."""
     o = ol.oracle()
     W, n, nind = 40, 200, 3
     rng = np.random.default_rng(0)
@@ -271,17 +272,20 @@ def test_a_window_sum_of_exactly_minus_9999(gpu_ctx):
         for pa in (1, 32):
             out = panel.lod_windows(W, 0.001, MG, use_gl=True, pitch_align=pa)
             assert ol.bits_equal(np.ascontiguousarray(out[0]), want), pa
+            assert panel.chain_kind() == 2          # the tuned chain ran, the scan found the value, the by-value chain ran
         feed, _ = panel.lod_feed(W, 0.001, MG, 7, use_gl=True)
         assert ol.bits_equal(feed, ol.oracle_flatten(want, 7))     # -9999.0 is dropped as MISSING, as in the reference
 
 
-def test_exact_chain_forced(gpu_ctx):
-    """GARLIC_EXACT_CHAIN=1: the to-the-letter kernel on ordinary panels (unweighted, dictionary TGLS,
-    continuous TGLS, the feed) equals the oracle like the tuned chains do"""
+@pytest.mark.parametrize("switch,kind_expected", [("GARLIC_EXACT_CHAIN_ONLY", 2), ("GARLIC_EXACT_CHAIN", 1)])
+def test_exact_chain_forced(gpu_ctx, switch, kind_expected):
+    """GARLIC_EXACT_CHAIN_ONLY=1: the to-the-letter kernel on ordinary panels (unweighted, dictionary TGLS,
+    continuous TGLS, the feed) equals the oracle like the tuned chains do.  GARLIC_EXACT_CHAIN=1: a sum of
+    -9999.0 is taken to be possible -- tuned chain, scan, nothing found (kind 1), the same scores."""
     rng = np.random.default_rng(61)
     nind, sizes, W = 130, [700, 45, 300], 30
     chroms = [ol.random_panel(rng, n, nind, max_gap=MG, gaps=2 if n > 500 else 0) for n in sizes]
-    with env(GARLIC_EXACT_CHAIN=1):
+    with env(**{switch: 1}):
         for kind in ("dictionary", "continuous"):
             err = [rng.choice([1e-3, 0.01, 0.2], size=c[0].shape) if kind == "dictionary"
                    else rng.uniform(1e-4, 0.5, size=c[0].shape) for c in chroms]
@@ -289,9 +293,14 @@ def test_exact_chain_forced(gpu_ctx):
                 panel.set_gl(np.concatenate(err, axis=0))
                 check_tgls(panel, chroms, err, W, pitch_align=32)
                 check_tgls(panel, chroms, err, W, ind_begin=37, ind_count=70, pitch_align=1)
+                assert panel.chain_kind() == kind_expected
                 got = panel.lod_windows(W, 0.001, MG, pitch_align=32)
+                assert panel.chain_kind() == kind_expected
                 wants = [ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, MG) for g, f, p, cs, ce in chroms]
                 for c in range(len(chroms)):
                     assert ol.bits_equal(np.ascontiguousarray(got[c]), wants[c]), (kind, c)
                 feed, per_chr = panel.lod_feed(W, 0.001, MG, W)
                 assert ol.bits_equal(feed, np.concatenate([ol.oracle_flatten(w, W) for w in wants]))
+    with make_panel(gpu_ctx, chroms, nind) as panel:      # no switch: 30 terms cannot reach -9999
+        panel.lod_windows(W, 0.001, MG, pitch_align=32)
+        assert panel.chain_kind() == 0
