@@ -1905,12 +1905,18 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
             e = hipFuncSetAttribute((const void *)ld_sum_col_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
         }
+        // (the call's dominant kernel: its HIP-event time is what garlic_recent_kernel_ms reports for an LD call)
+        garlic_ctx *ctx = p->ctx;
+        const int slot = (int)(ctx->n_calls % garlic_ctx::HIST);
+        (void)hipEventRecord(ctx->hist0[slot], s);
         if (by_snp)
             hipLaunchKernelGGL(ld_sum_col_kernel, dim3((unsigned)sum_blocks), dim3(threads), lds, s, d_fwd.p,
                                d_sum_chrs.p, (int)sum_chrs.size(), winsize, sum_b, ld, p->d_skew.p + SKEW_FRONT);
         else
             hipLaunchKernelGGL(ld_sum_tiled_kernel, dim3((unsigned)sum_blocks), dim3(threads), lds, s, d_fwd.p, d_bwd.p,
                                d_sum_chrs.p, (int)sum_chrs.size(), winsize, ld);
+        (void)hipEventRecord(ctx->hist1[slot], s);
+        ctx->n_calls++;
     }
     e = hipGetLastError();
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
