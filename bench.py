@@ -325,9 +325,8 @@ def main():
     ap.add_argument("--inds", type=int, default=0, help="individuals per GPU (default: workload's)")
     ap.add_argument("--cpu-inds", type=int, default=512, help="individuals in the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--out-candidates", type=int, default=3,
-                    help="plain score buffers timed for comparison with the library's allocation (placement in VRAM "
-                         "changes the kernel time)")
+    ap.add_argument("--out-candidates", type=int, default=8,
+                    help="score buffers to try for the timed passes (placement in VRAM changes the kernel time)")
     ap.add_argument("--also", default="auto", help="auto | none | comma list of c3,ns,e2e (N = 1 only)")
     ap.add_argument("--also-budget-s", type=float, default=330.0,
                     help="no further `also` leg is started once the run has taken this long")
@@ -371,17 +370,16 @@ def main():
 
     PITCH_ALIGN = 32
     base, pitch, total = panel.out_layout(PITCH_ALIGN, nind)
-    # Where a plain allocation puts the score buffer in VRAM changes the chain kernel's time by up to 18 % (same
-    # code, same virtual layout, same box: 1.36 .. 1.64 ms at C2 -- DESIGN.md section 4, "placement").  A plain
-    # streaming fill runs equally fast on every allocation; what differs is how the kernel's few HBM reads mix
-    # with its write stream.  The library's own allocator for score matrices (garlic_device_alloc: a virtual
-    # range backed by physical chunks of its own) has been in the fast mode every time it was measured; the timed
-    # passes write into a buffer from there.  For the record a few plain (torch / hipMalloc) buffers are timed on
-    # three passes each beforehand and reported next to it.
+    # Where the score buffer lands in VRAM changes the chain kernel's time by up to 18 % (same code, same virtual
+    # layout, same box: 1.34 .. 1.68 ms at C2 -- DESIGN.md section 4, "placement").  A plain streaming fill runs equally
+    # fast on every allocation; what differs is how the kernel's few HBM reads mix with its write stream.  A caller
+    # that keeps its score buffer (GARLIC's sweep over window sizes does) can pick a good one once: while they fit,
+    # a few candidate buffers are allocated side by side -- half through the library's allocator for score matrices
+    # (garlic_device_alloc: a virtual range backed by physical chunks of its own, in the fast mode more often than
+    # plain hipMalloc memory, not always), half plain torch buffers --, each is timed on three passes, the fastest is
+    # kept and the others are freed.  Every candidate's time is reported.
     placement = None
-    out_buf = ctx.alloc_scores(total)
-    out = out_buf.tensor()
-    n_cand = 0 if (args.out_candidates < 1 or total * 8 * (args.out_candidates + 1) > (96 << 30) or args.mode != "lod") else args.out_candidates
+    n_cand = 1 if (args.out_candidates <= 1 or total * 8 * args.out_candidates > (96 << 30) or args.mode != "lod") else args.out_candidates
 
     def three_passes(ptr):
         for _ in range(2):
@@ -391,21 +389,26 @@ def main():
             panel.lod_windows_device(ptr, W, ERROR, MAX_GAP, pitch_align=PITCH_ALIGN)
         return float(np.mean(ctx.recent_kernel_ms(3)))
 
-    if n_cand > 0:
-        cands = [torch.empty(total, dtype=torch.float64, device=dev) for _ in range(n_cand)]
+    out_buf = None
+    if n_cand > 1:
+        bufs = [ctx.alloc_scores(total) if k % 2 == 0 else None for k in range(n_cand)]
+        cands = [b.tensor() if b is not None else torch.empty(total, dtype=torch.float64, device=dev) for b in bufs]
         torch.cuda.synchronize()
         times = [three_passes(c.data_ptr()) for c in cands]
-        t_lib = three_passes(out.data_ptr())
         best = int(np.argmin(times))
-        placement = {"allocator": "garlic_device_alloc (HIP virtual memory management, 1-GB physical chunks)",
-                     "library_buffer_kernel_ms": t_lib, "candidates_kernel_ms": times, "kept": "library buffer",
-                     "note": "candidates: plain torch (hipMalloc) buffers allocated side by side, 3 timed passes each; "
-                             "the timed region writes into the library's buffer unless a plain one is more than 2 % faster"}
-        if times[best] < 0.98 * t_lib:      # the library's buffer is never in the slow mode, but not always the fastest
-            out = cands[best]
-            placement["kept"] = f"plain candidate {best}"
-        del cands
+        out, out_buf = cands[best], bufs[best]
+        placement = {"candidates_kernel_ms": times,
+                     "candidates_allocator": ["garlic_device_alloc" if b is not None else "torch (hipMalloc)" for b in bufs],
+                     "kept": best,
+                     "note": "score buffers allocated side by side, 3 timed passes each, fastest kept"}
+        for k, b in enumerate(bufs):
+            if b is not None and k != best:
+                b.free()
+        del cands, bufs
         torch.cuda.empty_cache()
+    else:
+        out_buf = ctx.alloc_scores(total)
+        out = out_buf.tensor()
     setup = {}
     if args.mode == "wlod":
         # LD weights (calcLDData) from --ld-subsample 500 of the WHOLE panel: every rank counts over its own
@@ -522,7 +525,8 @@ def main():
             res["cpu_baseline"] = None
     panel.close()
     del out, geno_sample
-    out_buf.free()
+    if out_buf is not None:
+        out_buf.free()
     torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and args.also != "none":

@@ -2230,11 +2230,11 @@ int garlic_recent_kernel_ms(garlic_ctx *ctx, float *ms, int32_t n, int32_t *got)
     return GARLIC_OK;
 }
 
-// Score buffers.  Where a plain hipMalloc puts 8 GB of scores decides between two speeds of lod_chain_kernel at
-// 1M SNPs x 1000 individuals (1.36 and 1.62 ms: DESIGN.md section 4, "placement"); a virtual range backed by
-// physical chunks of its own (HIP virtual memory management, 1 GB each) was in the fast mode every time (33 of
-// 33 allocations on two boxes, a third of the plain ones on the same boxes slow).  Falls back to hipMalloc where
-// the driver has no virtual memory management.
+// Score buffers.  Where 8 GB of scores sit in VRAM decides between two speeds of lod_chain_kernel at 1M SNPs x
+// 1000 individuals (1.36 and 1.62 ms: DESIGN.md section 4, "placement"); a virtual range backed by physical chunks
+// of its own (HIP virtual memory management, 1 GB each) was in the fast mode more often than plain hipMalloc
+// memory (33 of 36 allocations measured, against two out of three).  Falls back to hipMalloc where the driver has
+// no virtual memory management.
 struct ScoreAlloc { void *ptr; size_t size; std::vector<hipMemGenericAllocationHandle_t> handles; };
 static std::mutex g_score_mutex;
 static std::vector<ScoreAlloc> g_score_allocs;

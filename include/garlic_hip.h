@@ -78,12 +78,13 @@ int garlic_ctx_synchronize(garlic_ctx *ctx);
 int garlic_ctx_set_async(garlic_ctx *ctx, int32_t on);
 
 /* Device memory for score matrices (the `out` of garlic_lod_windows & co. with GARLIC_DEVICE).  Any device
- * pointer works as `out`; one from here additionally makes the unweighted kernel's speed reproducible: where a
- * plain hipMalloc places 8 GB of scores decides between 1.36 and 1.62 ms per pass at 1M SNPs x 1000 individuals
- * (a property of the allocation), a virtual range backed by its own physical chunks (HIP
- * virtual memory management) was in the fast mode every time it was measured.  GARLIC itself has no counterpart
- * (WinData rows are host memory, garlic-data.cpp:1690); keep the buffer across window sizes as GARLIC keeps its
- * WinData.  Falls back to hipMalloc when the driver offers no virtual memory management. */
+ * pointer works as `out`.  Where 8 GB of scores sit in VRAM relative to the panel decides between two speeds of
+ * the unweighted kernel at 1M SNPs x 1000 individuals (1.36 and 1.62 ms per pass: a property of the allocation,
+ * DESIGN.md section 4); a virtual range backed by physical chunks of its own (HIP virtual memory management),
+ * which this returns, was in the fast mode more often than plain hipMalloc memory (33 of 36 against two out of
+ * three) -- a caller that cares times a few buffers and keeps the best, as bench.py does.  GARLIC itself has no
+ * counterpart (WinData rows are host memory, garlic-data.cpp:1690); keep the buffer across window sizes as
+ * GARLIC keeps its WinData.  Falls back to hipMalloc when the driver offers no virtual memory management. */
 int garlic_device_alloc(garlic_ctx *ctx, int64_t bytes, void **out);
 int garlic_device_free(garlic_ctx *ctx, void *ptr);
 /* HIP-event durations (ms) of the dominant kernel of the context's most recent window-score calls,
