@@ -822,9 +822,9 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // per wave; it needs a block-aligned shard (a wave's 64 lanes = one block of the matrix)
     const bool wlod_gl_ring = wlod_gl && !wlod_small && (ind_begin & (WAVE - 1)) == 0 && !getenv("GARLIC_WLOD_GL_NO_RING");
     const bool ring_patch = !getenv("GARLIC_WLOD_GL_NO_PATCH");
-    // ... and with windows narrow enough for WS_MAX_WAVES compute waves per workgroup the strip form: the
+    // ... and with windows narrow enough for WS_WAVES (W <= 113) or WS_WAVES_WIDE (W <= 241) compute waves per workgroup the strip form: the
     // blocks' term rows enter a CU once per strip (wlod_strip_kernel.hpp)
-    const int strip_waves = WS_MAX_WAVES;
+    const int strip_waves = (W + 15 - 16 * WS_WAVES <= 16 || getenv("GARLIC_WLOD_STRIP_NARROW_ONLY")) ? WS_WAVES : WS_WAVES_WIDE;
     const bool wlod_gl_strip = wlod_gl_ring && W + 15 - 16 * strip_waves <= 16 && !getenv("GARLIC_WLOD_GL_NO_STRIP");
     const size_t wlod_lds = wlod_gl_ring ? WLOD_GL_RING_OFF + (size_t)WLOD_WAVES * GARLIC_WLOD_GL_RING_ROWS * WAVE * 8
                                    : wlod_rows + 16 + (wlod_use_patch ? wlod_patch : 0);   // 16: the patch lock
@@ -1000,14 +1000,14 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                              (int64_t)(GOFF + p->nloci + GPAD_BACK), ind_begin, ind_count, W, strip_waves, n_pairs,
                              ring_patch ? 1 : 0, (uint32_t)((int64_t)p->plan.n_strips * n_pairs)};
             const unsigned grid = (sa.n_work + 7u) / 8u * 8u;
-            const void *fn = aligned16 ? (const void *)wlod_strip_gl_kernel<true> : (const void *)wlod_strip_gl_kernel<false>;
+            const bool wide = strip_waves == WS_WAVES_WIDE;
+            const void *fn = wide ? (aligned16 ? (const void *)wlod_strip_gl_kernel<true, WS_WAVES_WIDE>
+                                               : (const void *)wlod_strip_gl_kernel<false, WS_WAVES_WIDE>)
+                                  : (aligned16 ? (const void *)wlod_strip_gl_kernel<true, WS_WAVES>
+                                               : (const void *)wlod_strip_gl_kernel<false, WS_WAVES>);
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES));
-            if (aligned16)
-                hipLaunchKernelGGL(wlod_strip_gl_kernel<true>, dim3(grid), dim3((strip_waves + 1) * WAVE), WS_LDS_BYTES,
-                                   ctx->stream, sa);
-            else
-                hipLaunchKernelGGL(wlod_strip_gl_kernel<false>, dim3(grid), dim3((strip_waves + 1) * WAVE), WS_LDS_BYTES,
-                                   ctx->stream, sa);
+            void *kargs[] = {(void *)&sa};
+            HIP_TRY(hipLaunchKernel(fn, dim3(grid), dim3((strip_waves + 1) * WAVE), kargs, WS_LDS_BYTES, ctx->stream));
         } else if (wlod_gl_ring && aligned16)
             hipLaunchKernelGGL((wlod_tile_glring_kernel<WLOD_R, true>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
                                a_packed, a_wtab, a_skew, d_out, a);

@@ -32,17 +32,19 @@
 
 namespace garlic {
 
-constexpr int WS_MAX_WAVES = 7;                         // compute waves per workgroup (+ the loader: 8 waves, two workgroups per CU)
+constexpr int WS_WAVES = 7;                             // compute waves per workgroup (+ the loader: 8 waves, two workgroups per CU)
+constexpr int WS_WAVES_WIDE = 15;                       // ... for 113 < W <= 241: 16 waves, one workgroup per CU (the same 14-15 compute waves per CU)
+constexpr int WS_NEED_ROWS = 16;
 constexpr int WS_RING = GARLIC_WLOD_GLS_RING_ROWS;      // rows per ring (power of two)
 constexpr int WS_DEPTH = 6;                             // loader: row pairs (per block) in flight
 constexpr int WS_NEVER = 0x7fffffff;
 constexpr uint32_t WS_RING_BYTES = (uint32_t)WS_RING * WAVE * 8u;
 // dynamic LDS: ring A, ring B (1-KB aligned), the loader's counter (one 512-B row: every lane reads its own copy,
-// at its ring address + an immediate offset -- no address register), need[8] (eight such rows), patch lock
+// at its ring address + an immediate offset -- no address register), need[16] (sixteen such rows), patch lock
 // (16 B), patch [64][WT_PITCH]
 constexpr uint32_t WS_LANDED_OFF = 2u * WS_RING_BYTES;
 constexpr uint32_t WS_NEED_OFF = WS_LANDED_OFF + 512u;
-constexpr uint32_t WS_LOCK_OFF = WS_NEED_OFF + 8u * 512u;
+constexpr uint32_t WS_LOCK_OFF = WS_NEED_OFF + (uint32_t)WS_NEED_ROWS * 512u;
 constexpr uint32_t WS_PATCH_OFF = WS_LOCK_OFF + 16u;
 constexpr uint32_t WS_LDS_BYTES = WS_PATCH_OFF + (uint32_t)(WAVE * WT_PITCH * 8);
 
@@ -68,15 +70,22 @@ __device__ __forceinline__ void ws_row_write(uint32_t lane8b, uint32_t off, int 
     asm volatile("ds_write_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(lane8b + off), "v"(v) : "memory");
 }
 __device__ __forceinline__ int ws_min_need(uint32_t lane8b)
-{
-    int x[WS_MAX_WAVES];
+{   // all sixteen rows (rows of waves the workgroup does not have hold WS_NEVER), one wait
+    static_assert(WS_NEED_ROWS == 16, "sixteen rows of need[] are read");
+    int x[16];
     const uint32_t a = lane8b + WS_NEED_OFF;
-    asm volatile("ds_read_b32 %0, %7\n\tds_read_b32 %1, %7 offset:512\n\tds_read_b32 %2, %7 offset:1024\n\t"
-                 "ds_read_b32 %3, %7 offset:1536\n\tds_read_b32 %4, %7 offset:2048\n\tds_read_b32 %5, %7 offset:2560\n\t"
-                 "ds_read_b32 %6, %7 offset:3072\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]) : "v"(a) : "memory");
-    static_assert(WS_MAX_WAVES == 7, "seven rows of need[] are read");
-    const int m = min(min(min(x[0], x[1]), min(x[2], x[3])), min(min(x[4], x[5]), x[6]));
+    asm volatile("ds_read_b32 %0, %16\n\tds_read_b32 %1, %16 offset:512\n\tds_read_b32 %2, %16 offset:1024\n\t"
+                 "ds_read_b32 %3, %16 offset:1536\n\tds_read_b32 %4, %16 offset:2048\n\tds_read_b32 %5, %16 offset:2560\n\t"
+                 "ds_read_b32 %6, %16 offset:3072\n\tds_read_b32 %7, %16 offset:3584\n\tds_read_b32 %8, %16 offset:4096\n\t"
+                 "ds_read_b32 %9, %16 offset:4608\n\tds_read_b32 %10, %16 offset:5120\n\tds_read_b32 %11, %16 offset:5632\n\t"
+                 "ds_read_b32 %12, %16 offset:6144\n\tds_read_b32 %13, %16 offset:6656\n\tds_read_b32 %14, %16 offset:7168\n\t"
+                 "ds_read_b32 %15, %16 offset:7680\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7]),
+                   "=&v"(x[8]), "=&v"(x[9]), "=&v"(x[10]), "=&v"(x[11]), "=&v"(x[12]), "=&v"(x[13]), "=&v"(x[14]), "=&v"(x[15])
+                 : "v"(a) : "memory");
+    int m = x[0];
+#pragma unroll
+    for (int k = 1; k < 16; k++) m = min(m, x[k]);
     return __builtin_amdgcn_readfirstlane(m);
 }
 
@@ -174,8 +183,10 @@ __device__ __forceinline__ void ws_loader(const double *srcA, const double *srcB
     ws_row_write(lane8b, WS_LANDED_OFF, n_rows);
 }
 
-template <bool ALIGNED16>
-__global__ void __launch_bounds__((WS_MAX_WAVES + 1) * WAVE, 5)   // 5 waves per SIMD: at most 96 VGPRs (at 80 -- 6 waves, three workgroups per CU -- hipcc does not finish allocating registers around the loop)
+// NW = 7: 8 waves, 5 waves per SIMD = at most 96 VGPRs (at 80 -- 6 waves, three workgroups per CU -- hipcc does not
+// finish allocating registers around the loop); NW = 15: 16 waves, one workgroup per CU
+template <bool ALIGNED16, int NW>
+__global__ void __launch_bounds__((NW + 1) * WAVE, NW == WS_WAVES ? 5 : 4)
 wlod_strip_gl_kernel(WlodStripArgs p)
 {
     extern __shared__ __attribute__((aligned(1024))) char ws_lds[];
@@ -185,7 +196,7 @@ wlod_strip_gl_kernel(WlodStripArgs p)
     int *patch_lock = reinterpret_cast<int *>(ws_lds + WS_LOCK_OFF);
     double *patch = reinterpret_cast<double *>(ws_lds + WS_PATCH_OFF);
     int *landed = reinterpret_cast<int *>(ws_lds + WS_LANDED_OFF);     // [64][2]: a copy per lane
-    int *need = reinterpret_cast<int *>(ws_lds + WS_NEED_OFF);         // [8][64][2]
+    int *need = reinterpret_cast<int *>(ws_lds + WS_NEED_OFF);         // [16][64][2]
     // one contiguous range of the work per XCD (one L2 each): the pairs of a strip share its weights
     const unsigned per_xcd = gridDim.x >> 3;
     const unsigned v = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
@@ -195,7 +206,7 @@ wlod_strip_gl_kernel(WlodStripArgs p)
     const ChrDev c = p.chrs[st.chr];
     if (threadIdx.x == 0) *patch_lock = 0;
     if (wave == 0) landed[2 * lane] = 0;
-    if (wave < WS_MAX_WAVES) need[(wave * WAVE + lane) * 2] = (wave < N && wave < st.n_groups) ? 16 * wave : WS_NEVER;
+    for (int r = wave; r < WS_NEED_ROWS; r += N + 1) need[(r * WAVE + lane) * 2] = (r < N && r < st.n_groups) ? 16 * r : WS_NEVER;
     __syncthreads();
     const int ind0A = pair * 2 * WAVE, ind0B = ind0A + WAVE;
     const bool activeB = ind0B < p.ind_count;

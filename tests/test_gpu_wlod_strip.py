@@ -1,5 +1,5 @@
 """GPU: the strip form of the GL-weighted wLOD kernel (wlod_strip_kernel.hpp: 7 compute waves + a loader per
-workgroup, the two blocks' term rows through shared LDS rings) against the oracle (garlic-roh.cpp:204-277 with
+workgroup for W <= 113, 15 + 1 for W <= 241, the two blocks' term rows through shared LDS rings) against the oracle (garlic-roh.cpp:204-277 with
 USE_GL) and against the tile kernel it replaces -- strips shorter than the workgroup has waves, many strips per
 chromosome, a last pair with one block, block-aligned sub-ranges, windows up to the widest the strip form takes."""
 import os
@@ -21,7 +21,8 @@ def _panel(rng, sizes, nind, W, mg):
     return chroms, gpos, lds, err
 
 
-@pytest.mark.parametrize("W,groups", [(16, None), (33, 1), (100, 5), (100, None), (113, 9), (64, 2)])
+@pytest.mark.parametrize("W,groups", [(16, None), (33, 1), (100, 5), (100, None), (113, 9), (64, 2), (114, 3), (200, None),
+                                      (241, 20), (242, None)])
 def test_strip_kernel_against_oracle_and_tile_kernel(gpu_ctx, W, groups, monkeypatch):
     rng = np.random.default_rng(4100 + W + (groups or 0))
     mg = 60000
