@@ -1850,7 +1850,7 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
     const bool by_snp = winsize > LD_COL_B && winsize <= 512 && col_threads <= LD_COL_MAX_THREADS && !getenv("GARLIC_LD_SUM_BY_COLUMN") &&
                         !getenv("GARLIC_LD_SUM_L2");
     const bool tiled = by_snp || (winsize <= LD_SUM_MAX_W && !getenv("GARLIC_LD_SUM_L2"));
-    const int sum_b = by_snp ? std::min(LD_COL_B, col_threads - winsize + 1) : LD_SUM_B;
+    const int sum_b = by_snp ? std::min(LD_COL_B, col_threads - winsize) : LD_SUM_B;      // (thread W + B - 1 reads one element further on odd steps)
     // (the SNP-per-thread kernel reads one combined row of 2W doubles per SNP, in d_fwd; + 1 KB the last row's
     // last request may run over)
     if ((rc = d_hf.reserve(p->nloci)) || (rc = d_fwd.reserve(by_snp ? 2 * n + 256 : n)) || (!by_snp && (rc = d_bwd.reserve(n))))
@@ -1899,19 +1899,30 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
         e = hipMemcpyAsync(d_sum_chrs.p, sum_chrs.data(), sizeof(LdSumChr) * sum_chrs.size(), hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
         const int threads = by_snp ? col_threads : (winsize + WAVE - 1) / WAVE * WAVE;
-        const size_t lds = by_snp ? sizeof(double) * (32 + (size_t)LD_COL_RING * 2 * winsize + threads + 160)
+        const int col_pieces = (threads * 8 + 1023) / 1024;
+        const size_t lds = by_snp ? sizeof(double) * std::max<size_t>((size_t)(ld_col_ahead(col_pieces) + 2) * threads + 130, (size_t)threads * 17)
                                   : sizeof(double) * 2 * (2 * (size_t)winsize - 1 + 128 + threads);
-        if (by_snp && lds > 48 * 1024) {
-            e = hipFuncSetAttribute((const void *)ld_sum_col_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
-        }
         // (the call's dominant kernel: its HIP-event time is what garlic_recent_kernel_ms reports for an LD call)
         garlic_ctx *ctx = p->ctx;
         const int slot = (int)(ctx->n_calls % garlic_ctx::HIST);
         (void)hipEventRecord(ctx->hist0[slot], s);
-        if (by_snp)
-            hipLaunchKernelGGL(ld_sum_col_kernel, dim3((unsigned)sum_blocks), dim3(threads), lds, s, d_fwd.p,
-                               d_sum_chrs.p, (int)sum_chrs.size(), winsize, sum_b, ld, p->d_skew.p + SKEW_FRONT);
+        if (by_snp) {
+            static_assert(LD_COL_MAX_THREADS <= 128 * LD_COL_MAX_PIECES, "one instantiation per request count");
+            const void *fn = col_pieces == 1 ? (const void *)ld_sum_col_kernel<1> : col_pieces == 2 ? (const void *)ld_sum_col_kernel<2>
+                           : col_pieces == 3 ? (const void *)ld_sum_col_kernel<3> : col_pieces == 4 ? (const void *)ld_sum_col_kernel<4>
+                                                                                                    : (const void *)ld_sum_col_kernel<5>;
+            if (lds > 48 * 1024) {
+                e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
+            }
+            const double *a_c = d_fwd.p;
+            const LdSumChr *a_chrs = d_sum_chrs.p;
+            int a_nchr = (int)sum_chrs.size(), a_w = winsize, a_b = sum_b;
+            double *a_ld = ld, *a_d = p->d_skew.p + SKEW_FRONT;
+            void *kargs[] = {(void *)&a_c, (void *)&a_chrs, (void *)&a_nchr, (void *)&a_w, (void *)&a_b, (void *)&a_ld, (void *)&a_d};
+            e = hipLaunchKernel(fn, dim3((unsigned)sum_blocks), dim3(threads), kargs, lds, s);
+            if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
+        }
         else
             hipLaunchKernelGGL(ld_sum_tiled_kernel, dim3((unsigned)sum_blocks), dim3(threads), lds, s, d_fwd.p, d_bwd.p,
                                d_sum_chrs.p, (int)sum_chrs.size(), winsize, ld);

@@ -491,25 +491,80 @@ ld_sum_tiled_kernel(const double *__restrict__ fwd, const double *__restrict__ b
 // The rows come from ld_hr2_kernel<true>'s combined table (one contiguous row of 2W doubles per SNP).
 constexpr int LD_COL_B = 32;
 constexpr int LD_COL_MAX_THREADS = 576;      // W + B - 1 SNPs in whole waves: W <= 512
-constexpr int LD_COL_RING = 8;       // rows in the LDS ring
-constexpr int LD_COL_AHEAD = 6;      // rows requested ahead of the step that reads them (<= LD_COL_RING - 2)
-constexpr int LD_COL_MAX_PIECES = 8; // 1-KB requests per row (16 W bytes): W <= 512
+// rows requested ahead of the step that reads them, per 1-KB requests a row takes (at most 63 requests can be
+// counted; more rows ahead were measured: no gain, the ring costs occupancy)
+__host__ __device__ constexpr int ld_col_ahead(int pieces) { return pieces <= 2 ? 6 : (pieces == 3 ? 5 : 4); }
+constexpr int LD_COL_MAX_PIECES = 5; // 1-KB requests per row (8 B per thread, 576 threads at most)
 
-// waits until at most n of the wave's vector-memory requests are outstanding (n wave-uniform, 0 .. 40)
+// waits until at most n of the wave's vector-memory requests are outstanding (n wave-uniform, 0 .. 63)
 __device__ __forceinline__ void ld_col_wait(int n)
 {
-    static_assert((LD_COL_AHEAD - 1) * LD_COL_MAX_PIECES <= 40, "one s_waitcnt per count below");
     switch (n) {
 #define LD_COL_WAIT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-        LD_COL_WAIT_CASE(0) LD_COL_WAIT_CASE(1) LD_COL_WAIT_CASE(2) LD_COL_WAIT_CASE(3) LD_COL_WAIT_CASE(4)
-        LD_COL_WAIT_CASE(5) LD_COL_WAIT_CASE(6) LD_COL_WAIT_CASE(7) LD_COL_WAIT_CASE(8) LD_COL_WAIT_CASE(9)
-        LD_COL_WAIT_CASE(10) LD_COL_WAIT_CASE(11) LD_COL_WAIT_CASE(12) LD_COL_WAIT_CASE(13) LD_COL_WAIT_CASE(14)
-        LD_COL_WAIT_CASE(15) LD_COL_WAIT_CASE(16) LD_COL_WAIT_CASE(17) LD_COL_WAIT_CASE(18) LD_COL_WAIT_CASE(19)
-        LD_COL_WAIT_CASE(20) LD_COL_WAIT_CASE(21) LD_COL_WAIT_CASE(22) LD_COL_WAIT_CASE(23) LD_COL_WAIT_CASE(24)
-        LD_COL_WAIT_CASE(25) LD_COL_WAIT_CASE(26) LD_COL_WAIT_CASE(27) LD_COL_WAIT_CASE(28) LD_COL_WAIT_CASE(29)
-        LD_COL_WAIT_CASE(30) LD_COL_WAIT_CASE(31) LD_COL_WAIT_CASE(32) LD_COL_WAIT_CASE(33) LD_COL_WAIT_CASE(34)
-        LD_COL_WAIT_CASE(35) LD_COL_WAIT_CASE(36) LD_COL_WAIT_CASE(37) LD_COL_WAIT_CASE(38) LD_COL_WAIT_CASE(39)
+        LD_COL_WAIT_CASE(0)
+        LD_COL_WAIT_CASE(1)
+        LD_COL_WAIT_CASE(2)
+        LD_COL_WAIT_CASE(3)
+        LD_COL_WAIT_CASE(4)
+        LD_COL_WAIT_CASE(5)
+        LD_COL_WAIT_CASE(6)
+        LD_COL_WAIT_CASE(7)
+        LD_COL_WAIT_CASE(8)
+        LD_COL_WAIT_CASE(9)
+        LD_COL_WAIT_CASE(10)
+        LD_COL_WAIT_CASE(11)
+        LD_COL_WAIT_CASE(12)
+        LD_COL_WAIT_CASE(13)
+        LD_COL_WAIT_CASE(14)
+        LD_COL_WAIT_CASE(15)
+        LD_COL_WAIT_CASE(16)
+        LD_COL_WAIT_CASE(17)
+        LD_COL_WAIT_CASE(18)
+        LD_COL_WAIT_CASE(19)
+        LD_COL_WAIT_CASE(20)
+        LD_COL_WAIT_CASE(21)
+        LD_COL_WAIT_CASE(22)
+        LD_COL_WAIT_CASE(23)
+        LD_COL_WAIT_CASE(24)
+        LD_COL_WAIT_CASE(25)
+        LD_COL_WAIT_CASE(26)
+        LD_COL_WAIT_CASE(27)
+        LD_COL_WAIT_CASE(28)
+        LD_COL_WAIT_CASE(29)
+        LD_COL_WAIT_CASE(30)
+        LD_COL_WAIT_CASE(31)
+        LD_COL_WAIT_CASE(32)
+        LD_COL_WAIT_CASE(33)
+        LD_COL_WAIT_CASE(34)
+        LD_COL_WAIT_CASE(35)
+        LD_COL_WAIT_CASE(36)
+        LD_COL_WAIT_CASE(37)
+        LD_COL_WAIT_CASE(38)
+        LD_COL_WAIT_CASE(39)
         LD_COL_WAIT_CASE(40)
+        LD_COL_WAIT_CASE(41)
+        LD_COL_WAIT_CASE(42)
+        LD_COL_WAIT_CASE(43)
+        LD_COL_WAIT_CASE(44)
+        LD_COL_WAIT_CASE(45)
+        LD_COL_WAIT_CASE(46)
+        LD_COL_WAIT_CASE(47)
+        LD_COL_WAIT_CASE(48)
+        LD_COL_WAIT_CASE(49)
+        LD_COL_WAIT_CASE(50)
+        LD_COL_WAIT_CASE(51)
+        LD_COL_WAIT_CASE(52)
+        LD_COL_WAIT_CASE(53)
+        LD_COL_WAIT_CASE(54)
+        LD_COL_WAIT_CASE(55)
+        LD_COL_WAIT_CASE(56)
+        LD_COL_WAIT_CASE(57)
+        LD_COL_WAIT_CASE(58)
+        LD_COL_WAIT_CASE(59)
+        LD_COL_WAIT_CASE(60)
+        LD_COL_WAIT_CASE(61)
+        LD_COL_WAIT_CASE(62)
+        LD_COL_WAIT_CASE(63)
 #undef LD_COL_WAIT_CASE
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
@@ -551,54 +606,69 @@ __device__ __forceinline__ void ld_col_adds(double (&a)[LD_COL_B], double h, boo
                  "LD_COL_END_%=:\n\t"
                  : LD_COL_OPS(a) : [h] "v"(h), [off] "s"(off) : "s98", "s99", "scc");
 }
+// PIECES: 1-KB requests per row = blockDim / 128 rounded up.  Rows ahead and the count of requests the wave may
+// leave outstanding while it waits for a row are compile-time (s_waitcnt takes an immediate; the per-step scalar
+// work -- ring offsets advanced, not recomputed, no switch -- is on the critical path of a step: ~100 scalar
+// instructions per step cost as much as the step's 32 adds).
+template <int PIECES>
 __global__ void __launch_bounds__(LD_COL_MAX_THREADS)
 ld_sum_col_kernel(const double *__restrict__ C, const LdSumChr *__restrict__ chrs, int nchr, int W, int B,
                   double *__restrict__ ld, double *__restrict__ D)
 {
-    // LDS: 32 doubles of slack, a ring of LD_COL_RING rows of 2W doubles, slack again: a thread's look-up
-    // x = W-1 + tl - j lies in [-(B-1), W-1 + blockDim) -- outside [0, 2W-1) it lands in a neighbouring row or the
-    // slack and feeds an accumulator that is never stored
+    // Step j (SNP i = s0 + j) needs of row i only the elements x = W-1 + tl - j of the workgroup's threads: blockDim
+    // consecutive doubles from a_j = (W-1 - j) rounded down to even (16-B aligned for the DMA) -- 1 KB for 128
+    // threads instead of the row's 2W doubles.  Thread tl finds its element at tl + ((W-1-j) & 1).  Elements in
+    // front of or behind the row proper (x < 0, x > 2W-2) are the neighbouring rows' and feed accumulators that are
+    // never stored.  LDS: a ring of AHEAD + 2 rows of blockDim doubles + slack (the last thread's odd step, the last
+    // request's tail).
+    constexpr int AHEAD = ld_col_ahead(PIECES), NRING = AHEAD + 2, STEADY = (AHEAD - 1) * PIECES;
     extern __shared__ double ld_rows[];
-    const int tl = threadIdx.x, P = 2 * W;
+    const int tl = threadIdx.x, P = 2 * W, nthreads = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int c = 0;
     while (c + 1 < nchr && (int64_t)blockIdx.x >= chrs[c + 1].block0) c++;
     const int64_t s0 = chrs[c].lo + ((int64_t)blockIdx.x - chrs[c].block0) * B;
     const int ns = (int)min<int64_t>(B, chrs[c].lo + chrs[c].nstarts - s0);
     const int nsteps = ns + W - 1;
-    // the rows of the SNPs s0 .. s0 + nsteps - 1 are one contiguous piece of C: wave 0 streams them into the ring by
-    // LDS-DMA, `pieces` requests of 1 KB per row (the last one runs into the next row: the same bytes that row's own
-    // requests bring, or slack), LD_COL_AHEAD rows ahead, no registers in between
-    const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)ld_rows + 32u * 8u;
-    const uint32_t row_bytes = (uint32_t)P * 8u;
-    const int pieces = (int)((row_bytes + 1023u) / 1024u);
+    // wave 0 streams the pieces into the ring by LDS-DMA, AHEAD rows ahead, no registers in between
+    const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)ld_rows;
+    const uint32_t row_bytes = (uint32_t)nthreads * 8u, ring_bytes = row_bytes * NRING;
     const uint32_t lane16 = (uint32_t)(tl & 63) * 16u;
-    const char *src = reinterpret_cast<const char *>(C + s0 * P);
-    auto request = [&](int j) {                               // row j of the strip -> ring slot j % LD_COL_RING
-        const uint32_t dst = ring + (uint32_t)(j % LD_COL_RING) * row_bytes;
-        const char *g = src + (int64_t)j * row_bytes;
-        for (int q = 0; q < pieces; q++)
+    // state of the next request: its row in C, W-1 - (its step), its ring offset
+    const char *req_row = reinterpret_cast<const char *>(C + s0 * P);
+    int req_e = W - 1;
+    uint32_t req_off = 0;
+    auto request = [&]() {
+        const char *g = req_row + (int64_t)(req_e & ~1) * 8;
+#pragma unroll
+        for (int q = 0; q < PIECES; q++)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         :: "s"(dst + (uint32_t)q * 1024u), "v"(lane16), "s"(g + q * 1024) : "memory");
+                         :: "s"(ring + req_off + (uint32_t)q * 1024u), "v"(lane16), "s"(g + q * 1024) : "memory");
+        req_row += (int64_t)P * 8;
+        req_e--;
+        req_off += row_bytes;
+        if (req_off == ring_bytes) req_off = 0;
     };
     if (wave == 0)
-        for (int j = 0; j < min(LD_COL_AHEAD, nsteps); j++) request(j);
+        for (int j = 0; j < min(AHEAD, nsteps); j++) request();
     double acc[LD_COL_B];
 #pragma unroll
     for (int q = 0; q < LD_COL_B; q++) acc[q] = 0.0;
+    uint32_t rd_addr = ring + (uint32_t)tl * 8u, rd_end = rd_addr + ring_bytes;     // this thread's element of row j, even step
+    uint32_t odd = (uint32_t)(W - 1) & 1u;                                             // (W-1-j) & 1
     for (int j = 0; j < nsteps; j++) {
         if (wave == 0) {
-            // requests retire in order: all but the rows j+1 .. issued so far have landed
-            const int behind = min(LD_COL_AHEAD - 1, nsteps - 1 - j) * pieces;   // requests issued after row j's
-            ld_col_wait(behind);
+            // requests retire in order: all but those of the rows issued after row j have landed
+            if (nsteps - 1 - j >= AHEAD - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEADY) : "memory");
+            else ld_col_wait((nsteps - 1 - j) * PIECES);
         }
         __syncthreads();       // row j is in the ring; everybody is done with row j - 1 (its slot is written next at the earliest)
-        if (wave == 0 && j + LD_COL_AHEAD < nsteps) request(j + LD_COL_AHEAD);
+        if (wave == 0 && j + AHEAD < nsteps) request();
         double h;              // hr2(s0 + j, s0 + tl)
-        {
-            const uint32_t a = ring + (uint32_t)(j % LD_COL_RING) * row_bytes + (uint32_t)((W - 1 + tl - j) * 8);
-            asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(h) : "v"(a) : "memory");
-        }
+        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(h) : "v"(rd_addr + odd * 8u) : "memory");
+        rd_addr += row_bytes;
+        if (rd_addr == rd_end) rd_addr -= ring_bytes;
+        odd ^= 1u;
         const bool leaving = j >= W;
         ld_col_adds(acc, h, leaving,                                     // entering: q = min(j, 31) .. 0
                     leaving ? j - W + 1 : (j < LD_COL_B - 1 ? LD_COL_B - 1 - j : 0));   // leaving: q = j-W+1 .. 31
@@ -606,13 +676,26 @@ ld_sum_col_kernel(const double *__restrict__ C, const LdSumChr *__restrict__ chr
 #pragma unroll
     for (int q = 0; q < LD_COL_B; q++) {
         const int k = tl - q;
-        if (q < ns && k >= 0 && k < W) {
-            const double v = x86_nan_if_nan(acc[q]);
-            ld[(s0 + q) * W + k] = v;
-            // ... and the weight the tuned wLOD kernels read, D[l][k] = 1 / LD[l - k][k] (skew_reciprocal_kernel):
-            // SNP l = s0 + tl is this thread's, its row takes the thread's values back to front
-            if (D) D[(s0 + tl) * W + k] = reciprocal_x86(v);
+        if (q < ns && k >= 0 && k < W) ld[(s0 + q) * W + k] = x86_nan_if_nan(acc[q]);
+    }
+    // ... and the weight the tuned wLOD kernels read, D[l][k] = 1 / LD[l - k][k] (skew_reciprocal_kernel): SNP
+    // l = s0 + tl is this thread's, its row takes the thread's values back to front.  Through an LDS tile
+    // [thread][16 starts], so that 16 lanes write 128 contiguous bytes of one row (straight from the registers every
+    // lane of a store went to another row: 4 ms of this kernel's 15 at 10M SNPs x 1250).
+    if (!D) return;
+    __syncthreads();                                          // the row ring is not read any more
+    double *tile = ld_rows;
+    for (int q0 = 0; q0 < LD_COL_B; q0 += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            if (q0 == 0) tile[tl * 17 + u] = reciprocal_x86(x86_nan_if_nan(acc[u]));
+            else tile[tl * 17 + u] = reciprocal_x86(x86_nan_if_nan(acc[16 + u]));
+        __syncthreads();
+        for (int e = tl; e < nthreads * 16; e += nthreads) {
+            const int t2 = e >> 4, u = e & 15, q = q0 + u, k = t2 - q;
+            if (q < ns && k >= 0 && k < W) D[(s0 + t2) * W + k] = tile[t2 * 17 + u];
         }
+        __syncthreads();
     }
 }
 
