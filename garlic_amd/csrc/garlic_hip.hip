@@ -1900,7 +1900,7 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
         if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
         const int threads = by_snp ? col_threads : (winsize + WAVE - 1) / WAVE * WAVE;
         const int col_pieces = (threads * 8 + 1023) / 1024;
-        const size_t lds = by_snp ? sizeof(double) * std::max<size_t>((size_t)(ld_col_ahead(col_pieces) + 2) * threads + 130, (size_t)threads * 17)
+        const size_t lds = by_snp ? sizeof(double) * std::max<size_t>((size_t)LD_COL_BATCH * LD_COL_NBATCH * col_pieces * 128 + 130, (size_t)threads * 17)
                                   : sizeof(double) * 2 * (2 * (size_t)winsize - 1 + 128 + threads);
         // (the call's dominant kernel: its HIP-event time is what garlic_recent_kernel_ms reports for an LD call)
         garlic_ctx *ctx = p->ctx;

@@ -491,9 +491,8 @@ ld_sum_tiled_kernel(const double *__restrict__ fwd, const double *__restrict__ b
 // The rows come from ld_hr2_kernel<true>'s combined table (one contiguous row of 2W doubles per SNP).
 constexpr int LD_COL_B = 32;
 constexpr int LD_COL_MAX_THREADS = 576;      // W + B - 1 SNPs in whole waves: W <= 512
-// rows requested ahead of the step that reads them, per 1-KB requests a row takes (at most 63 requests can be
-// counted; more rows ahead were measured: no gain, the ring costs occupancy)
-__host__ __device__ constexpr int ld_col_ahead(int pieces) { return pieces <= 2 ? 6 : (pieces == 3 ? 5 : 4); }
+constexpr int LD_COL_BATCH = 4;      // rows per wait + barrier
+constexpr int LD_COL_NBATCH = 4;     // batches in the LDS ring (NBATCH - 1 requested ahead)
 constexpr int LD_COL_MAX_PIECES = 5; // 1-KB requests per row (8 B per thread, 576 threads at most)
 
 // waits until at most n of the wave's vector-memory requests are outstanding (n wave-uniform, 0 .. 63)
@@ -621,57 +620,81 @@ ld_sum_col_kernel(const double *__restrict__ C, const LdSumChr *__restrict__ chr
     // front of or behind the row proper (x < 0, x > 2W-2) are the neighbouring rows' and feed accumulators that are
     // never stored.  LDS: a ring of AHEAD + 2 rows of blockDim doubles + slack (the last thread's odd step, the last
     // request's tail).
-    constexpr int AHEAD = ld_col_ahead(PIECES), NRING = AHEAD + 2, STEADY = (AHEAD - 1) * PIECES;
+    // Rows travel in batches of LD_COL_BATCH: one wait + one barrier per batch instead of per row (a step's 32 adds
+    // take 128 cycles; a wait, a barrier and the bookkeeping around them cost more than that per step).  The ring
+    // holds LD_COL_NBATCH batches; the batch requested at the start of batch k lands in the part batch k-1 just left.
+    constexpr int BATCH = LD_COL_BATCH, NB = LD_COL_NBATCH, NRING = BATCH * NB, STEADY = (NB - 2) * BATCH * PIECES;
+    static_assert(STEADY <= 63, "requests that can be counted");
     extern __shared__ double ld_rows[];
-    const int tl = threadIdx.x, P = 2 * W, nthreads = blockDim.x;
+    const int tl = threadIdx.x, P = 2 * W;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int c = 0;
     while (c + 1 < nchr && (int64_t)blockIdx.x >= chrs[c + 1].block0) c++;
     const int64_t s0 = chrs[c].lo + ((int64_t)blockIdx.x - chrs[c].block0) * B;
     const int ns = (int)min<int64_t>(B, chrs[c].lo + chrs[c].nstarts - s0);
-    const int nsteps = ns + W - 1;
-    // wave 0 streams the pieces into the ring by LDS-DMA, AHEAD rows ahead, no registers in between
+    const int nsteps = ns + W - 1, nbatches = (nsteps + BATCH - 1) / BATCH;
+    // wave 0 streams the pieces into the ring by LDS-DMA, NB - 1 batches ahead, no registers in between
     const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)ld_rows;
-    const uint32_t row_bytes = (uint32_t)nthreads * 8u, ring_bytes = row_bytes * NRING;
+    // (row pitch = the whole requests: a request never runs into the next row's slot, which may be the batch being read)
+    constexpr uint32_t row_bytes = (uint32_t)PIECES * 1024u, ring_bytes = row_bytes * NRING;
     const uint32_t lane16 = (uint32_t)(tl & 63) * 16u;
-    // state of the next request: its row in C, W-1 - (its step), its ring offset
+    // state of the next request: its row in C, W-1 - (its step), its ring offset, rows left to request
     const char *req_row = reinterpret_cast<const char *>(C + s0 * P);
-    int req_e = W - 1;
+    int req_e = W - 1, req_left = nsteps;
     uint32_t req_off = 0;
-    auto request = [&]() {
-        const char *g = req_row + (int64_t)(req_e & ~1) * 8;
+    auto request_batch = [&]() {             // BATCH rows (fewer at the strip's end; the ring offset moves on all the same)
 #pragma unroll
-        for (int q = 0; q < PIECES; q++)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                         :: "s"(ring + req_off + (uint32_t)q * 1024u), "v"(lane16), "s"(g + q * 1024) : "memory");
-        req_row += (int64_t)P * 8;
-        req_e--;
-        req_off += row_bytes;
+        for (int u = 0; u < BATCH; u++) {
+            if (req_left > 0) {
+                const char *g = req_row + (int64_t)(req_e & ~1) * 8;
+#pragma unroll
+                for (int q = 0; q < PIECES; q++)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                                 :: "s"(ring + req_off + (uint32_t)q * 1024u), "v"(lane16), "s"(g + q * 1024) : "memory");
+                req_row += (int64_t)P * 8;
+                req_e--;
+                req_left--;
+            }
+            req_off += row_bytes;
+        }
         if (req_off == ring_bytes) req_off = 0;
     };
     if (wave == 0)
-        for (int j = 0; j < min(AHEAD, nsteps); j++) request();
+        for (int k = 0; k < NB - 1; k++) request_batch();
     double acc[LD_COL_B];
 #pragma unroll
     for (int q = 0; q < LD_COL_B; q++) acc[q] = 0.0;
-    uint32_t rd_addr = ring + (uint32_t)tl * 8u, rd_end = rd_addr + ring_bytes;     // this thread's element of row j, even step
-    uint32_t odd = (uint32_t)(W - 1) & 1u;                                             // (W-1-j) & 1
-    for (int j = 0; j < nsteps; j++) {
+    uint32_t rd_addr = ring + (uint32_t)tl * 8u;                 // this thread's element of the batch's first row, even step
+    const uint32_t rd_end = rd_addr + ring_bytes;
+    uint32_t odd = (uint32_t)(W - 1) & 1u;                        // (W-1-j) & 1 of the batch's first row (BATCH is even)
+    static_assert(BATCH % 2 == 0, "the parity of W-1-j repeats per batch");
+    for (int k = 0; k < nbatches; k++) {
         if (wave == 0) {
-            // requests retire in order: all but those of the rows issued after row j have landed
-            if (nsteps - 1 - j >= AHEAD - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEADY) : "memory");
-            else ld_col_wait((nsteps - 1 - j) * PIECES);
+            // requests retire in order: all but those of the batches requested after batch k have landed
+            // (exactly: a larger count would let the wait pass before batch k is complete)
+            const int rows_later = min(nsteps, (k + NB - 1) * BATCH) - (k + 1) * BATCH;   // rows of the batches k+1 .. k+NB-2
+            if (rows_later == (NB - 2) * BATCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEADY) : "memory");
+            else ld_col_wait(max(rows_later, 0) * PIECES);
         }
-        __syncthreads();       // row j is in the ring; everybody is done with row j - 1 (its slot is written next at the earliest)
-        if (wave == 0 && j + AHEAD < nsteps) request();
-        double h;              // hr2(s0 + j, s0 + tl)
-        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(h) : "v"(rd_addr + odd * 8u) : "memory");
-        rd_addr += row_bytes;
+        __syncthreads();       // batch k is in the ring; everybody is done with batch k - 1 (its part is written next)
+        if (wave == 0) request_batch();
+        const int j0 = k * BATCH;
+        double h[BATCH];       // hr2(s0 + j, s0 + tl), j = j0 ..
+#pragma unroll
+        for (int u = 0; u < BATCH; u++)
+            asm volatile("ds_read_b64 %0, %1" : "=v"(h[u]) : "v"(rd_addr + (uint32_t)u * row_bytes + ((odd ^ (uint32_t)(u & 1)) * 8u)) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        rd_addr += BATCH * row_bytes;
         if (rd_addr == rd_end) rd_addr -= ring_bytes;
-        odd ^= 1u;
-        const bool leaving = j >= W;
-        ld_col_adds(acc, h, leaving,                                     // entering: q = min(j, 31) .. 0
-                    leaving ? j - W + 1 : (j < LD_COL_B - 1 ? LD_COL_B - 1 - j : 0));   // leaving: q = j-W+1 .. 31
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {
+            const int j = j0 + u;
+            if (j < nsteps) {
+                const bool leaving = j >= W;
+                ld_col_adds(acc, h[u], leaving,                                 // entering: q = min(j, 31) .. 0
+                            leaving ? j - W + 1 : (j < LD_COL_B - 1 ? LD_COL_B - 1 - j : 0));   // leaving: q = j-W+1 .. 31
+            }
+        }
     }
 #pragma unroll
     for (int q = 0; q < LD_COL_B; q++) {
@@ -685,6 +708,7 @@ ld_sum_col_kernel(const double *__restrict__ C, const LdSumChr *__restrict__ chr
     if (!D) return;
     __syncthreads();                                          // the row ring is not read any more
     double *tile = ld_rows;
+    const int nthreads = blockDim.x;
     for (int q0 = 0; q0 < LD_COL_B; q0 += 16) {
 #pragma unroll
         for (int u = 0; u < 16; u++)
