@@ -1763,8 +1763,10 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
         if ((rc = d_loc.reserve((size_t)p->nloci * 2)) || (rc = d_pair.reserve(npair))) return done(rc);
         loc = d_loc.p; pair = d_pair.p;
     }
+    // pair counts: LDS-tiled (thread = distance, W - 1 <= 256; writes every entry of the table) or streamed from L2
+    const bool pair_tiled = winsize - 1 <= 256 && !getenv("GARLIC_LD_PAIR_L2");
     hipError_t e = hipMemcpyAsync(d_sub.p, sub.data(), sizeof(uint64_t) * nblk, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemsetAsync(pair, 0, sizeof(int32_t) * npair, s);
+    if (e == hipSuccess && !pair_tiled) e = hipMemsetAsync(pair, 0, sizeof(int32_t) * npair, s);
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
     if (phased)
         hipLaunchKernelGGL(ld_planes_kernel<true>, dim3((unsigned)p->nwordrows), dim3(256), 0, s, p->d_packed.p,
@@ -1772,8 +1774,6 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
     else
         hipLaunchKernelGGL(ld_planes_kernel<false>, dim3((unsigned)p->nwordrows), dim3(256), 0, s, p->d_packed.p,
                            p->nwordrows, nblk, d_sub.p, p->nloci, d_m.p, d_h.p, (uint64_t *)nullptr, loc);
-    // pair counts: LDS-tiled (thread = distance, W - 1 <= 256) or streamed from L2
-    const bool pair_tiled = winsize - 1 <= 256 && !getenv("GARLIC_LD_PAIR_L2");
     const int pair_threads = (winsize - 1 + WAVE - 1) / WAVE * WAVE;
     const size_t pair_lds = sizeof(uint64_t) * (phased ? 4 : 2) * LD_PAIR_BLK * (LD_PAIR_T + winsize - 1);
     if (pair_tiled && pair_lds > 48 * 1024) {
@@ -1860,7 +1860,16 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
         if ((rc = d_ld.reserve(n))) return done(rc);
         ld = d_ld.p;
     }
-    if (e == hipSuccess) e = hipMemsetAsync(ld, 0, sizeof(double) * n, s);   // initLDData zero-fills
+    // initLDData zero-fills; ld_sum_col_kernel writes every entry of the window starts that have a full window, which
+    // leaves the last W - 1 rows of each chromosome
+    if (by_snp) {
+        for (int c = 0; c < p->nchr && e == hipSuccess; c++) {
+            const int64_t lo = p->chr_off[c], hi = p->chr_off[c + 1], from = std::max(lo, hi - winsize + 1);
+            if (hi > from) e = hipMemsetAsync(ld + from * winsize, 0, sizeof(double) * (size_t)(hi - from) * winsize, s);
+        }
+    } else {
+        e = hipMemsetAsync(ld, 0, sizeof(double) * n, s);
+    }
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
     if (phased) {       // r2 takes FreqData::freq where hr2 takes homFreq (garlic-data.cpp:587-588)
         e = hipMemcpyAsync(d_hf.p, p->freq.data(), sizeof(double) * p->nloci, hipMemcpyHostToDevice, s);

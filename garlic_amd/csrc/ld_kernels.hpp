@@ -225,8 +225,12 @@ ld_pair_tiled_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__rest
 #pragma unroll
         for (int q = 0; q < LD_PAIR_T; q++) {
             if (q >= ni) continue;
-            pair[((i0 + q) * W + d) * 2 + 0] = tot[q];           // pairs leaving the chromosome stay 0
+            pair[((i0 + q) * W + d) * 2 + 0] = tot[q];           // pairs leaving the chromosome: 0
             pair[((i0 + q) * W + d) * 2 + 1] = hab[q];
+            if (d == 1) {                                        // d = 0 is not a pair: 0 (the table needs no zero-fill)
+                pair[((i0 + q) * W) * 2 + 0] = 0;
+                pair[((i0 + q) * W) * 2 + 1] = 0;
+            }
         }
     }
 }
