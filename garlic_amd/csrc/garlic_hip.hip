@@ -1649,12 +1649,21 @@ int garlic_panel_set_phase(garlic_panel *p, const uint8_t *first_copy, int64_t l
 // the skewed reciprocals D[l][j] = 1 / LD[l - j][j]: the weights SNP l has in the windows that contain it as one
 // contiguous row (tuned wLOD kernels); rows past the panel stay 0 (SKEW_FRONT doubles of zero padding in front:
 // the kernels' first steps read up to 15 elements before a row)
-static int reserve_skew(garlic_panel *p, int32_t winsize)
+// zero: clear it (skew_reciprocal_kernel's caller).  ld_sum_col_kernel writes every weight a scored window reads; what it
+// leaves alone only ever reaches windows that have no score (they are computed along and written as MISSING), so its
+// caller clears just the padding behind the panel, which the last windows' loads run into.
+static int reserve_skew(garlic_panel *p, int32_t winsize, bool zero = true)
 {
     int rc;
     const size_t nskew = SKEW_FRONT + ((size_t)p->nloci + winsize + 64) * winsize;
     if ((rc = p->d_skew.reserve(nskew))) return rc;
-    HIP_TRY(hipMemsetAsync(p->d_skew.p, 0, sizeof(double) * nskew, p->ctx->stream));
+    if (zero) {
+        HIP_TRY(hipMemsetAsync(p->d_skew.p, 0, sizeof(double) * nskew, p->ctx->stream));
+    } else {
+        HIP_TRY(hipMemsetAsync(p->d_skew.p, 0, sizeof(double) * SKEW_FRONT, p->ctx->stream));
+        const size_t body = SKEW_FRONT + (size_t)p->nloci * winsize;
+        HIP_TRY(hipMemsetAsync(p->d_skew.p + body, 0, sizeof(double) * (nskew - body), p->ctx->stream));
+    }
     return GARLIC_OK;
 }
 
@@ -1887,7 +1896,7 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
         sum_blocks += (nstarts + sum_b - 1) / sum_b;
     }
     if (tiled && (rc = d_sum_chrs.reserve(std::max<size_t>(sum_chrs.size(), 1)))) return done(rc);
-    if (by_snp && (rc = reserve_skew(p, winsize))) return done(rc);      // the sum kernel writes the wLOD weights as well
+    if (by_snp && (rc = reserve_skew(p, winsize, false))) return done(rc);      // the sum kernel writes the wLOD weights as well
     for (int c = 0; c < p->nchr; c++) {
         const int64_t lo = p->chr_off[c], hi = p->chr_off[c + 1];
         const size_t hr2_lds = sizeof(double) * (LD_HR2_T + winsize + (size_t)LD_HR2_T * (winsize + 1));
