@@ -615,6 +615,7 @@ int ensure_gl_terms(garlic_panel *p, bool scaled = false, int32_t M = 0, double 
     hipStream_t s = p->ctx->stream;
     int rc;
     const bool rebuild = !p->glterms_valid || p->glterms_scaled;   // the raw terms have to be made (again)
+    bool fused_scale = false;                                       // ... and were scaled in the same pass
     if (p->gl_cont && rebuild) {
         if (p->gl_vals_dropped)
             return fail(GARLIC_ERR_STATE, "the likelihoods of this panel were converted to terms in place (no room for "
@@ -684,16 +685,35 @@ int ensure_gl_terms(garlic_panel *p, bool scaled = false, int32_t M = 0, double 
         }
         if ((rc = p->d_glterms.reserve(n))) return rc;
         p->glterms_valid = false;
-        HIP_TRY(hipMemsetAsync(p->d_glterms.p, 0, sizeof(double) * n, s));
+        // pad rows in front of and behind each block's SNPs: 0.0, the term of a missing genotype (the kernel writes the rest)
+        for (int64_t b = 0; b < p->nind_pad / WAVE; b++) {
+            HIP_TRY(hipMemsetAsync(p->d_glterms.p + (size_t)b * rows * WAVE, 0, sizeof(double) * GOFF * WAVE, s));
+            HIP_TRY(hipMemsetAsync(p->d_glterms.p + ((size_t)b * rows + GOFF + p->nloci) * WAVE, 0,
+                                   sizeof(double) * (size_t)(rows - GOFF - p->nloci) * WAVE, s));
+        }
         VariantArgs a{p->d_packed.p, nullptr, p->d_tabgl.p, p->d_codes.p, nullptr, nullptr, nullptr, nullptr, nullptr,
                       p->nind_pad, p->nwordrows, 0, 0, 0, (int32_t)p->gl_values.size(), 1, nullptr, 0};
+        const size_t terms_lds = sizeof(double) * GL_TERMS_S * 4 * (size_t)a.ncodes;      // <= 64 KB (256 codes)
+        if (!getenv("GARLIC_GL_TERMS_GATHER")) {
+            if (terms_lds > 48 * 1024)
+                HIP_TRY(hipFuncSetAttribute((const void *)gl_terms_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)terms_lds));
+            // (the weighted kernel's scores in the same pass when that is what is asked for)
+            hipLaunchKernelGGL(gl_terms_lds_kernel, dim3((unsigned)((p->nloci + GL_TERMS_S - 1) / GL_TERMS_S)), dim3(256), terms_lds, s,
+                               a, p->nloci, rows, (int)(p->nind_pad / WAVE), scaled ? p->d_decay.p : (const double *)nullptr,
+                               p->d_glterms.p);
+            fused_scale = scaled;
+        } else
         hipLaunchKernelGGL(gl_terms_kernel, dim3((unsigned)((p->nloci + 63) / 64), (unsigned)(p->nind_pad / WAVE)),
                            dim3(256), 0, s, a, p->nloci, rows, p->d_glterms.p);
         HIP_TRY(hipGetLastError());
         p->glterms_scaled = false;
         p->gl_terms_by = 0;
     }
-    if (scaled) {
+    if (scaled && fused_scale) {
+        p->glterms_scaled = true;
+        p->glterms_M = M;
+        p->glterms_mu = mu;
+    } else if (scaled) {
         hipLaunchKernelGGL(gl_scale_kernel, dim3(4096), dim3(256), 0, s, p->d_glterms.p, p->d_decay.p, rows,
                            (int64_t)(p->nind_pad / WAVE));
         HIP_TRY(hipGetLastError());

@@ -224,6 +224,45 @@ gl_terms_kernel(VariantArgs p, int64_t nloci, int64_t rows, double *__restrict__
     }
 }
 
+// The same pass with the SNPs' table rows staged in LDS.  gl_terms_kernel gathers each term from the
+// ncodes x 32 B row of its SNP in global memory -- up to 15 cache lines per wave and SNP, for every one of the
+// panel's 64-individual blocks again (88.9 ms at 10M SNPs x 1250, where the 9.25 B per genotype it moves would
+// take 22).  Here a workgroup owns GL_TERMS_S SNPs for ALL blocks: their rows come in once, coalesced, and the
+// look-ups are LDS reads.  Dynamic LDS: GL_TERMS_S * ncodes * 4 doubles.
+constexpr int GL_TERMS_S = 8;            // SNPs per workgroup: half a genotype word
+__global__ void __launch_bounds__(256)
+gl_terms_lds_kernel(VariantArgs p, int64_t nloci, int64_t rows, int nblk, const double *__restrict__ decay,
+                    double *__restrict__ terms)
+{
+    extern __shared__ double gl_rows[];                      // [GL_TERMS_S][ncodes][4]
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    const int64_t l0 = (int64_t)blockIdx.x * GL_TERMS_S;     // unpadded; GOFF is a multiple of 16, so l0 + GOFF is one of 8
+    const int ns = (int)min<int64_t>(GL_TERMS_S, nloci - l0);
+    const int64_t G0 = GOFF + l0;
+    const int row_doubles = p.ncodes * 4;
+    // decay != NULL: the scores of the weighted kernel straight away, (term * nomut) * norec as gl_scale_kernel makes
+    // them (the same two multiplications, here on the table row: 4 * ncodes values instead of one per genotype)
+    for (int e = threadIdx.x; e < ns * row_doubles; e += blockDim.x) {
+        const double t = p.tabgl[G0 * row_doubles + e];
+        const int64_t G = G0 + e / row_doubles;
+        gl_rows[e] = decay ? (t * decay[2 * G]) * decay[2 * G + 1] : t;
+    }
+    __syncthreads();
+    const int shift0 = 2 * (int)(G0 & 15);                   // 0 or 16: the chunk is one half of a genotype word
+    for (int blk = wave; blk < nblk; blk += 4) {
+        const int64_t col = (int64_t)blk * WAVE + lane;
+        const uint32_t word = p.packed[packed_index(G0 >> 4, col, p.nwordrows)] >> shift0;
+        uint32_t code[GL_TERMS_S];
+#pragma unroll
+        for (int u = 0; u < GL_TERMS_S; u++) code[u] = u < ns ? p.codes[(G0 + u) * p.nind_pad + col] : 0u;
+#pragma unroll
+        for (int u = 0; u < GL_TERMS_S; u++)
+            if (u < ns)
+                terms[((int64_t)blk * rows + G0 + u) * WAVE + lane] =
+                    gl_rows[(u * p.ncodes + (int)code[u]) * 4 + (int)((word >> (2 * u)) & 3u)];
+    }
+}
+
 // ---- Continuous likelihoods (--gl-type GL / PL: more distinct values than a dictionary holds).
 // The error probabilities live in the term matrix's layout, vals[blk][rows][64]; the terms come from
 // lod() evaluated on the device with glibc's log10 restated (tgls_math.hpp).
