@@ -640,15 +640,19 @@ int ensure_gl_terms(garlic_panel *p, bool scaled = false, int32_t M = 0, double 
         double *dst = separate ? p->d_glterms.p : p->d_glval.p;
         p->glterms_valid = false;
         const bool on_host = p->ctx->log10_state < 0 || getenv("GARLIC_TGLS_HOST_TERMS");
-        if (separate)   // pad rows of the term matrix: +0.0
-            HIP_TRY(hipMemsetAsync(dst, 0, sizeof(double) * n, s));
+        DevBuf<unsigned long long> d_minbits;
         if (on_host) {
+            if (separate)   // pad rows of the term matrix: +0.0
+                HIP_TRY(hipMemsetAsync(dst, 0, sizeof(double) * n, s));
             if ((rc = build_terms_on_host(p, p->d_glval.p, dst))) return rc;
         } else {
-            // all rows, pad rows included: their frequency is 0 and their genotypes code 3 -> +0.0
+            // all rows, pad rows included: their frequency is 0 and their genotypes code 3 -> +0.0; the most negative
+            // finite term (lod_exact_needed) is collected along the way
+            if ((rc = d_minbits.reserve(GL_MIN_SLOTS))) return rc;
+            HIP_TRY(hipMemsetAsync(d_minbits.p, 0, sizeof(unsigned long long) * GL_MIN_SLOTS, s));
             hipLaunchKernelGGL(gl_terms_cont_kernel, dim3((unsigned)((rows + 63) / 64), (unsigned)(p->nind_pad / WAVE)),
                                dim3(256), 0, s, p->d_packed.p, p->nwordrows, p->d_freq.p, p->ctx->d_logtab.p, p->d_glval.p,
-                               (int64_t)0, rows, rows, dst);
+                               (int64_t)0, rows, rows, dst, d_minbits.p);
             HIP_TRY(hipGetLastError());
         }
         if (!separate) {   // the term matrix takes the buffer over
@@ -660,7 +664,15 @@ int ensure_gl_terms(garlic_panel *p, bool scaled = false, int32_t M = 0, double 
         }
         p->gl_terms_by = on_host ? 2 : 1;
         p->glterms_scaled = false;
-        {   // most negative finite term, for lod_exact_needed
+        if (!on_host) {
+            unsigned long long bits[GL_MIN_SLOTS], best = 0;
+            hipError_t e = hipMemcpyAsync(bits, d_minbits.p, sizeof bits, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            d_minbits.release();
+            if (e != hipSuccess) return fail(GARLIC_ERR_HIP, "term minimum: %s", hipGetErrorString(e));
+            for (unsigned long long b : bits) best = std::max(best, b);
+            p->glterms_min = best ? f64_from_bits(best) : 0.0;
+        } else {   // most negative finite term, for lod_exact_needed
             constexpr int NB = 1024;
             DevBuf<double> d_part;
             if ((rc = d_part.reserve(NB))) return rc;
