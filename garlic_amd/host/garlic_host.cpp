@@ -1328,27 +1328,68 @@ DoubleData *convertSubsetWinData2DoubleData(std::vector<WinData *> *wins, const 
     return d;
 }
 
+// one gzip member holding `text` (members may simply follow each other in a .gz file)
+static std::string gzip_member(const std::string &text)
+{
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw -1;
+    std::string out;
+    out.resize(deflateBound(&z, (uLong)text.size()) + 64);
+    z.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(text.data()));
+    z.avail_in = (uInt)text.size();
+    z.next_out = reinterpret_cast<Bytef *>(&out[0]);
+    z.avail_out = (uInt)out.size();
+    const int rc = deflate(&z, Z_FINISH);
+    out.resize(out.size() - z.avail_out);
+    deflateEnd(&z);
+    if (rc != Z_STREAM_END) throw -1;
+    return out;
+}
+
+// The reference's text (garlic-data.cpp:1722-1745: one line per individual, "NA" for MISSING, operator<<'s six
+// significant digits = printf's %g), written the way a GPU-sized panel needs it: the individuals' lines are formatted and
+// compressed on all host cores, a few lines per gzip member, and appended in order (formatted through one
+// ostringstream and one gz stream, 20 M values took 8 s).
 void writeWinData(std::vector<WinData *> *wins, IndData *indData, std::vector<MapData *> *maps,
                   const std::string &outfile)
 {
+    const unsigned nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
     for (size_t c = 0; c < maps->size(); c++) {
         const std::string path = outfile + "." + indData->pop + "." + maps->at(c)->chr + ".raw.lod.windows.gz";
-        gzFile f = gzopen(path.c_str(), "wb");
+        FILE *f = fopen(path.c_str(), "wb");
         if (!f) { std::cerr << "ERROR: Failed to open " << path << " for writing.\n"; throw -1; }
         const WinData *w = wins->at(c);
-        std::ostringstream row;
-        for (int i = 0; i < w->nind; i++) {
-            row.str("");
-            for (int l = 0; l < w->nloci; l++) {
-                if (w->data[i][l] == MISSING) row << "NA"; // garlic-data.cpp:1736
-                else row << w->data[i][l];                  // default precision: 6 significant digits
-                if (l < w->nloci - 1) row << " ";
-            }
-            row << "\n";
-            const std::string s = row.str();
-            gzwrite(f, s.data(), (unsigned)s.size());
+        // rows per member: ~4 MB of text each; a wave of members = one per thread
+        const int per = std::max(1, (int)(((size_t)4 << 20) / ((size_t)std::max(1, w->nloci) * 8 + 1)));
+        for (int i0 = 0; i0 < w->nind; i0 += per * (int)nthreads) {
+            const int ntasks = std::min<int>((int)nthreads, (w->nind - i0 + per - 1) / per);
+            std::vector<std::string> members((size_t)ntasks);
+            std::vector<std::thread> pool;
+            bool failed = false;
+            for (int t = 0; t < ntasks; t++)
+                pool.emplace_back([&, t]() {
+                    std::string text;
+                    text.reserve((size_t)per * ((size_t)w->nloci * 9 + 1));
+                    char buf[40];
+                    const int a = i0 + t * per, b = std::min(w->nind, a + per);
+                    for (int i = a; i < b; i++) {
+                        for (int l = 0; l < w->nloci; l++) {
+                            if (w->data[i][l] == MISSING) text += "NA";               // garlic-data.cpp:1736
+                            else text.append(buf, (size_t)snprintf(buf, sizeof buf, "%g", w->data[i][l]));
+                            if (l < w->nloci - 1) text += ' ';
+                        }
+                        text += '\n';
+                    }
+                    try { members[(size_t)t] = gzip_member(text); } catch (...) { failed = true; }
+                });
+            for (auto &th : pool) th.join();
+            if (failed) { fclose(f); std::cerr << "ERROR: Failed to compress " << path << "\n"; throw -1; }
+            for (const std::string &m : members)
+                if (fwrite(m.data(), 1, m.size(), f) != m.size()) { fclose(f); std::cerr << "ERROR: Failed to write " << path << "\n"; throw -1; }
         }
-        gzclose(f);
+        if (w->nind == 0) { const std::string m = gzip_member(""); fwrite(m.data(), 1, m.size(), f); }
+        fclose(f);
         std::cerr << "Wrote " << path << "\n";
     }
 }
