@@ -1176,23 +1176,26 @@ roh_coverage_kernel(const double *__restrict__ scores, const ChrDev *__restrict_
     const int halo = W - 1;
     const int first = seg0 - halo;                      // window index of pre[1]
     const int n = halo + min(COV_SEG, c.nloci - seg0);  // windows looked at
-    // each thread marks a contiguous chunk, then the chunks are chained
-    const int per = (n + COV_THREADS - 1) / COV_THREADS;
-    const int lo = threadIdx.x * per, hi = min(n, lo + per);
+    // each wave marks a contiguous quarter, 64 consecutive windows per step (coalesced 512-B reads; a thread per
+    // contiguous chunk read a line nine times over), counting along with ballots; then the quarters are chained
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    const int per = ((n + 3) / 4 + WAVE - 1) / WAVE * WAVE;     // windows per wave, whole steps
+    const int lo = wave * per, hi = min(n, lo + per);
     int cnt = 0;
-    for (int k = lo; k < hi; k++) {
-        const int w = first + k;
-        const bool q = (w >= 0) && (row[w] >= cutoff);  // NaN >= x is false
-        cnt += q ? 1 : 0;
-        pre[k + 1] = cnt;
+    for (int k0 = lo; k0 < hi; k0 += WAVE) {
+        const int k = k0 + lane, w = first + k;
+        const bool q = (k < hi) && (w >= 0) && (row[w] >= cutoff);  // NaN >= x is false
+        const uint64_t m = __ballot(q);
+        if (k < hi) pre[k + 1] = cnt + __popcll(m & (((uint64_t)2 << lane) - 1));   // inclusive count
+        cnt += __popcll(m);
     }
-    part[threadIdx.x] = cnt;
+    if (lane == 0) part[wave] = cnt;
     if (threadIdx.x == 0) pre[0] = 0;
     __syncthreads();
     int offset = 0;
-    for (int t = 0; t < (int)threadIdx.x; t++) offset += part[t];
-    __syncthreads();
-    for (int k = lo; k < hi; k++) pre[k + 1] += offset;
+    for (int t = 0; t < wave; t++) offset += part[t];
+    if (offset)
+        for (int k = lo + lane; k < hi; k += WAVE) pre[k + 1] += offset;
     __syncthreads();
     int16_t *orow = inwin + oc.out_base + (int64_t)ind * oc.out_pitch;
     for (int k = halo + (int)threadIdx.x; k < n; k += COV_THREADS) {
