@@ -3,9 +3,13 @@
 // containers hold, before and after the site filter.
 #include "../../garlic_amd/host/garlic_host.hpp"
 
+#include <zlib.h>
+
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <sstream>
 
 using namespace garlic_host;
 
@@ -86,6 +90,63 @@ int main(int argc, char **argv)
         releaseHapData(h); releaseHapData(hp); releaseHapData(hs);
         releaseMapData(m); releaseMapData(mp); releaseMapData(ms);
         releaseFreqData(f); releaseFreqData(fp); releaseFreqData(fs);
+        // writeWinData: the text (inflated, members concatenated) is what one ostringstream per line gives --
+        // garlic-data.cpp:1722-1745 -- for ordinary, MISSING, NaN, infinite and tiny values; many lines per gzip
+        // member (narrow chromosome) and many members (wide one)
+        {
+            const int nind = 37, sizes[2] = {5, 200000};
+            std::vector<MapData *> wm;
+            std::vector<WinData *> ww;
+            IndData ind;
+            ind.pop = "popX";
+            ind.nind = nind;
+            ind.indID = nullptr;
+            uint64_t x = 88172645463325252ull;
+            for (int c = 0; c < 2; c++) {
+                MapData *m = new MapData;
+                m->physicalPos = nullptr; m->geneticPos = nullptr; m->locusName = nullptr; m->allele = nullptr;
+                m->nloci = sizes[c];
+                m->chr = c == 0 ? "7" : "X";
+                wm.push_back(m);
+                WinData *w = initWinData(nind, sizes[c]);
+                for (int i = 0; i < nind; i++)
+                    for (int l = 0; l < sizes[c]; l++) {
+                        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+                        double v = ((double)(x >> 11) / 9007199254740992.0 - 0.5) * ((x & 7) == 0 ? 1e-7 : 2000.0);
+                        if ((x & 1023) == 1) v = MISSING;
+                        if ((x & 1023) == 2) v = std::nan("");
+                        if ((x & 1023) == 3) v = -std::nan("");
+                        if ((x & 1023) == 4) v = -INFINITY;
+                        if ((x & 1023) == 5) v = -0.0;
+                        w->data[i][l] = v;
+                    }
+                ww.push_back(w);
+            }
+            const std::string base = std::string(argv[4]) + "/rawlod";
+            writeWinData(&ww, &ind, &wm, base);
+            for (int c = 0; c < 2; c++) {
+                const std::string path = base + ".popX." + wm[c]->chr + ".raw.lod.windows.gz";
+                gzFile f = gzopen(path.c_str(), "rb");
+                CHECK(f != nullptr);
+                std::string got;
+                static char buf[1 << 16];
+                int n;
+                while ((n = gzread(f, buf, sizeof buf)) > 0) got.append(buf, (size_t)n);
+                gzclose(f);
+                std::ostringstream want;
+                for (int i = 0; i < nind; i++) {
+                    for (int l = 0; l < sizes[c]; l++) {
+                        if (ww[c]->data[i][l] == MISSING) want << "NA";
+                        else want << ww[c]->data[i][l];
+                        if (l < sizes[c] - 1) want << " ";
+                    }
+                    want << "\n";
+                }
+                CHECK(got == want.str());
+                releaseWinData(ww[c]);
+                delete wm[c];
+            }
+        }
     } catch (...) {
         std::cerr << "FAILED: exception\n";
         return 1;
