@@ -594,20 +594,51 @@ std::vector<FreqData *> *readFreqData(const std::string &freqfile, std::vector<M
     return out;
 }
 
+static std::string gzip_member(const std::string &text);
+
+// The reference's table (garlic-data.cpp:790-826; default ostream formatting = 6 significant digits = %g), lines
+// formatted and compressed on all host cores, 100k lines per gzip member, appended in order.
 void writeFreqData(const std::string &freqOutfile, std::vector<FreqData *> *freqs, std::vector<MapData *> *maps)
 {
     const std::string path = freqOutfile + ".gz";
-    gzFile f = gzopen(path.c_str(), "wb");
+    FILE *f = fopen(path.c_str(), "wb");
     if (!f) fail("Failed to open " + path);
-    gzprintf(f, "CHR\tSNP\tPOS\tALLELE\tFREQ\n");
+    struct Chunk { size_t c; int l0, l1; };
+    std::vector<Chunk> chunks;
     for (size_t c = 0; c < maps->size(); c++)
-        for (int l = 0; l < maps->at(c)->nloci; l++) {
-            std::ostringstream v; // default ostream formatting = 6 significant digits, like the reference
-            v << freqs->at(c)->freq[l];
-            gzprintf(f, "%s\t%s\t%d\t%c\t%s\n", maps->at(c)->chr.c_str(), maps->at(c)->locusName[l].c_str(),
-                     maps->at(c)->physicalPos[l], maps->at(c)->allele[l], v.str().c_str());
-        }
-    gzclose(f);
+        for (int l0 = 0; l0 < maps->at(c)->nloci; l0 += 100000)
+            chunks.push_back(Chunk{c, l0, std::min(maps->at(c)->nloci, l0 + 100000)});
+    const unsigned nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    bool failed = false;
+    {
+        const std::string m = gzip_member("CHR\tSNP\tPOS\tALLELE\tFREQ\n");
+        failed = fwrite(m.data(), 1, m.size(), f) != m.size();
+    }
+    for (size_t k0 = 0; k0 < chunks.size() && !failed; k0 += nthreads) {
+        const size_t n = std::min<size_t>(nthreads, chunks.size() - k0);
+        std::vector<std::string> members(n);
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < n; t++)
+            pool.emplace_back([&, t]() {
+                const Chunk ch = chunks[k0 + t];
+                const MapData *m = maps->at(ch.c);
+                const double *fr = freqs->at(ch.c)->freq;
+                std::string text;
+                text.reserve((size_t)(ch.l1 - ch.l0) * 48);
+                char num[64];
+                for (int l = ch.l0; l < ch.l1; l++) {
+                    text += m->chr; text += '\t';
+                    text += m->locusName[l]; text += '\t';
+                    text.append(num, (size_t)snprintf(num, sizeof num, "%d\t%c\t%g\n", m->physicalPos[l], m->allele[l], fr[l]));
+                }
+                try { members[t] = gzip_member(text); } catch (...) { failed = true; }
+            });
+        for (auto &th : pool) th.join();
+        for (const std::string &m : members)
+            if (!failed && fwrite(m.data(), 1, m.size(), f) != m.size()) failed = true;
+    }
+    fclose(f);
+    if (failed) fail("Failed to write " + path);
 }
 
 namespace {
