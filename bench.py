@@ -271,6 +271,17 @@ def leg_ns(ctx, dev, steps):
     dt, k = timed_passes(ctx, lambda: panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU, use_gl=True),
                          steps, 1, torch.cuda.synchronize)
     res["wlod_gl"] = dict(rate(k, dt), roofline=fp64_roofline("wlod_strip_gl_kernel", win, W, k))
+    # GARLIC's default --winsize 10 (windows narrower than the kernels' 16-window groups): bound by the scores written
+    W10 = 10
+    t0 = time.perf_counter()
+    panel.compute_ld(W10, want_output=False)
+    ld10 = time.perf_counter() - t0
+    dt, k = timed_passes(ctx, lambda: panel.wlod_windows_device(out.data_ptr(), W10, ERROR, MAX_GAP, M_GEN, MU), steps, 1,
+                         torch.cuda.synchronize)
+    res["wlod_winsize10"] = dict(rate(k, dt), ld_call_ms=ld10 * 1e3,
+                                 roofline=hbm_roofline("wlod_tile_small_kernel", BYTES_LOD * win, k,
+                                                       note="2 * 10 flops per window: the 8 B of score per window bound it"))
+    res["wlod_winsize10"]["lod_windows_per_s"] = win / W10 / (dt / steps)
     panel.close()
     out.free()
     torch.cuda.empty_cache()
