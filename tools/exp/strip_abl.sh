@@ -3,8 +3,6 @@ run() {
   r=$(env $2 timeout -k 10 120 python3 tools/bench_variants.py --snps 2000000 --inds 1280 --winsize ${3:-100} --modes wlodgl --steps 3 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['kernel_ms'], round(d['roofline']['frac'],3))")
   echo "$1 $2 W=${3:-100} | wlodgl 2M x 1280: $r"
 }
-run "pfw1" GARLIC_X=1
-run "pfw1" GARLIC_X=1 200
-GARLIC_WLOD_GLS_PFW=0 python3 tools/gen_wlod_asm.py > /dev/null; make -s -C garlic_amd/csrc 2>&1 | grep error
-run "pfw0" GARLIC_X=1
-run "pfw0" GARLIC_X=1 200
+run "n5" GARLIC_X=1 50
+run "n5" GARLIC_X=1 64
+run "n5" GARLIC_X=1 80
