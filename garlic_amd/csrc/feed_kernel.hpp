@@ -1,0 +1,272 @@
+// Thinned LOD scores for the KDE feed (the explore / auto-winsize flows, src/garlic-roh.cpp:726-751, 798-837,
+// 881-920 -> convertWinData2DoubleData, src/garlic-data.cpp:2026-2069: only the windows at chromosome-local
+// loci 0, step, 2*step, .. are ever looked at).
+//
+// With no score stream to write, the window recurrence (src/garlic-roh.cpp:92-100) is all there is, and the
+// four-role kernel of lod_kernels.hpp -- three helper waves feeding ONE chain wave per CU, built for the
+// store-bound full output -- leaves the machine idle: 35 cycles per window and CU.  Here every wave is a
+// chain of its own and a CU runs sixteen of them:
+//
+//   work item   one run of valid windows x FEED_G 64-individual blocks = one workgroup of FEED_G waves (lane =
+//               individual); persistent workgroups (four per CU) pull items longest run first; the waves of the
+//               longest runs raise their issue priority (s_setprio): the run length x the pace of one wave is
+//               the kernel's critical path, everything shorter fills the issue slots they leave;
+//   term rows   {lod(0), lod(1), lod(2), +0.0} of the 32 entering and of the 32 leaving SNPs of a tile of 32
+//               windows: two 1-KB chunks per tile, each in a 4-slot ring in LDS shared by the workgroup's waves
+//               (tile t in slot (t + 3) % 4), fetched by LDS-DMA three tiles ahead, a quarter per wave; whatever
+//               the window size: 9 KB of LDS;
+//   genotypes   the lane's own packed words straight into registers (one dword per 16 SNPs and stream); the leaving
+//               stream is a second, cache-served read of the same words;
+//   per window  the genotype's term offset for both streams, two ds_read_b64, the two dependent adds
+//               acc = (acc - t_out) + t_in;
+//   samples     a sampled locus is stored straight from the lanes (8 B each into the [individual][sample] matrix).
+//
+// One barrier per tile keeps the FEED_G waves within a tile of each other: the rings' only protocol.  Tile t:
+// barrier | request the chunks of tile t + 3 | the tile | wait for what was requested.
+// Interior tiles (every window a rolling update) go through the hand-scheduled loop of tools/gen_feed_asm.py
+// (feed_loop_gfx950.inc), 4 n tiles at a time from tile 1 on; a run's first tile, its last ones and everything
+// of a shard that does not start on a block boundary through the compiler-generated tile below, which keeps
+// the same protocol.
+#pragma once
+#include "lod_kernels.hpp"
+#include "feed_loop_gfx950.inc"
+
+namespace garlic {
+
+constexpr int FEED_G = 4;                 // waves (64-individual blocks) per workgroup: each moves a quarter of a chunk
+constexpr int FEED_AHEAD = GARLIC_FEED_AHEAD;
+
+struct FeedItem {
+    int32_t chr, a, b;        // run of valid windows [a, b] (chromosome-local)
+    int32_t prio;             // 0..3: issue priority of the item's waves (long runs first)
+    int32_t ind0[FEED_G];     // first individual of each wave's block (relative to ind_begin); -1: none
+};
+
+struct FeedArgs {
+    const uint32_t *packed;   // [nind_pad/64][nwordrows][64]
+    const double *tab;        // [GOFF + nloci + pad][4]
+    const FeedItem *items;
+    const ChrDev *chrs;       // out_base / out_pitch: the thinned matrix
+    double *out;
+    int64_t nwordrows;
+    int32_t ind_begin, ind_count, winsize, n_items, thin_step;
+    int32_t use_asm;          // 0: every tile through the compiler-generated path (GARLIC_FEED_NO_ASM)
+    int32_t *next_item;       // [0] queue head, [1] workgroups that have left (zero at launch, reset by the last)
+    int64_t *trace;           // optional (GARLIC_TRACE): per item {workgroup, begin, tiles begin, end} in 100 MHz ticks + shader clocks
+};
+
+__device__ __forceinline__ void feed_barrier()
+{   // s_barrier alone: __syncthreads() would also wait for every outstanding memory request
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// this wave's quarter (256 B = 8 rows) of a 1-KB chunk of term rows: lane i moves bytes 4 i .. 4 i + 3 of the quarter
+__device__ __forceinline__ void feed_dma_quarter(uint32_t lds_quarter, const double *chunk, uint32_t dma_off)
+{
+    const uint64_t u = reinterpret_cast<uint64_t>(chunk);      // wave-uniform: say so
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    chunk = reinterpret_cast<const double *>(((uint64_t)hi << 32) | lo);
+    lds_quarter = __builtin_amdgcn_readfirstlane(lds_quarter);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+                 :: "s"(lds_quarter), "v"(dma_off), "s"(chunk) : "memory");
+}
+
+// wave-uniform values for the "s" operands of the inline assembly (hipcc passes a VGPR where it has not proven uniformity)
+__device__ __forceinline__ uint32_t feed_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+template <class T> __device__ __forceinline__ T *feed_uni(T *ptr)
+{
+    const uint64_t u = reinterpret_cast<uint64_t>(ptr);
+    return reinterpret_cast<T *>(((uint64_t)feed_uni((uint32_t)(u >> 32)) << 32) | feed_uni((uint32_t)u));
+}
+
+// LDS address of the term of step j (0..15) of a funnel-shifted genotype word: (genotype * 8) | rows
+__device__ __forceinline__ uint32_t feed_addr(uint32_t w, int j, uint32_t rows)
+{
+    const uint32_t x = (2 * j >= 3) ? (w >> (2 * j - 3)) : (w << (3 - 2 * j));
+    uint32_t a;
+    asm("v_and_or_b32 %0, %1, 24, %2" : "=v"(a) : "v"(x), "s"(rows));
+    return a;
+}
+
+__device__ __forceinline__ double feed_lds_double(uint32_t addr)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) double *>((uintptr_t)addr);
+}
+
+__global__ void __launch_bounds__(FEED_G * WAVE, 4)
+lod_feed_kernel(FeedArgs p)
+{
+    // one LDS object at offset 0: the hand-scheduled loop addresses the rings with absolute offsets
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[GARLIC_FEED_LDS_TOTAL];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t dma_off = (uint32_t)lane * 4u + (uint32_t)wave * 256u;
+    // LDS address of smem: 0, the kernel's only LDS object (taking it here also keeps the whole array allocated: most of
+    // it is only ever touched through the integer addresses below and the loop's immediates)
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem);
+    const int W = p.winsize, step = p.thin_step;
+    for (;;) {
+        if (threadIdx.x == 0) *reinterpret_cast<int *>(smem) = atomicAdd(p.next_item, 1);
+        __syncthreads();
+        const int item_idx = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(smem));
+        __syncthreads();   // (also: every wave is done with the previous item's rings)
+        if (item_idx >= p.n_items) {
+            if (threadIdx.x == 0) {
+                __threadfence();
+                if (atomicAdd(p.next_item + 1, 1) == (int)gridDim.x - 1) {
+                    p.next_item[0] = 0;
+                    p.next_item[1] = 0;
+                }
+            }
+            return;
+        }
+        if (p.trace && threadIdx.x == 0) {
+            p.trace[8 * item_idx + 0] = blockIdx.x;
+            p.trace[8 * item_idx + 1] = wall_clock64();
+            p.trace[8 * item_idx + 4] = clock64();
+        }
+        const FeedItem *it = p.items + item_idx;
+        const ChrDev c = p.chrs[it->chr];
+        const int a = it->a, b = it->b, prio = it->prio;
+        if (prio >= 3) __builtin_amdgcn_s_setprio(3);
+        else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        const int ind0 = __builtin_amdgcn_readfirstlane(it->ind0[wave]);   // (indexed in memory: a local copy of the item would live in scratch)
+        const bool active = ind0 >= 0;
+        const int rows_valid = active ? min(WAVE, p.ind_count - ind0) : 0;
+        const int64_t col0 = (int64_t)p.ind_begin + (active ? ind0 : 0);
+        const uint32_t *gcol = p.packed + packed_index(0, col0 + lane, p.nwordrows);
+        const int64_t Gbase = c.loc_base + GOFF;
+
+        const int first = a & ~(TILE - 1);
+        const int ntiles = ((b - first) >> 5) + 1;
+        // term rows: the chunks of tile t are rows first + W - 1 + 32 t .. (entering) and first - 1 + 32 t .. (leaving)
+        const double *lead_chunks = p.tab + (Gbase + first + W - 1) * 4;
+        const double *trail_chunks = p.tab + (Gbase + first - 1) * 4;
+        // (pad rows behind the table and the packed panel make requests past the run's last tile harmless)
+        for (int t = 0; t < FEED_AHEAD; t++) {
+            const uint32_t slot = (uint32_t)((t + 3) & 3) * 1024u + (uint32_t)wave * 256u;
+            feed_dma_quarter(lds0 + GARLIC_FEED_LDS_LEAD + slot, lead_chunks + (int64_t)t * 128, dma_off);
+            feed_dma_quarter(lds0 + GARLIC_FEED_LDS_TRAIL + slot, trail_chunks + (int64_t)t * 128, dma_off);
+        }
+
+        // ---- first window of the run: its first W-1 terms left to right (garlic-roh.cpp:57-71); the W-th
+        //      enters in the first tile.  32 SNPs per round, every load of a round before its first add.
+        double acc = 0.0;
+        if (active) {
+            int l = a;
+            const int lend = a + W - 1;
+            while (l < lend) {
+                const int64_t G = Gbase + l;
+                const int sh = 2 * (int)(G & 15);
+                const uint32_t *wp = gcol + (G >> 4) * WAVE;
+                const uint32_t w0 = wp[0], w1 = wp[WAVE], w2 = wp[2 * WAVE];
+                const uint32_t al[2] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh)};
+                const int n = min(32, lend - l);
+                double t[32];
+#pragma unroll
+                for (int q = 0; q < 32; q++) {
+                    const uint32_t g = (al[q >> 4] >> (2 * (q & 15))) & 3u;
+                    t[q] = p.tab[(G + min(q, n - 1)) * 4 + ((q < n) ? g : 3u)];
+                }
+#pragma unroll
+                for (int q = 0; q < 32; q++) acc += (q < n) ? t[q] : 0.0;
+                l += n;
+            }
+        }
+
+        // ---- streams: entering SNP of window s is s + W - 1, leaving SNP s - 1
+        const int64_t Glead = Gbase + first + W - 1, Gtrail = Gbase + first - 1;
+        const int sh_lead = 2 * (int)(Glead & 15), sh_trail = 2 * (int)(Gtrail & 15);
+        // thinned output: next sampled locus at or after a; its column in the block's rows
+        int next = (a + step - 1) / step * step;
+        double *const out_row0 = p.out + c.out_base + (int64_t)(active ? ind0 : 0) * c.out_pitch;
+        int col = next / step;
+        const bool row_ok = lane < rows_valid;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's quarters of the first chunks
+        if (p.trace && threadIdx.x == 0) {
+            p.trace[8 * item_idx + 2] = wall_clock64();
+            p.trace[8 * item_idx + 5] = clock64();
+        }
+
+        // interior tiles 1 .. k_int (all 32 windows inside (a, b]); the hand-scheduled loop takes 4 n of them
+        const int k_int = (b - first - (TILE - 1)) >> 5;
+        const int niter = (p.use_asm && lds0 == 0 && (col0 & 63) == 0 && k_int >= 1) ? k_int / 4 : 0;
+        for (int k = 0; k < ntiles; k++) {
+            if (k == 1 && niter > 0) {
+                const int s0 = first + TILE;
+                const uint32_t *blk = p.packed + packed_index(0, col0, p.nwordrows);     // the block's word rows (lane 0)
+                const uint32_t *plw = blk + ((Glead + TILE) >> 4) * WAVE;                // word row 0 of tile 1
+                const uint32_t *ptw = blk + ((Gtrail + TILE) >> 4) * WAVE;
+                const double *out_next = out_row0 + col;
+                uint32_t next_rel = (uint32_t)(next - s0);
+                asm volatile(GARLIC_FEED_LOOP_ASM
+                             : [acc] "+v"(acc), [next_out] "=s"(next_rel), [out_out] "=s"(out_next)
+                             : [wave] "s"(wave), [lane] "v"(lane), [active] "s"(feed_uni(active ? 1u : 0u)), [plw] "s"(feed_uni(plw)),
+                               [ptw] "s"(feed_uni(ptw)), [ptl] "s"(feed_uni(lead_chunks + 128)), [ptt] "s"(feed_uni(trail_chunks + 128)),
+                               [out] "s"(feed_uni(out_next)), [next] "s"(feed_uni(next_rel)), [step] "s"(feed_uni((uint32_t)step)),
+                               [shl] "s"(feed_uni((uint32_t)sh_lead)), [sht] "s"(feed_uni((uint32_t)sh_trail)),
+                               [rows] "s"(feed_uni((uint32_t)rows_valid)), [pitch8] "s"(feed_uni((uint32_t)(c.out_pitch * 8))),
+                               [niter] "s"(feed_uni((uint32_t)niter))
+                             : GARLIC_FEED_LOOP_CLOBBERS);
+                k += 4 * niter;
+                next = first + k * TILE + (int)next_rel;
+                col = (int)(out_next - out_row0);
+                if (k >= ntiles) break;
+            }
+            feed_barrier();   // every wave is done with tile k-1; the chunks of tiles <= k + 2 have landed
+            {
+                const uint32_t slot = (uint32_t)((k + FEED_AHEAD + 3) & 3) * 1024u + (uint32_t)wave * 256u;
+                feed_dma_quarter(lds0 + GARLIC_FEED_LDS_LEAD + slot, lead_chunks + (int64_t)(k + FEED_AHEAD) * 128, dma_off);
+                feed_dma_quarter(lds0 + GARLIC_FEED_LDS_TRAIL + slot, trail_chunks + (int64_t)(k + FEED_AHEAD) * 128, dma_off);
+            }
+            if (active) {
+                const int s0 = first + k * TILE;
+                const uint32_t *lw = gcol + ((Glead + (int64_t)k * TILE) >> 4) * WAVE;
+                const uint32_t *tw = gcol + ((Gtrail + (int64_t)k * TILE) >> 4) * WAVE;
+                const uint32_t l0 = lw[0], l1 = lw[WAVE], l2 = lw[2 * WAVE];
+                const uint32_t t0 = tw[0], t1 = tw[WAVE], t2 = tw[2 * WAVE];
+                const uint32_t lead_w[2] = {__builtin_amdgcn_alignbit(l1, l0, sh_lead), __builtin_amdgcn_alignbit(l2, l1, sh_lead)};
+                const uint32_t trail_w[2] = {__builtin_amdgcn_alignbit(t1, t0, sh_trail), __builtin_amdgcn_alignbit(t2, t1, sh_trail)};
+                const uint32_t lead_rows = lds0 + GARLIC_FEED_LDS_LEAD + (uint32_t)((k + 3) & 3) * 1024u;
+                const uint32_t trail_rows = lds0 + GARLIC_FEED_LDS_TRAIL + (uint32_t)((k + 3) & 3) * 1024u;
+#pragma unroll
+                for (int bq = 0; bq < 4; bq++) {
+                    double tin[8], tout[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int j = 8 * bq + i;
+                        tin[i] = feed_lds_double(feed_addr(lead_w[j >> 4], j & 15, lead_rows) + (uint32_t)j * 32u);
+                        tout[i] = feed_lds_double(feed_addr(trail_w[j >> 4], j & 15, trail_rows) + (uint32_t)j * 32u);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int s = s0 + 8 * bq + i;
+                        // the first window of a run is a plain sum (no leaving term); steps outside [a, b] leave the
+                        // accumulator as it is (x - 0.0 + 0.0 == x: it starts at +0.0 and never becomes -0.0)
+                        const double to = (s > a && s <= b) ? tout[i] : 0.0;
+                        const double ti = (s >= a && s <= b) ? tin[i] : 0.0;
+                        acc = (acc - to) + ti;   // two roundings, as garlic-roh.cpp:98-100
+                        if (s == next && s <= b) {
+                            if (row_ok) out_row0[(int64_t)lane * c.out_pitch + col] = acc;
+                            col++;
+                            next += step;
+                        }
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's quarters of the chunks of tile k + 3
+        }
+        if (p.trace && threadIdx.x == 0) {
+            p.trace[8 * item_idx + 3] = wall_clock64();
+            p.trace[8 * item_idx + 6] = clock64();
+            p.trace[8 * item_idx + 7] = ntiles;
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+} // namespace garlic

@@ -11,6 +11,7 @@
 #include "ld_kernels.hpp"
 #include "tgls_ring_kernel.hpp"
 #include "wlod_strip_kernel.hpp"
+#include "feed_kernel.hpp"
 
 #include <algorithm>
 #include <mutex>
@@ -117,6 +118,7 @@ struct garlic_ctx {
     bool own_stream = false;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool async_device = false;   // garlic_ctx_set_async
+    int n_cu = 256;              // compute units of the device (persistent kernels: one or a few workgroups per CU)
     // the dominant kernel of the last HIST calls, one event pair each (asynchronous passes are
     // timed without being waited for one by one): garlic_recent_kernel_ms
     static constexpr int HIST = 32;
@@ -157,6 +159,7 @@ struct garlic_panel {
     DevBuf<int64_t> d_boundaries;
     // per-call scratch
     DevBuf<ChainItem> d_items;
+    DevBuf<FeedItem> d_feed_items;                 // thinned feed: (run, FEED_G blocks) items of lod_feed_kernel
     DevBuf<FillItem> d_fill;
     DevBuf<int32_t> d_counter;
     DevBuf<ChrDev> d_chrs;
@@ -230,8 +233,9 @@ struct garlic_panel {
         int mode = -1;
         int32_t W = 0, max_gap = 0, ind_begin = 0, ind_count = 0, pitch_align = 0;
         size_t n_items = 0, n_fill = 0;
-        bool wlod_fast = false, wlod_strip = false;
+        bool wlod_fast = false, wlod_strip = false, feed_kernel = false;
         int32_t thin_step = 0;
+        size_t n_feed_items = 0;
         uint64_t blocks_hash = 0;                  // 0: every 64-individual block; else a hash of the block subset
         int32_t n_tiles = 0, n_strips = 0;
         int64_t n_runs = 0, n_valid = 0;
@@ -870,6 +874,9 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         if (3 * L.pitch[c] * 8 + 512 >= (int64_t)1 << 32)
             return fail(GARLIC_ERR_INVALID, "chromosome %d too long for 32-bit row offsets", c);
 
+    // Thinned feed: every wave a chain of its own (feed_kernel.hpp); GARLIC_FEED_ROLES: the four-role kernel with the
+    // thinned write-out instead
+    const bool feed_kernel = thin_step > 0 && !getenv("GARLIC_FEED_ROLES");
     uint64_t blocks_hash = 0;
     if (blocks) {
         blocks_hash = 0xCBF29CE484222325ull;
@@ -879,14 +886,16 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     const bool reuse = p->plan.valid && p->plan.blocks_hash == blocks_hash && p->plan.mode == (int)mode && p->plan.W == W &&
                        p->plan.max_gap == max_gap && p->plan.ind_begin == ind_begin &&
                        p->plan.ind_count == ind_count && p->plan.pitch_align == pitch_align &&
-                       p->plan.wlod_fast == wlod_fast && p->plan.thin_step == thin_step && p->plan.wlod_strip == wlod_gl_strip;
+                       p->plan.wlod_fast == wlod_fast && p->plan.thin_step == thin_step && p->plan.wlod_strip == wlod_gl_strip &&
+                       p->plan.feed_kernel == feed_kernel;
     const int nblk = (ind_count + WAVE - 1) / WAVE;
     std::vector<Run> runs;
     std::vector<FillItem> fill;
     std::vector<ChainItem> items;
+    std::vector<FeedItem> feed_items;
     std::vector<ChrDev> chrs;
     int64_t n_valid = p->plan.n_valid;
-    size_t n_items = p->plan.n_items, n_fill = p->plan.n_fill;
+    size_t n_items = p->plan.n_items, n_fill = p->plan.n_fill, n_feed_items = p->plan.n_feed_items;
     int64_t n_runs = p->plan.n_runs;
     if (!reuse) {
         plan_runs(p, W, runs, fill, n_valid);
@@ -902,6 +911,26 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
             const Run &r = runs[order[i]];
             for (int k = 0; k < nblk; k++)
                 if (!blocks || (*blocks)[(size_t)k]) items.push_back(ChainItem{r.chr, r.a, r.b, k * WAVE});
+        }
+        if (feed_kernel) {
+            // (run, FEED_G blocks) items, longest runs first; the runs within reach of the longest one run at raised
+            // issue priority: their length x one wave's pace is the kernel's critical path
+            std::vector<int> blk;
+            for (int k = 0; k < nblk; k++)
+                if (!blocks || (*blocks)[(size_t)k]) blk.push_back(k);
+            const int longest = runs.empty() ? 0 : runs[order[0]].b - runs[order[0]].a + 1;
+            for (size_t i = 0; i < order.size(); i++) {
+                const Run &r = runs[order[i]];
+                const int64_t len = r.b - r.a + 1;
+                const int prio = (4 * len >= 3 * (int64_t)longest) ? 3 : (2 * len >= longest) ? 2 : (4 * len >= longest) ? 1 : 0;
+                for (size_t k = 0; k < blk.size(); k += FEED_G) {
+                    FeedItem f{r.chr, r.a, r.b, prio, {-1, -1, -1, -1}};
+                    for (size_t w = 0; w < FEED_G && k + w < blk.size(); w++) f.ind0[w] = blk[k + w] * WAVE;
+                    feed_items.push_back(f);
+                }
+            }
+            n_feed_items = feed_items.size();
+            if ((rc = p->d_feed_items.reserve(std::max<size_t>(n_feed_items, 1)))) return rc;
         }
         chrs.resize(p->nchr);
         for (int c = 0; c < p->nchr; c++)
@@ -949,7 +978,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // Persistent workgroups (4 waves each: CHAIN, POST, PRE, COMB), one per CU; items are pulled longest
     // first, so the short runs pack behind the long ones instead of competing with them for HBM
     // bandwidth.
-    int workers = 256;
+    int workers = ctx->n_cu;
     if (const char *e = getenv("GARLIC_WORKERS")) workers = std::max(1, atoi(e));
     workers = std::min<int>(workers, (int)n_items);
 
@@ -970,6 +999,9 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                                hipMemcpyHostToDevice, ctx->stream));
         if (n_items)
             HIP_TRY(hipMemcpyAsync(p->d_items.p, items.data(), sizeof(ChainItem) * n_items,
+                                   hipMemcpyHostToDevice, ctx->stream));
+        if (feed_kernel && n_feed_items)
+            HIP_TRY(hipMemcpyAsync(p->d_feed_items.p, feed_items.data(), sizeof(FeedItem) * n_feed_items,
                                    hipMemcpyHostToDevice, ctx->stream));
         if (n_fill)
             HIP_TRY(hipMemcpyAsync(p->d_fill.p, fill.data(), sizeof(FillItem) * n_fill,
@@ -1075,11 +1107,43 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                     ind_begin,     ind_count,  W,               (int32_t)n_items, thin_step, p->d_counter.p, nullptr};
         DevBuf<int64_t> d_trace;   // debugging aid: GARLIC_TRACE=<file> dumps per-item timestamps
         const char *trace_path = getenv("GARLIC_TRACE");
-        if (trace_path && d_trace.reserve(4 * n_items) == GARLIC_OK) {
+        if (trace_path && !(feed_kernel && n_feed_items) && d_trace.reserve(4 * n_items) == GARLIC_OK) {
             (void)hipMemsetAsync(d_trace.p, 0, sizeof(int64_t) * 4 * n_items, ctx->stream);
             a.trace = d_trace.p;
         }
-        if (thin_step > 0)
+        if (feed_kernel && n_feed_items) {
+            FeedArgs f{p->d_packed.p, p->d_tab.p, p->d_feed_items.p, p->d_chrs.p, d_out, p->nwordrows, ind_begin, ind_count, W,
+                       (int32_t)n_feed_items, thin_step, getenv("GARLIC_FEED_NO_ASM") ? 0 : 1, p->d_counter.p, nullptr};
+            DevBuf<int64_t> d_ftrace;   // debugging aid: GARLIC_TRACE=<file> dumps per-item time stamps
+            const char *ftrace_path = getenv("GARLIC_TRACE");
+            if (ftrace_path && d_ftrace.reserve(8 * n_feed_items) == GARLIC_OK) {
+                (void)hipMemsetAsync(d_ftrace.p, 0, sizeof(int64_t) * 8 * n_feed_items, ctx->stream);
+                f.trace = d_ftrace.p;
+            }
+            // persistent workgroups of FEED_G waves, as many as stay resident (four per CU)
+            const void *fn = (const void *)lod_feed_kernel;
+            int per_cu = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FEED_G * WAVE, 0));
+            per_cu = std::max(1, std::min(per_cu, 16 / FEED_G));
+            if (const char *e = getenv("GARLIC_FEED_PER_CU")) per_cu = std::max(1, atoi(e));
+            const int grid = (int)std::min<size_t>(n_feed_items, (size_t)ctx->n_cu * per_cu);
+            void *kargs[] = {(void *)&f};
+            HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(FEED_G * WAVE), kargs, 0, ctx->stream));
+            if (f.trace) {
+                std::vector<int64_t> tr(8 * n_feed_items);
+                (void)hipMemcpyAsync(tr.data(), d_ftrace.p, sizeof(int64_t) * tr.size(), hipMemcpyDeviceToHost, ctx->stream);
+                (void)hipStreamSynchronize(ctx->stream);
+                if (FILE *fo = fopen(ftrace_path, "w")) {
+                    for (size_t i = 0; i < n_feed_items; i++) {
+                        fprintf(fo, "%zu", i);
+                        for (int q = 0; q < 8; q++) fprintf(fo, " %lld", (long long)tr[8 * i + q]);
+                        fprintf(fo, "\n");
+                    }
+                    fclose(fo);
+                }
+                d_ftrace.release();
+            }
+        } else if (thin_step > 0)
             hipLaunchKernelGGL((lod_chain_kernel<true, true>), dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
                                ctx->stream, a);
         else if (aligned16)
@@ -1169,6 +1233,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     p->plan.mode = (int)mode; p->plan.W = W; p->plan.max_gap = max_gap; p->plan.ind_begin = ind_begin;
     p->plan.ind_count = ind_count; p->plan.pitch_align = pitch_align;
     p->plan.wlod_fast = wlod_fast; p->plan.wlod_strip = wlod_gl_strip; p->plan.thin_step = thin_step; p->plan.blocks_hash = blocks_hash;
+    p->plan.feed_kernel = feed_kernel; p->plan.n_feed_items = n_feed_items;
     p->plan.n_items = n_items; p->plan.n_fill = n_fill; p->plan.n_runs = n_runs; p->plan.n_valid = n_valid;
     st.n_valid_windows = n_valid;
     st.n_missing = p->nloci - n_valid;
@@ -1216,6 +1281,7 @@ int garlic_ctx_create(int32_t device, void *hip_stream, garlic_ctx **out)
                     prop.gcnArchName);
     garlic_ctx *ctx = new garlic_ctx;
     ctx->device = device;
+    ctx->n_cu = std::max(1, prop.multiProcessorCount);   // a partitioned device (CPX / DPX) shows 32-128 of the 256
     if (hip_stream) {
         ctx->stream = reinterpret_cast<hipStream_t>(hip_stream);
     } else {

@@ -1,6 +1,6 @@
 """CPU: generated sources are current, and the device's log10 restatement agrees with the host libm.
 
-The hand-scheduled loops (chain_loop_gfx950.inc, wlod_loop_gfx950.inc) and the glibc log table
+The hand-scheduled loops (chain_loop_gfx950.inc, feed_loop_gfx950.inc, wlod_loop_gfx950.inc) and the glibc log table
 (glibc_log_data.inc) are committed generator output: regenerating them must be a no-op, so that what is
 reviewed in tools/gen_*.py is what runs."""
 import os
@@ -14,6 +14,7 @@ CSRC = os.path.join(ROOT, "garlic_amd", "csrc")
 
 
 @pytest.mark.parametrize("tool,inc", [("gen_chain_asm.py", "chain_loop_gfx950.inc"),
+                                      ("gen_feed_asm.py", "feed_loop_gfx950.inc"),
                                       ("gen_wlod_asm.py", "wlod_loop_gfx950.inc"),
                                       ("gen_log_data.py", "glibc_log_data.inc")])
 def test_regenerating_is_a_no_op(tmp_path, tool, inc):
