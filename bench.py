@@ -202,12 +202,27 @@ def leg_c3(ctx, dev, steps):
         feed[W] = {"kernel_ms": float(np.mean(ks)), "call_ms": float(np.mean(ws)) * 1e3, "feed_values": int(f.shape[0])}
     k_all = sum(v["kernel_ms"] for v in feed.values())
     bytes_feed = sum((0.25 + 8.0 / W) * nloci * nind for W in sizes)
+    # the whole --winsize-multi flow in one call: every size on a stream of its own, feeds fetched in order
+    panel.lod_feed_multi(sizes, ERROR, MAX_GAP, copy=False)      # scratch, streams
+    ws = []
+    for _ in range(max(2, steps // 2)):
+        t0 = time.perf_counter()
+        fm, _ = panel.lod_feed_multi(sizes, ERROR, MAX_GAP, copy=False)
+        ws.append(time.perf_counter() - t0)
+    feed_bytes = 8.0 * sum(int(f.shape[0]) for f in fm)
     res["thinned_feed"] = {
-        "per_winsize": feed, "four_sizes_kernel_ms": k_all, "four_sizes_call_ms": sum(v["call_ms"] for v in feed.values()),
+        "per_winsize": feed, "four_sizes_kernel_ms": k_all,
+        "four_sizes_call_ms": float(np.mean(ws)) * 1e3,
+        "four_sizes_call_note": "one garlic_lod_feed_multi call: the sizes' kernels overlap with each other's tails and with "
+                                "the feeds' way over PCIe (%.2f GB to host memory)" % (feed_bytes / 1e9),
+        "four_single_calls_ms": sum(v["call_ms"] for v in feed.values()),
+        "feed_gb": feed_bytes / 1e9,
         "sliding_windows_per_s": 4 * nloci * nind / (k_all * 1e-3),
-        "roofline": hbm_roofline("lod_chain_kernel<thinned>", bytes_feed, k_all,
-                                 note="0.25 + 8/W B per window (SURVEY 8(d) 'thinned output'): with the stores gone the kernel "
-                                      "runs at the pace of the sequential FP64 chain, far from any memory bound")}
+        "roofline": hbm_roofline("lod_feed_kernel", bytes_feed, k_all,
+                                 note="0.25 + 8/W B per window (SURVEY 8(d) 'thinned output'); bound by the two dependent FP64 adds and "
+                                      "the two term look-ups per window and lane (vector-instruction issue), not by memory: "
+                                      "fp64_add_frac = the adds alone against the FP64 add rate"),
+        "fp64_add_frac": (2.0 * 4 * nloci * nind / (k_all * 1e-3)) / (FP64_PEAK_TFLOPS * 1e12)}
     panel.close()
     return res
 

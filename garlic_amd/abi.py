@@ -28,7 +28,7 @@ SYMBOLS = [
     "garlic_panel_compute_ld", "garlic_ld_counts", "garlic_ld_finish", "garlic_roh_coverage",
     "garlic_panel_release_scratch",
     "garlic_lod_feed", "garlic_ctx_set_async",
-    "garlic_recent_kernel_ms", "garlic_panel_tgls_mode", "garlic_lod_feed_subset",
+    "garlic_recent_kernel_ms", "garlic_panel_tgls_mode", "garlic_lod_feed_subset", "garlic_lod_feed_multi",
     "garlic_device_alloc", "garlic_device_free", "garlic_panel_chain_kind",
 ]
 
@@ -52,7 +52,7 @@ _i64p = C.POINTER(C.c_int64)
 _f64p = C.POINTER(C.c_double)
 
 
-ABI_VERSION = 4   # GARLIC_HIP_ABI_VERSION of include/garlic_hip.h these bindings were written against
+ABI_VERSION = 5   # GARLIC_HIP_ABI_VERSION of include/garlic_hip.h these bindings were written against
 
 
 def lib():
@@ -105,6 +105,8 @@ def lib():
                                       C.c_int32]
     L.garlic_lod_feed_subset.argtypes = [_vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_double, C.c_int32, _i32p, C.c_int32, _vp, C.c_int64, _i64p, _i64p]
+    L.garlic_lod_feed_multi.argtypes = [_vp, _i32p, _i32p, C.c_int32, C.c_double, C.c_int32, _i32p, C.c_int32,
+                                        C.POINTER(C.c_void_p), _i64p, _i64p, _i64p]
     L.garlic_panel_tgls_mode.argtypes = [_vp, _i32p, _i32p]
     L.garlic_panel_chain_kind.argtypes = [_vp, _i32p]
     for name in SYMBOLS:
@@ -437,6 +439,31 @@ class Panel:
                                            step, _ptr(idx, _i32p), 0 if idx is None else n_rows,
                                            _vp(feed.ctypes.data), cap, C.byref(n), _ptr(per_chr, _i64p)))
         return (feed[: n.value].copy() if copy else feed[: n.value]), per_chr
+
+    def lod_feed_multi(self, winsizes, error, max_gap, steps=None, ind_idx=None, copy=True):
+        """garlic_lod_feed_multi: the feeds of several window sizes in one call (unweighted --error scores; steps
+        default to the window sizes).  Returns ([feed per size], per-chromosome counts [n_sizes, nchr]).
+        copy=False: the feeds are views of buffers the panel object reuses for the next call."""
+        sizes = np.ascontiguousarray(winsizes, dtype=np.int32)
+        st = sizes.copy() if steps is None else np.ascontiguousarray(steps, dtype=np.int32)
+        idx = None if ind_idx is None else np.ascontiguousarray(ind_idx, dtype=np.int32)
+        n_rows = self.nind if idx is None else int(idx.shape[0])
+        caps = np.array([max(1, int(sum((int(n) + int(s) - 1) // int(s) for n in self.chr_nloci)) * n_rows) for s in st],
+                        dtype=np.int64)
+        if copy:
+            bufs = [np.empty(int(c), dtype=np.float64) for c in caps]
+        else:
+            old = getattr(self, "_feed_multi", [])
+            bufs = [old[i] if i < len(old) and old[i].shape[0] >= int(c) else np.empty(int(c), dtype=np.float64)
+                    for i, c in enumerate(caps)]
+            self._feed_multi = bufs
+        ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+        counts = np.zeros(len(bufs), dtype=np.int64)
+        per_chr = np.zeros((len(bufs), self.nchr), dtype=np.int64)
+        check(lib().garlic_lod_feed_multi(self.handle, _ptr(sizes, _i32p), _ptr(st, _i32p), len(bufs), error, max_gap,
+                                          _ptr(idx, _i32p), 0 if idx is None else n_rows, ptrs, _ptr(caps, _i64p),
+                                          _ptr(counts, _i64p), _ptr(per_chr, _i64p)))
+        return [b[: int(n)] for b, n in zip(bufs, counts)], per_chr
 
     def chain_kind(self):
         """0 tuned chain, 1 tuned chain + scan for the value -9999.0 (none found), 2 by-value chain (garlic_hip.h)"""

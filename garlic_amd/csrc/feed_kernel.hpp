@@ -19,7 +19,11 @@
 //               stream is a second, cache-served read of the same words;
 //   per window  the genotype's term offset for both streams, two ds_read_b64, the two dependent adds
 //               acc = (acc - t_out) + t_in;
-//   samples     a sampled locus is stored straight from the lanes (8 B each into the [individual][sample] matrix).
+//   samples     a sampled locus is stored straight from the lanes, 8 B each, into a [row][column] matrix per chromosome.
+//               The host chooses rows and columns: row = individual, column = locus / step gives the thinned score
+//               matrix; row = position in the caller's individual list, column = rank of the sample among the
+//               chromosome's scored samples gives the KDE feed itself (convertWinData2DoubleData's order: the mask
+//               is the same for every individual, so the rank of a sample is known before anything is computed).
 //
 // One barrier per tile keeps the FEED_G waves within a tile of each other: the rings' only protocol.  Tile t:
 // barrier | request the chunks of tile t + 3 | the tile | wait for what was requested.
@@ -40,14 +44,17 @@ struct FeedItem {
     int32_t chr, a, b;        // run of valid windows [a, b] (chromosome-local)
     int32_t prio;             // 0..3: issue priority of the item's waves (long runs first)
     int32_t ind0[FEED_G];     // first individual of each wave's block (relative to ind_begin); -1: none
+    int32_t col0;             // column (in the chromosome's rows of the sample matrix) of the run's first sampled locus
+    int32_t pad[3];
 };
 
 struct FeedArgs {
     const uint32_t *packed;   // [nind_pad/64][nwordrows][64]
     const double *tab;        // [GOFF + nloci + pad][4]
     const FeedItem *items;
-    const ChrDev *chrs;       // out_base / out_pitch: the thinned matrix
+    const ChrDev *chrs;       // out_base / out_pitch: the sample matrix, [row][column] per chromosome
     double *out;
+    const int32_t *row_map;   // row of each individual of the call in the sample matrix, -1: none; NULL: row = individual
     int64_t nwordrows;
     int32_t ind_begin, ind_count, winsize, n_items, thin_step;
     int32_t use_asm;          // 0: every tile through the compiler-generated path (GARLIC_FEED_NO_ASM)
@@ -136,7 +143,9 @@ lod_feed_kernel(FeedArgs p)
         else __builtin_amdgcn_s_setprio(0);
         const int ind0 = __builtin_amdgcn_readfirstlane(it->ind0[wave]);   // (indexed in memory: a local copy of the item would live in scratch)
         const bool active = ind0 >= 0;
-        const int rows_valid = active ? min(WAVE, p.ind_count - ind0) : 0;
+        // the lane's row in the sample matrix
+        int row = -1;
+        if (active && ind0 + lane < p.ind_count) row = p.row_map ? p.row_map[ind0 + lane] : ind0 + lane;
         const int64_t col0 = (int64_t)p.ind_begin + (active ? ind0 : 0);
         const uint32_t *gcol = p.packed + packed_index(0, col0 + lane, p.nwordrows);
         const int64_t Gbase = c.loc_base + GOFF;
@@ -183,9 +192,8 @@ lod_feed_kernel(FeedArgs p)
         const int sh_lead = 2 * (int)(Glead & 15), sh_trail = 2 * (int)(Gtrail & 15);
         // thinned output: next sampled locus at or after a; its column in the block's rows
         int next = (a + step - 1) / step * step;
-        double *const out_row0 = p.out + c.out_base + (int64_t)(active ? ind0 : 0) * c.out_pitch;
-        int col = next / step;
-        const bool row_ok = lane < rows_valid;
+        double *const out_chr = p.out + c.out_base;
+        int col = it->col0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's quarters of the first chunks
         if (p.trace && threadIdx.x == 0) {
             p.trace[8 * item_idx + 2] = wall_clock64();
@@ -201,7 +209,7 @@ lod_feed_kernel(FeedArgs p)
                 const uint32_t *blk = p.packed + packed_index(0, col0, p.nwordrows);     // the block's word rows (lane 0)
                 const uint32_t *plw = blk + ((Glead + TILE) >> 4) * WAVE;                // word row 0 of tile 1
                 const uint32_t *ptw = blk + ((Gtrail + TILE) >> 4) * WAVE;
-                const double *out_next = out_row0 + col;
+                const double *out_next = out_chr + col;
                 uint32_t next_rel = (uint32_t)(next - s0);
                 asm volatile(GARLIC_FEED_LOOP_ASM
                              : [acc] "+v"(acc), [next_out] "=s"(next_rel), [out_out] "=s"(out_next)
@@ -209,12 +217,12 @@ lod_feed_kernel(FeedArgs p)
                                [ptw] "s"(feed_uni(ptw)), [ptl] "s"(feed_uni(lead_chunks + 128)), [ptt] "s"(feed_uni(trail_chunks + 128)),
                                [out] "s"(feed_uni(out_next)), [next] "s"(feed_uni(next_rel)), [step] "s"(feed_uni((uint32_t)step)),
                                [shl] "s"(feed_uni((uint32_t)sh_lead)), [sht] "s"(feed_uni((uint32_t)sh_trail)),
-                               [rows] "s"(feed_uni((uint32_t)rows_valid)), [pitch8] "s"(feed_uni((uint32_t)(c.out_pitch * 8))),
+                               [row] "v"(row), [pitch8] "s"(feed_uni((uint32_t)(c.out_pitch * 8))),
                                [niter] "s"(feed_uni((uint32_t)niter))
                              : GARLIC_FEED_LOOP_CLOBBERS);
                 k += 4 * niter;
                 next = first + k * TILE + (int)next_rel;
-                col = (int)(out_next - out_row0);
+                col = (int)(out_next - out_chr);
                 if (k >= ntiles) break;
             }
             feed_barrier();   // every wave is done with tile k-1; the chunks of tiles <= k + 2 have landed
@@ -251,7 +259,7 @@ lod_feed_kernel(FeedArgs p)
                         const double ti = (s >= a && s <= b) ? tin[i] : 0.0;
                         acc = (acc - to) + ti;   // two roundings, as garlic-roh.cpp:98-100
                         if (s == next && s <= b) {
-                            if (row_ok) out_row0[(int64_t)lane * c.out_pitch + col] = acc;
+                            if (row >= 0) out_chr[(int64_t)row * c.out_pitch + col] = acc;
                             col++;
                             next += step;
                         }

@@ -151,6 +151,7 @@ struct garlic_panel {
     bool tab_valid = false;
     double tab_error = 0;
     double tab_min = 0, tabgl_min = 0, glterms_min = 0;   // most negative finite term (lod_exact_needed)
+    bool tab_all_finite = false;                   // no infinite or NaN term (--error 0, a NaN frequency): every scored window is finite
     // segment boundaries (global loci, ascending), cached per max_gap
     bool seg_valid = false;
     int32_t seg_max_gap = 0;
@@ -223,6 +224,17 @@ struct garlic_panel {
     int32_t decay_M = 0;
     double decay_mu = 0;
     DevBuf<double> d_out, d_feed;
+    // garlic_lod_feed_multi: one set of scratch and one stream per window size of the call, kept for the next call
+    struct FeedSlot {
+        hipStream_t stream = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        DevBuf<FeedItem> items;
+        DevBuf<ChrDev> chrs;
+        DevBuf<int32_t> counter;
+        DevBuf<int64_t> row_counts;
+        DevBuf<double> out, feed;
+    };
+    std::vector<FeedSlot *> feed_slots;
     garlic_call_stats stats{};
     bool stats_pending = false;                    // event times of the last call not read yet
     int stats_slot = 0;                            // the context's event pair that brackets its dominant kernel
@@ -310,6 +322,9 @@ int ensure_term_table(garlic_panel *p, double error)
     p->tab_valid = true;
     p->tab_error = error;
     p->tab_min = min_finite(tab.data(), tab.size());
+    p->tab_all_finite = true;
+    for (double x : tab)
+        if (!std::isfinite(x)) { p->tab_all_finite = false; break; }
     p->h_tab.swap(tab);
     p->wtab_valid = false;
     return GARLIC_OK;
@@ -379,6 +394,43 @@ void plan_runs(const garlic_panel *p, int32_t W, std::vector<Run> &runs, std::ve
 }
 
 enum Mode { MODE_LOD, MODE_LOD_GL, MODE_WLOD };
+
+// Work list of lod_feed_kernel: (run, FEED_G blocks) items, longest runs first (`order`); the runs within reach of
+// the longest one run at raised issue priority: their length x one wave's pace is the kernel's critical path.
+// blocks: per 64-individual block, 1 = score it (NULL: all nblk of them).
+// col0[r]: column of run r's first sampled locus in its chromosome's rows of the sample matrix; < 0: the run holds
+// no sampled locus, no item.
+void build_feed_items(const std::vector<Run> &runs, const std::vector<int> &order, const std::vector<uint8_t> *blocks,
+                      int nblk, const std::vector<int32_t> &col0, std::vector<FeedItem> &items)
+{
+    items.clear();
+    std::vector<int> blk;
+    for (int k = 0; k < nblk; k++)
+        if (!blocks || (*blocks)[(size_t)k]) blk.push_back(k);
+    const int longest = runs.empty() ? 0 : runs[order[0]].b - runs[order[0]].a + 1;
+    for (size_t i = 0; i < order.size(); i++) {
+        const Run &r = runs[order[i]];
+        if (col0[(size_t)order[i]] < 0) continue;
+        const int64_t len = r.b - r.a + 1;
+        const int prio = (4 * len >= 3 * (int64_t)longest) ? 3 : (2 * len >= longest) ? 2 : (4 * len >= longest) ? 1 : 0;
+        for (size_t k = 0; k < blk.size(); k += FEED_G) {
+            FeedItem f{r.chr, r.a, r.b, prio, {-1, -1, -1, -1}, col0[(size_t)order[i]], {0, 0, 0}};
+            for (size_t w = 0; w < FEED_G && k + w < blk.size(); w++) f.ind0[w] = blk[k + w] * WAVE;
+            items.push_back(f);
+        }
+    }
+}
+
+// persistent workgroups of lod_feed_kernel: as many as stay resident (four per CU)
+int feed_grid(garlic_ctx *ctx, size_t n_items, int *grid)
+{
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)lod_feed_kernel, FEED_G * WAVE, 0));
+    per_cu = std::max(1, std::min(per_cu, 16 / FEED_G));
+    if (const char *e = getenv("GARLIC_FEED_PER_CU")) per_cu = std::max(1, atoi(e));
+    *grid = (int)std::min<size_t>(n_items, (size_t)ctx->n_cu * per_cu);
+    return GARLIC_OK;
+}
 
 // The reference tests "previous window has no score" by value (garlic-roh.cpp:79); the tuned chains by
 // position.  They agree unless a scored window sums to exactly -9999.0, which needs W terms that can add
@@ -913,22 +965,13 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                 if (!blocks || (*blocks)[(size_t)k]) items.push_back(ChainItem{r.chr, r.a, r.b, k * WAVE});
         }
         if (feed_kernel) {
-            // (run, FEED_G blocks) items, longest runs first; the runs within reach of the longest one run at raised
-            // issue priority: their length x one wave's pace is the kernel's critical path
-            std::vector<int> blk;
-            for (int k = 0; k < nblk; k++)
-                if (!blocks || (*blocks)[(size_t)k]) blk.push_back(k);
-            const int longest = runs.empty() ? 0 : runs[order[0]].b - runs[order[0]].a + 1;
-            for (size_t i = 0; i < order.size(); i++) {
-                const Run &r = runs[order[i]];
-                const int64_t len = r.b - r.a + 1;
-                const int prio = (4 * len >= 3 * (int64_t)longest) ? 3 : (2 * len >= longest) ? 2 : (4 * len >= longest) ? 1 : 0;
-                for (size_t k = 0; k < blk.size(); k += FEED_G) {
-                    FeedItem f{r.chr, r.a, r.b, prio, {-1, -1, -1, -1}};
-                    for (size_t w = 0; w < FEED_G && k + w < blk.size(); w++) f.ind0[w] = blk[k + w] * WAVE;
-                    feed_items.push_back(f);
-                }
+            // the thinned score matrix: row = individual, column = locus / step
+            std::vector<int32_t> col0(runs.size());
+            for (size_t i = 0; i < runs.size(); i++) {
+                const int32_t s = (runs[i].a + thin_step - 1) / thin_step;
+                col0[i] = (int64_t)s * thin_step <= runs[i].b ? s : -1;
             }
+            build_feed_items(runs, order, blocks, nblk, col0, feed_items);
             n_feed_items = feed_items.size();
             if ((rc = p->d_feed_items.reserve(std::max<size_t>(n_feed_items, 1)))) return rc;
         }
@@ -1112,7 +1155,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
             a.trace = d_trace.p;
         }
         if (feed_kernel && n_feed_items) {
-            FeedArgs f{p->d_packed.p, p->d_tab.p, p->d_feed_items.p, p->d_chrs.p, d_out, p->nwordrows, ind_begin, ind_count, W,
+            FeedArgs f{p->d_packed.p, p->d_tab.p, p->d_feed_items.p, p->d_chrs.p, d_out, nullptr, p->nwordrows, ind_begin, ind_count, W,
                        (int32_t)n_feed_items, thin_step, getenv("GARLIC_FEED_NO_ASM") ? 0 : 1, p->d_counter.p, nullptr};
             DevBuf<int64_t> d_ftrace;   // debugging aid: GARLIC_TRACE=<file> dumps per-item time stamps
             const char *ftrace_path = getenv("GARLIC_TRACE");
@@ -1120,13 +1163,9 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                 (void)hipMemsetAsync(d_ftrace.p, 0, sizeof(int64_t) * 8 * n_feed_items, ctx->stream);
                 f.trace = d_ftrace.p;
             }
-            // persistent workgroups of FEED_G waves, as many as stay resident (four per CU)
             const void *fn = (const void *)lod_feed_kernel;
-            int per_cu = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FEED_G * WAVE, 0));
-            per_cu = std::max(1, std::min(per_cu, 16 / FEED_G));
-            if (const char *e = getenv("GARLIC_FEED_PER_CU")) per_cu = std::max(1, atoi(e));
-            const int grid = (int)std::min<size_t>(n_feed_items, (size_t)ctx->n_cu * per_cu);
+            int grid = 1;
+            if ((rc = feed_grid(ctx, n_feed_items, &grid))) return rc;
             void *kargs[] = {(void *)&f};
             HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(FEED_G * WAVE), kargs, 0, ctx->stream));
             if (f.trace) {
@@ -1378,6 +1417,18 @@ int garlic_panel_create(garlic_ctx *ctx, int32_t nchr, const int32_t *chr_nloci,
     return GARLIC_OK;
 }
 
+static void release_feed_slots(garlic_panel *p)
+{
+    for (auto *sl : p->feed_slots) {
+        if (sl->stream) { (void)hipStreamSynchronize(sl->stream); (void)hipStreamDestroy(sl->stream); }
+        if (sl->ev0) (void)hipEventDestroy(sl->ev0);
+        if (sl->ev1) (void)hipEventDestroy(sl->ev1);
+        sl->items.release(); sl->chrs.release(); sl->counter.release(); sl->row_counts.release(); sl->out.release(); sl->feed.release();
+        delete sl;
+    }
+    p->feed_slots.clear();
+}
+
 int garlic_panel_destroy(garlic_panel *p)
 {
     if (!p) return GARLIC_OK;
@@ -1389,7 +1440,8 @@ int garlic_panel_destroy(garlic_panel *p)
     p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release(); p->d_row_counts.release(); p->d_codes.release(); p->d_tabgl.release();
     p->d_rld.release(); p->d_decay.release(); p->d_stage64.release(); p->d_phase.release(); p->lds.release();
     p->d_glterms.release(); p->d_glval.release(); p->d_freq.release(); p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release(); p->d_strips.release();
-    p->d_out.release(); p->d_feed.release();
+    p->d_out.release(); p->d_feed.release(); p->d_feed_items.release();
+    release_feed_slots(p);
     delete p;
     return GARLIC_OK;
 }
@@ -2200,10 +2252,11 @@ int garlic_lod_flatten(garlic_panel *p, const double *scores, int32_t pitch_alig
     return flatten_impl(p, scores, pitch_align, nind_out, step, feed, feed_capacity, count, nullptr);
 }
 
-// LOD / wLOD scores and their thinned KDE feed in one call: the scores never leave the device
-int garlic_lod_feed_subset(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
-                           int32_t weighted, int32_t M, double mu, int32_t step, const int32_t *ind_idx, int32_t n_idx,
-                           double *feed, int64_t feed_capacity, int64_t *count, int64_t *chr_counts)
+// LOD / wLOD scores and their thinned KDE feed in one call: the scores never leave the device.  The general form:
+// the scores (full, or the chain kernel's thinned matrix) into device scratch, then garlic_lod_flatten's two passes.
+static int feed_single(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
+                       int32_t weighted, int32_t M, double mu, int32_t step, const int32_t *ind_idx, int32_t n_idx,
+                       double *feed, int64_t feed_capacity, int64_t *count, int64_t *chr_counts)
 {
     if (!p || !count) return fail(GARLIC_ERR_INVALID, "panel and count are required");
     if (step < 1) return fail(GARLIC_ERR_INVALID, "step must be >= 1");
@@ -2262,12 +2315,180 @@ int garlic_lod_feed_subset(garlic_panel *p, int32_t winsize, double error, int32
     return done(GARLIC_OK);
 }
 
+int garlic_lod_feed_subset(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
+                           int32_t weighted, int32_t M, double mu, int32_t step, const int32_t *ind_idx, int32_t n_idx,
+                           double *feed, int64_t feed_capacity, int64_t *count, int64_t *chr_counts)
+{
+    if (!p || !count) return fail(GARLIC_ERR_INVALID, "panel and count are required");
+    // unweighted --error scores with a real thinning step: the chain kernel writes the feed itself (garlic_lod_feed_multi)
+    if (!weighted && !use_gl && step >= 4 && !getenv("GARLIC_FEED_MATRIX"))
+        return garlic_lod_feed_multi(p, &winsize, &step, 1, error, max_gap, ind_idx, n_idx, &feed, &feed_capacity, count, chr_counts);
+    return feed_single(p, winsize, error, max_gap, use_gl, weighted, M, mu, step, ind_idx, n_idx, feed, feed_capacity, count,
+                       chr_counts);
+}
+
 int garlic_lod_feed(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
                     int32_t weighted, int32_t M, double mu, int32_t step, double *feed,
                     int64_t feed_capacity, int64_t *count, int64_t *chr_counts)
 {
     return garlic_lod_feed_subset(p, winsize, error, max_gap, use_gl, weighted, M, mu, step, nullptr, 0, feed,
                                   feed_capacity, count, chr_counts);
+}
+
+// The KDE feeds of several window sizes in one call (exploreWinsizes / selectWinsizeFromList run the same panel
+// through every size of --winsize-multi, src/garlic-roh.cpp:726-751, 881-920).
+//
+// The window mask depends on positions only (the same for every individual), so which sampled loci hold a score --
+// and the place of every sample in convertWinData2DoubleData's chromosome -> individual -> locus order -- is known
+// before anything is computed: lod_feed_kernel stores every sample straight into the feed (row = position in the
+// individual list, column = rank among the chromosome's scored samples).  No thinned score matrix, no compaction
+// pass.  (That needs every scored window to be a finite number other than -9999, i.e. finite terms and
+// !lod_exact_needed; otherwise, and for steps below 4, the single-size path runs: scores, then garlic_lod_flatten.)
+// Each size has a stream and a feed buffer of its own and every size's kernel is enqueued before the first feed is
+// fetched: the tail of one size's chain kernel (its longest runs, a few waves per CU) runs beside the bulk of the
+// next size's, and a feed crosses PCIe while the following sizes are computed.
+int garlic_lod_feed_multi(garlic_panel *p, const int32_t *winsizes, const int32_t *steps, int32_t n_sizes, double error,
+                          int32_t max_gap, const int32_t *ind_idx, int32_t n_idx, double *const *feeds,
+                          const int64_t *feed_capacity, int64_t *counts, int64_t *chr_counts)
+{
+    if (!p || !winsizes || !steps || !feeds || !feed_capacity || !counts)
+        return fail(GARLIC_ERR_INVALID, "panel, winsizes, steps, feeds, feed_capacity and counts are required");
+    if (n_sizes < 1) return fail(GARLIC_ERR_INVALID, "n_sizes must be >= 1");
+    if (ind_idx && n_idx < 1) return fail(GARLIC_ERR_INVALID, "an individual list needs at least one entry");
+    for (int i = 0; i < n_sizes; i++) {
+        if (winsizes[i] <= 1) return fail(GARLIC_ERR_INVALID, "SNP window size must be > 1 (got %d)", winsizes[i]);
+        if (steps[i] < 1) return fail(GARLIC_ERR_INVALID, "step must be >= 1");
+    }
+    garlic_ctx *ctx = p->ctx;
+    int rc;
+    if ((rc = set_device(ctx))) return rc;
+    if (!p->have_map || !p->have_freq || !p->have_geno)
+        return fail(GARLIC_ERR_STATE, "panel needs map, freq and genotypes before computing LOD");
+    bool direct = !getenv("GARLIC_FEED_FULL") && !getenv("GARLIC_FEED_ROLES") && !getenv("GARLIC_FEED_SERIAL");
+    for (int i = 0; i < n_sizes && direct; i++) direct = steps[i] >= 4;
+    if (direct) {
+        if ((rc = ensure_segments(p, max_gap))) return rc;
+        if ((rc = ensure_term_table(p, error))) return rc;
+        direct = p->tab_all_finite;
+        for (int i = 0; i < n_sizes && direct; i++) direct = !lod_exact_needed(p, MODE_LOD, winsizes[i]);
+    }
+    if (!direct) {
+        for (int i = 0; i < n_sizes; i++)
+            if ((rc = feed_single(p, winsizes[i], error, max_gap, 0, 0, 0, 0.0, steps[i], ind_idx, n_idx, feeds[i],
+                                  feed_capacity[i], &counts[i], chr_counts ? chr_counts + (size_t)i * p->nchr : nullptr)))
+                return rc;
+        return GARLIC_OK;
+    }
+    // rows of the feed: the listed individuals in list order, or everyone
+    const int nblk = (p->nind + WAVE - 1) / WAVE;
+    const int nrows = ind_idx ? n_idx : p->nind;
+    std::vector<uint8_t> blocks;
+    std::vector<int32_t> row_map;
+    DevBuf<int32_t> d_rowmap;
+    auto done = [&](int code) { d_rowmap.release(); return code; };
+    if (ind_idx) {
+        blocks.assign((size_t)nblk, 0);
+        row_map.assign((size_t)p->nind, -1);
+        for (int k = 0; k < n_idx; k++) {
+            const int i = ind_idx[k];
+            if (i < 0 || i >= p->nind) return fail(GARLIC_ERR_INVALID, "feed individual %d outside panel of %d", i, p->nind);
+            if (row_map[(size_t)i] >= 0) return fail(GARLIC_ERR_INVALID, "feed individual %d listed twice", i);
+            row_map[(size_t)i] = k;
+            blocks[(size_t)(i >> 6)] = 1;
+        }
+        if ((rc = d_rowmap.reserve((size_t)p->nind))) return done(rc);
+        hipError_t e = hipMemcpy(d_rowmap.p, row_map.data(), sizeof(int32_t) * (size_t)p->nind, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "feed: %s", hipGetErrorString(e)));
+    }
+    while ((int)p->feed_slots.size() < n_sizes) {
+        auto *sl = new garlic_panel::FeedSlot;
+        p->feed_slots.push_back(sl);
+        if (hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&sl->ev0) != hipSuccess ||
+            hipEventCreate(&sl->ev1) != hipSuccess)
+            return done(fail(GARLIC_ERR_HIP, "feed: stream / event creation failed"));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));          // uploads and earlier calls on the context's stream
+    // ---- plans and their uploads, all sizes, before any kernel is enqueued (an upload from pageable memory waits
+    //      for the device to take it: behind a running chain kernel it would hold back the sizes that follow)
+    std::vector<size_t> n_items((size_t)n_sizes, 0);
+    std::vector<int64_t> total((size_t)n_sizes, 0);
+    for (int i = 0; i < n_sizes; i++) {
+        garlic_panel::FeedSlot &sl = *p->feed_slots[(size_t)i];
+        const int32_t W = winsizes[i], step = steps[i];
+        std::vector<Run> runs;
+        std::vector<FillItem> fill;
+        int64_t n_valid = 0;
+        plan_runs(p, W, runs, fill, n_valid);             // in chromosome and position order
+        // rank of every run's first sample among its chromosome's scored samples; samples per chromosome
+        std::vector<int32_t> col0(runs.size(), -1);
+        std::vector<int64_t> nkeep((size_t)p->nchr, 0);
+        for (size_t r = 0; r < runs.size(); r++) {
+            const int64_t s = ((int64_t)runs[r].a + step - 1) / step * step;
+            if (s > runs[r].b) continue;
+            col0[r] = (int32_t)nkeep[(size_t)runs[r].chr];
+            nkeep[(size_t)runs[r].chr] += (runs[r].b - s) / step + 1;
+        }
+        std::vector<int> order(runs.size());
+        for (size_t k = 0; k < runs.size(); k++) order[k] = (int)k;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return (runs[x].b - runs[x].a) > (runs[y].b - runs[y].a); });
+        std::vector<FeedItem> items;
+        build_feed_items(runs, order, ind_idx ? &blocks : nullptr, nblk, col0, items);
+        std::vector<ChrDev> chrs((size_t)p->nchr);
+        int64_t off = 0;
+        for (int c = 0; c < p->nchr; c++) {
+            chrs[(size_t)c] = ChrDev{p->chr_off[c], off, nkeep[(size_t)c], p->chr_nloci[c], 1};
+            if (chr_counts) chr_counts[(size_t)i * p->nchr + c] = nkeep[(size_t)c] * nrows;
+            if (nkeep[(size_t)c] * 8 * (int64_t)nrows >= (int64_t)1 << 32)
+                return done(fail(GARLIC_ERR_INVALID, "chromosome %d: feed rows beyond 32-bit offsets", c));
+            off += nkeep[(size_t)c] * nrows;
+        }
+        total[(size_t)i] = off;
+        counts[i] = off;
+        n_items[(size_t)i] = items.size();
+        if (off > feed_capacity[i] || off == 0) { n_items[(size_t)i] = 0; continue; }
+        if (!feeds[i]) return done(fail(GARLIC_ERR_INVALID, "feed %d is NULL", i));
+        if ((rc = sl.items.reserve(std::max<size_t>(items.size(), 1)))) return done(rc);
+        if ((rc = sl.chrs.reserve((size_t)p->nchr))) return done(rc);
+        if ((rc = sl.counter.reserve(4))) return done(rc);
+        if ((rc = sl.feed.reserve((size_t)off))) return done(rc);
+        HIP_TRY(hipMemcpy(sl.chrs.p, chrs.data(), sizeof(ChrDev) * (size_t)p->nchr, hipMemcpyHostToDevice));
+        if (!items.empty()) HIP_TRY(hipMemcpy(sl.items.p, items.data(), sizeof(FeedItem) * items.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(sl.counter.p, 0, 2 * sizeof(int32_t)));
+    }
+    p->plan.valid = false;
+    // ---- every size's chain kernel, each on its own stream; every element of a feed is written by its kernel
+    for (int i = 0; i < n_sizes; i++) {
+        garlic_panel::FeedSlot &sl = *p->feed_slots[(size_t)i];
+        HIP_TRY(hipEventRecord(sl.ev0, sl.stream));
+        if (n_items[(size_t)i]) {
+            FeedArgs f{p->d_packed.p, p->d_tab.p, sl.items.p, sl.chrs.p, sl.feed.p, ind_idx ? d_rowmap.p : nullptr, p->nwordrows, 0,
+                       p->nind, winsizes[i], (int32_t)n_items[(size_t)i], steps[i], getenv("GARLIC_FEED_NO_ASM") ? 0 : 1,
+                       sl.counter.p, nullptr};
+            int grid = 1;
+            if ((rc = feed_grid(ctx, n_items[(size_t)i], &grid))) return done(rc);
+            void *kargs[] = {(void *)&f};
+            HIP_TRY(hipLaunchKernel((const void *)lod_feed_kernel, dim3((unsigned)grid), dim3(FEED_G * WAVE), kargs, 0, sl.stream));
+        }
+        HIP_TRY(hipEventRecord(sl.ev1, sl.stream));
+        HIP_TRY(hipGetLastError());
+    }
+    // ---- the feeds, in order
+    for (int i = 0; i < n_sizes; i++) {
+        garlic_panel::FeedSlot &sl = *p->feed_slots[(size_t)i];
+        if (n_items[(size_t)i])
+            HIP_TRY(hipMemcpyAsync(feeds[i], sl.feed.p, sizeof(double) * (size_t)total[(size_t)i], hipMemcpyDeviceToHost, sl.stream));
+    }
+    float ms_sum = 0.f;
+    for (int i = 0; i < n_sizes; i++) {
+        garlic_panel::FeedSlot &sl = *p->feed_slots[(size_t)i];
+        HIP_TRY(hipStreamSynchronize(sl.stream));
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, sl.ev0, sl.ev1) == hipSuccess) ms_sum += ms;
+    }
+    p->stats = garlic_call_stats{};
+    p->stats.chain_kernel_ms = ms_sum;    // (the sizes overlap: the sum of their spans, not wall time)
+    p->stats_pending = false;
+    return done(GARLIC_OK);
 }
 
 int garlic_panel_tgls_mode(garlic_panel *p, int32_t *mode, int32_t *terms_by)

@@ -1152,6 +1152,79 @@ DoubleData *LodEngine::lodFeed(int winsize, double error, int MAX_GAP, int step,
     return d;
 }
 
+// The callers that sweep window sizes on one data set -- exploreWinsizes (garlic-roh.cpp:726-751), selectWinsize
+// (:798-837), selectWinsizeFromList (:881-920) -- through garlic_lod_feed_multi: unweighted --error scores, the thinning
+// step of a size is the size itself (convertWinData2DoubleData(.., winsize), :735,743,817,900) unless `steps` says otherwise.
+std::vector<DoubleData *> LodEngine::lodFeedMulti(const std::vector<int> &winsizes, double error, int MAX_GAP,
+                                                  const std::vector<int> *steps, const std::vector<int> *kdeSubsample)
+{
+    const int nchr = (int)impl->chr_nloci.size();
+    const size_t ns = impl->shards.size(), nw = winsizes.size();
+    if (nw == 0) return {};
+    if (steps && steps->size() != nw) fail("lodFeedMulti: one thinning step per window size");
+    std::cerr << "Calculating LOD scores with winsizes";
+    for (int W : winsizes) std::cerr << " " << W;
+    std::cerr << " (thinned on the device).\n";
+    const bool subset = kdeSubsample && !kdeSubsample->empty();
+    if (subset)
+        for (size_t i = 1; i < kdeSubsample->size(); i++)
+            if ((*kdeSubsample)[i] <= (*kdeSubsample)[i - 1]) fail("KDE subsample must be in increasing order");
+    std::vector<int32_t> W32(winsizes.begin(), winsizes.end()), S32(nw);
+    for (size_t i = 0; i < nw; i++) S32[i] = steps ? (*steps)[i] : winsizes[i];
+    // feeds[shard][size], per_chr[shard][size * nchr + c]
+    std::vector<std::vector<std::vector<double>>> feeds(ns, std::vector<std::vector<double>>(nw));
+    std::vector<std::vector<int64_t>> per_chr(ns, std::vector<int64_t>(nw * (size_t)nchr, 0));
+    std::vector<std::string> errors(ns);
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < ns; k++)
+        th.emplace_back([&, k] {
+            auto &s = impl->shards[k];
+            std::vector<int32_t> mine;
+            if (subset) {
+                for (int g : *kdeSubsample)
+                    if (g >= s.ind_begin && g < s.ind_begin + s.nind) mine.push_back(g - s.ind_begin);
+                if (mine.empty()) return;      // no listed individual lives here
+            }
+            const int64_t rows = subset ? (int64_t)mine.size() : s.nind;
+            std::vector<double *> ptrs(nw);
+            std::vector<int64_t> cap(nw, 0), n(nw, 0);
+            for (size_t i = 0; i < nw; i++) {
+                for (int c = 0; c < nchr; c++) cap[i] += ((int64_t)impl->chr_nloci[c] + S32[i] - 1) / S32[i] * rows;
+                feeds[k][i].resize((size_t)std::max<int64_t>(cap[i], 1));
+                ptrs[i] = feeds[k][i].data();
+            }
+            if (garlic_lod_feed_multi(s.panel, W32.data(), S32.data(), (int32_t)nw, error, MAX_GAP, subset ? mine.data() : nullptr,
+                                      (int32_t)mine.size(), ptrs.data(), cap.data(), n.data(), per_chr[k].data()) != GARLIC_OK)
+                errors[k] = garlic_hip_last_error();
+            else
+                for (size_t i = 0; i < nw; i++) feeds[k][i].resize((size_t)n[i]);
+        });
+    for (auto &t : th) t.join();
+    for (auto &e : errors)
+        if (!e.empty()) fail("garlic_lod_feed_multi: " + e);
+    // merge per size in the reference's order: chromosome -> individual (= shard order) -> locus
+    std::vector<DoubleData *> out(nw, nullptr);
+    for (size_t i = 0; i < nw; i++) {
+        int64_t total = 0;
+        for (size_t k = 0; k < ns; k++) total += (int64_t)feeds[k][i].size();
+        if (total > 0x7fffffff) fail("KDE feed has more than 2^31 values: DoubleData::size is an int");
+        DoubleData *d = new DoubleData;
+        d->size = (int)total;
+        d->data = new double[total > 0 ? total : 1];
+        std::vector<int64_t> off(ns, 0);
+        int64_t o = 0;
+        for (int c = 0; c < nchr; c++)
+            for (size_t k = 0; k < ns; k++) {
+                const int64_t m = feeds[k][i].empty() ? 0 : per_chr[k][i * (size_t)nchr + c];
+                memcpy(d->data + o, feeds[k][i].data() + off[k], sizeof(double) * (size_t)m);
+                o += m;
+                off[k] += m;
+            }
+        out[i] = d;
+    }
+    return out;
+}
+
 std::vector<LDData *> *LodEngine::ldWeights(int winsize, const std::vector<int> &subsample, bool want_host,
                                             bool phased)
 {

@@ -242,6 +242,11 @@ public:
     // gsl_ran_choose draws); NULL or empty = everyone.  Only their 64-individual blocks are scored.
     DoubleData *lodFeed(int winsize, double error, int MAX_GAP, int step, bool weighted = false, int M = 0,
                         double mu = 0.0, const std::vector<int> *kdeSubsample = nullptr);
+    // several window sizes in one call (unweighted --error scores): the feeds of exploreWinsizes / selectWinsize /
+    // selectWinsizeFromList (garlic-roh.cpp:726-751, 798-837, 881-920), one DoubleData per size; steps NULL: the sizes
+    std::vector<DoubleData *> lodFeedMulti(const std::vector<int> &winsizes, double error, int MAX_GAP,
+                                           const std::vector<int> *steps = nullptr,
+                                           const std::vector<int> *kdeSubsample = nullptr);
     LodEngine(const LodEngine &) = delete;
     LodEngine &operator=(const LodEngine &) = delete;
 

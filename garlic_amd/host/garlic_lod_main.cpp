@@ -27,6 +27,7 @@ struct Args {
     int winsize = 0;               // :38
     std::vector<int> winsize_multi;
     bool auto_winsize = false, weighted = false, raw_lod = false, kde_thinning = true, phased = false;
+    bool winsize_stream = false;   // extension: further window sizes from stdin (the loop of selectWinsize, driven by the KDE's owner)
     int auto_winsize_step = 10, max_gap = 200000, M = 7, threads = 1, kde_subsample = 20, gpus = 1;
     std::vector<int> devices;      // --devices; empty = 0 .. gpus-1
     int ld_subsample = 0;          // src/garlic-cli.cpp:137
@@ -42,7 +43,7 @@ struct Args {
     std::cerr << "ERROR: " << msg << "\n"
               << "usage: garlic-lod --tped F --tfam F --out P (--build hg18|hg19|hg38 | --centromere F)\n"
                  "         (--error E | --tgls F --gl-type GQ|GL|PL) (--winsize W | --winsize-multi W1 W2 ...)\n"
-                 "         [--auto-winsize] [--auto-winsize-step N] [--max-gap N] [--overlap-frac X]\n"
+                 "         [--auto-winsize] [--auto-winsize-step N] [--winsize-stream] [--max-gap N] [--overlap-frac X]\n"
                  "         [--freq-file F] [--tped-missing C] [--raw-lod] [--kde-subsample N] [--kde-seed S] [--no-kde-thinning]\n"
                  "         [--weighted --map F --M N --mu X --ld-subsample N --ld-seed S --threads N]\n"
                  "         [--resample N --resample-seed S] [--gpus N | --devices 0,1,...] [--genotype-cache F]\n";
@@ -73,6 +74,7 @@ Args parse(int argc, char **argv)
         }
         else if (f == "--auto-winsize") a.auto_winsize = !a.auto_winsize; // bool flags toggle (param_t.cpp:278)
         else if (f == "--auto-winsize-step") a.auto_winsize_step = atoi(val().c_str());
+        else if (f == "--winsize-stream") a.winsize_stream = !a.winsize_stream;
         else if (f == "--max-gap") a.max_gap = atoi(val().c_str());
         else if (f == "--overlap-frac") a.overlap_frac = atof(val().c_str());
         else if (f == "--weighted") a.weighted = !a.weighted;
@@ -203,6 +205,17 @@ int main(int argc, char **argv)
             for (int i : kdesub) std::cerr << " " << ind->indID[i];
             std::cerr << "\n";
         }
+        if (!a.raw_lod && !a.weighted && !USE_GL && sizes.size() > 1) {
+            // --winsize-multi, feeds only, unweighted: all sizes in one call (their kernels and downloads overlap)
+            std::vector<int> steps;
+            for (int W : sizes) steps.push_back(a.kde_thinning ? W : 1);
+            std::vector<DoubleData *> feeds = engine.lodFeedMulti(sizes, a.error, a.max_gap, &steps, &kdesub);
+            for (size_t i = 0; i < sizes.size(); i++) {
+                writeFeed(a.out + "." + std::to_string(sizes[i]) + "SNPs.lod.f64", feeds[i]);
+                releaseDoubleData(feeds[i]);
+            }
+            sizes.clear();
+        }
         for (int W : sizes) {
             if (a.weighted) engine.ldWeights(W, ldsub, false, a.phased);   // garlic-main.cpp:346-357: LD weights per window size
             const std::string feed_path = a.out + "." + std::to_string(W) + "SNPs.lod.f64";
@@ -221,8 +234,31 @@ int main(int argc, char **argv)
             releaseDoubleData(feed);
             releaseWinData(win);
         }
-        if (a.auto_winsize)
-            std::cerr << "NOTE: --auto-winsize picks among the feeds above in GARLIC's KDE stage (Phase II, not part of this tool)\n";
+        if (a.winsize_stream) {
+            // selectWinsize (garlic-roh.cpp:766-850) computes a window size, looks at the KDE of its scores and, if that is
+            // not smooth enough, goes on with winsize + --auto-winsize-step on the same data.  The KDE is Phase II and not
+            // part of this tool, so its owner drives that loop: one window size per line on stdin ("+" = the previous size
+            // + --auto-winsize-step), the feed of each on the resident panel, one line "FEED <winsize> <file> <values>"
+            // on stdout when it is written; end of input or 0 ends the run.
+            int last = a.winsize_multi.empty() ? a.winsize : a.winsize_multi.back();
+            std::string line;
+            while (std::getline(std::cin, line)) {
+                while (!line.empty() && isspace((unsigned char)line.back())) line.pop_back();
+                if (line.empty()) continue;
+                const int W = line == "+" ? last + a.auto_winsize_step : atoi(line.c_str());
+                if (W == 0) break;
+                if (W <= 1) { std::cerr << "ERROR: SNP window size must be > 1.\n"; return 1; }
+                if (a.weighted) engine.ldWeights(W, ldsub, false, a.phased);
+                DoubleData *feed = engine.lodFeed(W, a.error, a.max_gap, a.kde_thinning ? W : 1, a.weighted, a.M, a.mu, &kdesub);
+                const std::string path = a.out + "." + std::to_string(W) + "SNPs.lod.f64";
+                writeFeed(path, feed);
+                std::cout << "FEED " << W << " " << path << " " << feed->size << std::endl;
+                releaseDoubleData(feed);
+                last = W;
+            }
+        } else if (a.auto_winsize)
+            std::cerr << "NOTE: --auto-winsize picks among the feeds above in GARLIC's KDE stage (Phase II, not part of this tool); "
+                         "--winsize-stream lets that stage ask for further window sizes on the resident panel\n";
     } catch (...) {
         return 1;
     }

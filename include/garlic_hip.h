@@ -39,8 +39,10 @@ extern "C" {
 
 /* 2: the LD functions take `phased`; garlic_panel_set_phase
  * 3: likelihoods may be continuous (no 256-value limit), garlic_panel_tgls_mode; an LD subsample may be
- *    empty (sub_idx != NULL, n_sub = 0); garlic_lod_feed_subset */
-#define GARLIC_HIP_ABI_VERSION 4
+ *    empty (sub_idx != NULL, n_sub = 0); garlic_lod_feed_subset
+ * 4: garlic_device_alloc / garlic_device_free (score matrices), garlic_panel_chain_kind
+ * 5: garlic_lod_feed_multi (the feeds of several window sizes in one call) */
+#define GARLIC_HIP_ABI_VERSION 5
 
 #define GARLIC_OK 0
 #define GARLIC_ERR_INVALID 1  /* bad argument (e.g. winsize <= 1: src/garlic-cli.cpp:433-442) */
@@ -266,6 +268,19 @@ int garlic_lod_feed(garlic_panel *panel, int32_t winsize, double error, int32_t 
 int garlic_lod_feed_subset(garlic_panel *panel, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
                            int32_t weighted, int32_t M, double mu, int32_t step, const int32_t *ind_idx,
                            int32_t n_idx, double *feed, int64_t feed_capacity, int64_t *count, int64_t *chr_counts);
+
+/* The callers that sweep window sizes -- exploreWinsizes (src/garlic-roh.cpp:726-751), selectWinsize (:798-837),
+ * selectWinsizeFromList (:881-920: --winsize-multi with --auto-winsize) -- run calcLODWindows + the KDE thinning once
+ * per size on the same data.  This is garlic_lod_feed_subset for n_sizes window sizes in one call (unweighted --error
+ * scores; steps[i] is the thinning step of winsizes[i], the reference uses the window size).  Every size gets a
+ * stream and device scratch of its own and all of them are enqueued before the first feed is fetched: the tail of one
+ * size's chain kernel (its longest runs, a few waves per CU) runs beside the bulk of the next size's, and a feed crosses
+ * PCIe while the following sizes are computed.  feeds[i]: HOST buffer of feed_capacity[i] doubles; counts[i] as
+ * *count there; chr_counts (may be NULL): [n_sizes][nchr].  ind_idx / n_idx as in garlic_lod_feed_subset (NULL:
+ * everyone).  Values identical to n_sizes single calls. */
+int garlic_lod_feed_multi(garlic_panel *panel, const int32_t *winsizes, const int32_t *steps, int32_t n_sizes, double error,
+                          int32_t max_gap, const int32_t *ind_idx, int32_t n_idx, double *const *feeds,
+                          const int64_t *feed_capacity, int64_t *counts, int64_t *chr_counts);
 
 /* First half of assembleROHWindows (src/garlic-roh.cpp:446-454) on the device: for every individual
  * and SNP the number of windows with score >= cutoff that cover the SNP,

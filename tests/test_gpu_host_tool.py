@@ -148,6 +148,35 @@ def test_kde_feed_matches_oracle(tmp_path):
         assert ol.bits_equal(got, want), W
 
 
+def test_winsize_multi_feeds_sharded_and_streamed(tmp_path):
+    """--winsize-multi goes through garlic_lod_feed_multi (all sizes in one call per shard); --devices 0,0,0 merges
+    three shards' feeds per size; --winsize-stream serves further window sizes on the resident panel, the loop of
+    selectWinsize (garlic-roh.cpp:766-850) as the KDE's owner would drive it ('+' = previous + --auto-winsize-step)"""
+    per_chr = tiny_panels()
+
+    def want(W):
+        return np.concatenate([ol.oracle_flatten(ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, 200000), W)
+                               for g, f, p, (cs, ce) in per_chr])
+    d = tmp_path / "sh"
+    d.mkdir()
+    out = run_tool(d, "--winsize-multi", "20", "45", "33", "--devices", "0,0,0")
+    for W in (20, 45, 33):
+        assert ol.bits_equal(np.fromfile(f"{out}.{W}SNPs.lod.f64", dtype=np.float64), want(W)), W
+    out = str(tmp_path / "st")
+    cmd = [TOOL, "--tped", os.path.join(E2E, "tiny.tped.gz"), "--tfam", os.path.join(E2E, "tiny.tfam"),
+           "--centromere", os.path.join(E2E, "tiny.centromeres.txt"), "--error", "0.001", "--out", out, "--kde-subsample", "0",
+           "--winsize", "30", "--auto-winsize", "--auto-winsize-step", "10", "--winsize-stream"]
+    r = subprocess.run(cmd, input="+\n+\n25\n0\n77\n", capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    served = [l.split() for l in r.stdout.splitlines() if l.startswith("FEED ")]
+    assert [int(t[1]) for t in served] == [40, 50, 25]            # 0 ends the run: 77 is never computed
+    for W in (30, 40, 50, 25):
+        got = np.fromfile(f"{out}.{W}SNPs.lod.f64", dtype=np.float64)
+        assert ol.bits_equal(got, want(W)), W
+    assert all(int(t[3]) == want(int(t[1])).shape[0] for t in served)
+    assert not os.path.exists(f"{out}.77SNPs.lod.f64")
+
+
 def test_kde_subsample_feed(tmp_path):
     """--kde-subsample N (selectLODCutoff -> convertSubsetWinData2DoubleData, garlic-data.cpp:2071-2150): the
     feed holds the drawn individuals only, in TFAM order; the draw is named on stderr as the reference logs

@@ -329,6 +329,46 @@ def test_lod_feed_thinned_write_out(gpu_ctx, W, step):
             assert ol.bits_equal(got[c], ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg)), c
 
 
+def test_lod_feed_multi_equals_single_calls_and_the_oracle(gpu_ctx, monkeypatch):
+    """garlic_lod_feed_multi (--winsize-multi: exploreWinsizes / selectWinsizeFromList, garlic-roh.cpp:726-751,
+    881-920): every size on its own stream, feeds fetched in order -- the values of one garlic_lod_feed call per
+    size and of flatten(oracle scores); with an individual list; with a step the chain kernel does not thin for
+    (falls back to single calls); repeated (resident scratch); the serial path forced"""
+    rng = np.random.default_rng(77)
+    mg, nind = 200000, 200
+    sizes = [6000, 45, 1500, 301]
+    chroms = [ol.random_panel(rng, n, nind, max_gap=mg, gaps=3 if n > 1000 else 0) for n in sizes]
+    Ws = [50, 100, 200, 300, 20]
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms])
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        wins = {W: [ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg) for g, f, p, cs, ce in chroms] for W in Ws}
+        for rep in range(2):
+            feeds, per_chr = panel.lod_feed_multi(Ws, 0.001, mg)
+            for i, W in enumerate(Ws):
+                want = [ol.oracle_flatten(w, W) for w in wins[W]]
+                assert [len(w) for w in want] == list(per_chr[i]), (W, rep)
+                assert ol.bits_equal(feeds[i], np.concatenate(want)), (W, rep)
+                single, _ = panel.lod_feed(W, 0.001, mg, W)
+                assert ol.bits_equal(feeds[i], single), (W, rep)
+        idx = np.array([199, 3, 64, 130])
+        feeds, per_chr = panel.lod_feed_multi(Ws[:3], 0.001, mg, steps=[7, 100, 33], ind_idx=idx)
+        for i, (W, step) in enumerate(zip(Ws[:3], (7, 100, 33))):
+            want = [ol.oracle_flatten_subset(w, step, idx) for w in wins[W]]
+            assert [len(w) for w in want] == list(per_chr[i]), (W, step)
+            assert ol.bits_equal(feeds[i], np.concatenate(want)), (W, step)
+        feeds, _ = panel.lod_feed_multi([100, 50], 0.001, mg, steps=[1, 50])     # step 1: full scores, sampled
+        assert ol.bits_equal(feeds[0], np.concatenate([ol.oracle_flatten(w, 1) for w in wins[100]]))
+        assert ol.bits_equal(feeds[1], np.concatenate([ol.oracle_flatten(w, 50) for w in wins[50]]))
+        monkeypatch.setenv("GARLIC_FEED_SERIAL", "1")
+        feeds, _ = panel.lod_feed_multi(Ws, 0.001, mg)
+        for i, W in enumerate(Ws):
+            assert ol.bits_equal(feeds[i], np.concatenate([ol.oracle_flatten(w, W) for w in wins[W]])), W
+        with pytest.raises(abi.GarlicError):
+            panel.lod_feed_multi([100, 1], 0.001, mg)
+
+
 @pytest.mark.parametrize("W,step,nind", [(2, 4, 64), (5, 31, 65), (33, 32, 1), (129, 5, 130), (1100, 64, 70)])
 def test_lod_feed_thinned_edge_shapes(gpu_ctx, W, step, nind):
     """thinned write-out at the edges: windows narrower than a tile and than the step, a step of one

@@ -60,7 +60,7 @@ V_BUF = [68, 84]        # two term buffers: 4 steps x {t_in, t_out} (16 register
 V_ACC = 100             # 8 accumulators of the current batch (16 registers)
 V_LANE4 = 116           # lane * 4: genotype word offset inside a word row
 V_DMAOFF = 117          # lane * 4 + wave * 256: this wave's quarter of a chunk
-V_STOFF = 118           # lane * row pitch (bytes) of the sample matrix
+V_STOFF = 118           # the lane's row * row pitch (bytes) of the sample matrix
 V_S = 120               # the sampled accumulator (2 registers)
 V_FUN = 122             # funnel-shifted genotype words being spread (2 registers: entering, leaving)
 CLOBBER_V = list(range(20, 124))
@@ -75,7 +75,7 @@ S_SHL, S_SHT = 53, 54   # funnel shifts of the two streams
 S_W256 = 55             # wave * 256
 S_TMP = 56
 S_IDX = 57
-S_MASK, S_EXEC = 58, 60   # lanes that are rows of the shard; saved exec
+S_MASK, S_EXEC = 58, 60   # lanes that have a row in the sample matrix; saved exec
 CLOBBER_S = list(range(40, 62))
 
 MASK = "0x18181818"
@@ -192,7 +192,7 @@ def gen_capture(g_, u, b):
     e(f"v_mov_b32_e32 v{V_S}, v{V_ACC}")
     e(f"v_mov_b32_e32 v{V_S + 1}, v{V_ACC + 1}")
     e("s_set_gpr_idx_off")
-    e(f"s_mov_b64 exec, s[{S_MASK}:{S_MASK + 1}]")          # rows past the shard's last individual: not stored
+    e(f"s_mov_b64 exec, s[{S_MASK}:{S_MASK + 1}]")          # individuals without a row: not stored
     e(f"global_store_dwordx2 v{V_STOFF}, {pair(V_S)}, s[{S_OUT}:{S_OUT + 1}]")
     e(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
     e(f"s_add_u32 s{S_OUT}, s{S_OUT}, 8")
@@ -308,8 +308,8 @@ def gen_all():
     e(f"s_mov_b32 s{S_SHL}, %[shl]")
     e(f"s_mov_b32 s{S_SHT}, %[sht]")
     e(f"s_mov_b64 s[{S_EXEC}:{S_EXEC + 1}], exec")
-    e(f"v_cmp_lt_u32_e64 s[{S_MASK}:{S_MASK + 1}], %[lane], %[rows]")
-    e(f"v_mul_lo_u32 v{V_STOFF}, %[lane], %[pitch8]")
+    e(f"v_cmp_le_i32_e64 s[{S_MASK}:{S_MASK + 1}], 0, %[row]")     # lanes with a row in the sample matrix
+    e(f"v_mul_lo_u32 v{V_STOFF}, %[row], %[pitch8]")
     e(f"v_mov_b64 {pair(V_ACC + 14)}, %[acc]")
     # words 0..6 of both streams (tile t funnel-shifts words 2t .. 2t + 3); the loop loads from word 7 on
     for ring, ptr in ((V_WL, S_PLW), (V_WT, S_PTW)):
