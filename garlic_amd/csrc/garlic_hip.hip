@@ -905,7 +905,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // transposed write-out patch only while rows + patch keep 8 workgroups (32 waves) on a CU
     const size_t wlod_rows = wlod_gl ? 0 : sizeof(double) * (size_t)(W + TILE) * 4;
     const size_t wlod_patch = sizeof(double) * (size_t)WAVE * WT_PITCH;
-    const bool wlod_use_patch = wlod_rows + 16 + wlod_patch <= 160 * 1024 / 8;
+    const bool wlod_use_patch = wlod_rows + 16 + wlod_patch <= 160 * 1024 / 8 && !getenv("GARLIC_WLOD_NO_PATCH");
     // term-matrix variant: the hand-scheduled loop stages the block's term rows through one LDS ring
     // per wave; it needs a block-aligned shard (a wave's 64 lanes = one block of the matrix)
     const bool wlod_gl_ring = wlod_gl && !wlod_small && (ind_begin & (WAVE - 1)) == 0 && !getenv("GARLIC_WLOD_GL_NO_RING");
@@ -1078,7 +1078,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         const int per_wg = two_blocks ? WLOD2_BLOCKS : WLOD_WAVES;
         const int nquad = (nblk + per_wg - 1) / per_wg;
         WlodArgs a{p->d_valid.p, p->d_chrs.p, p->d_tiles.p, p->nwordrows, p->nchr, ind_begin, ind_count, W, nquad,
-                   (uint32_t)((int64_t)p->plan.n_tiles * nquad), (wlod_gl_ring ? ring_patch : wlod_use_patch) ? 1 : 0,
+                   (uint32_t)((int64_t)p->plan.n_tiles * nquad), ((wlod_gl_ring ? ring_patch : wlod_use_patch) ? 1 : 0) | (getenv("GARLIC_WLOD_NO_PF") ? 2 : 0),
                    (int64_t)(GOFF + p->nloci + GPAD_BACK), wlod_gl_ring ? 1 : 0};
         const uint32_t *a_packed = p->d_packed.p;
         const double *a_wtab = wlod_gl ? p->d_glterms.p : p->d_wtab.p, *a_skew = p->d_skew.p + SKEW_FRONT;

@@ -809,7 +809,7 @@ __device__ __forceinline__ void wlod_write_group(double (&acc)[R], uint32_t gm, 
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = (gm != 0 && ((gm >> r) & 1u)) ? acc[r] : MISSING_D;
     const int sg = s0 + grp * R;
-    if (ALIGNED16 && p.use_patch) {
+    if (ALIGNED16 && (p.use_patch & 1)) {
         if (lane == 0)
             while (atomicCAS(patch_lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -967,7 +967,7 @@ wlod_tile_small_gl_kernel(const uint32_t *__restrict__ packed, const double *__r
 template <int R>
 __device__ __forceinline__ void wlod_group2(const double *rows, const uint32_t *packed, int64_t colA, int64_t colB,
                                             int64_t nwordrows, int64_t G, const double *Ds, int W, double (&acc)[R],
-                                            double (&bcc)[R])
+                                            double (&bcc)[R], bool touch_ahead)
 {
     static_assert(R == 16, "the hand-scheduled loop keeps 16 weights per step in SGPRs");
     uint64_t gaddr = reinterpret_cast<uint64_t>(packed + packed_index(G >> 4, colA, nwordrows));
@@ -993,7 +993,7 @@ __device__ __forceinline__ void wlod_group2(const double *rows, const uint32_t *
                    [nextwb] "=&v"(nextwb), [gaddr] "+v"(gaddr), [gaddrb] "+v"(gaddrb), [bit] "+s"(bit),
                    [row] "+s"(row), [n] "+s"(n), [vd] "=&v"(vd)
                  : [dp] "s"(dp), [stride] "s"(stride), [rowbytes] "s"((uint64_t)(WAVE * 4)), [vz] "v"((uint32_t)GARLIC_WLOD_PFW * stride),
-                   [pfon] "s"(__builtin_amdgcn_readfirstlane(W <= GARLIC_WLOD_PFW_MAX_W ? 1 : 0))
+                   [pfon] "s"(__builtin_amdgcn_readfirstlane(touch_ahead && W <= GARLIC_WLOD_PFW_MAX_W ? 1 : 0))
                  : GARLIC_WLOD_LOOP_CLOBBERS);
 }
 
@@ -1039,7 +1039,7 @@ wlod_tile2_kernel(const uint32_t *__restrict__ packed, const double *__restrict_
         const uint32_t gm = (vm >> (grp * R)) & ((1u << R) - 1u);
         if (gm != 0)
             wlod_group2<R>(rows + grp * R * 4, packed, colA, colB, p.nwordrows, G0 + grp * R,
-                           D + (c.loc_base + s0 + grp * R) * (int64_t)W, W, acc, bcc);
+                           D + (c.loc_base + s0 + grp * R) * (int64_t)W, W, acc, bcc, (p.use_patch & 2) == 0);
         wlod_write_group<R, ALIGNED16>(acc, gm, c, p, out, patch, patch_lock, ind0A, s0, grp, lane);
         if (activeB) wlod_write_group<R, ALIGNED16>(bcc, gm, c, p, out, patch, patch_lock, ind0B, s0, grp, lane);
     }

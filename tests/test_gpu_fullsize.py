@@ -130,6 +130,50 @@ def test_variants_200k_by_1000_sampled_parity(gpu_ctx):
                 assert ol.bits_equal(blk[sample].cpu().numpy(), want), (name, c)
 
 
+def test_run_to_run_determinism_200k_by_1000(gpu_ctx):
+    """every score kernel, many launches into one buffer, each result bit for bit the first one.  (The two-block wLOD
+    loop once waited for its look-ahead genotype word with a COUNT of the vector loads issued behind it; with more than
+    63 of them outstanding the wave's VM counter let a stale word through about once in a hundred launches, 2048 wrong
+    scores each time -- and tests that look at one launch pass 99 times in a hundred.)"""
+    import torch
+    nloci, nind, W, mg = 200_000, 1000, 100, 200000
+    spec = synth.PanelSpec(nloci, seed=20260106, max_gap=mg)
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(13)
+    with abi.Panel(gpu_ctx, spec.chr_nloci, nind) as panel:
+        panel.set_map(spec.pos, spec.centro_start, spec.centro_end, gpos=spec.gpos)
+        panel.set_freq(spec.freq)
+        for l0, g in synth.genotype_chunks(spec, nind, dev):
+            gq = torch.randint(3, 61, g.shape, generator=gen, device=dev).to(torch.float64)
+            gl = torch.pow(torch.tensor(10.0, dtype=torch.float64, device=dev), -gq / 10.0)
+            torch.cuda.synchronize()
+            panel.set_genotypes_device(g.data_ptr(), g.shape[1], l0, g.shape[0])
+            panel.set_gl_device(gl.data_ptr(), gl.shape[1], l0, gl.shape[0])
+        panel.compute_ld(W, sub_idx=np.arange(0, nind, 10, dtype=np.int32), want_output=False)
+        base, pitch, total = panel.out_layout(32, nind)
+        out = torch.empty(total, dtype=torch.float64, device=dev)
+        runs = {
+            "wlod": (150, lambda: panel.wlod_windows_device(out.data_ptr(), W, 0.001, mg, 7, 1e-9)),
+            "wlod_gl": (100, lambda: panel.wlod_windows_device(out.data_ptr(), W, 0.001, mg, 7, 1e-9, use_gl=True)),
+            "lod": (60, lambda: panel.lod_windows_device(out.data_ptr(), W, 0.001, mg)),
+            "tgls": (60, lambda: panel.lod_windows_device(out.data_ptr(), W, 0.001, mg, use_gl=True)),
+        }
+        for name, (reps, call) in runs.items():
+            first = None
+            for rep in range(reps):
+                out.fill_(float("nan"))
+                torch.cuda.synchronize()
+                call()
+                torch.cuda.synchronize()
+                if first is None:
+                    first = out.clone()
+                else:
+                    assert torch.equal(out.view(torch.int64), first.view(torch.int64)), (name, rep)
+        feeds = [panel.lod_feed(W, 0.001, mg, W)[0] for _ in range(40)]
+        assert all(ol.bits_equal(f, feeds[0]) for f in feeds[1:])
+
+
 @pytest.mark.parametrize("W,step", [(100, 100), (50, 50), (100, 7)])
 def test_c2_thinned_feed_equals_feed_of_full_scores(c2_panel, W, step):
     """at C2 size (1M SNPs x 1000 individuals): the feed the chain kernel thins itself

@@ -104,19 +104,13 @@ class Gen:
     def e(self, s):
         self.out.append(s)
 
-    def switch_wait(self, counted=False):
-        """before nextw (requested 16 steps earlier) is consumed at a word switch; `counted`: the 16 steps since
-        have each issued PFW_LOADS touches behind it (vector loads return in order) -- unless they are switched off"""
-        e = self.e
-        if counted:
-            self.uid += 1
-            e(f"s_cbranch_vccz WL_SW0_{self.uid}_%=")
-            e(f"s_waitcnt vmcnt({16 * PFW_LOADS})")
-            e(f"s_branch WL_SW1_{self.uid}_%=")
-            e(f"WL_SW0_{self.uid}_%=:")
-        e("s_waitcnt vmcnt(0)")
-        if counted:
-            e(f"WL_SW1_{self.uid}_%=:")
+    def switch_wait(self):
+        """before nextw (requested 16 steps earlier) is consumed at a word switch.  vmcnt(0), not a count of the touches
+        issued behind it: with two touches per step up to 66 vector loads of a wave are outstanding between two switches,
+        the wave's VM counter holds 63, and a counted wait then let a stale genotype word through about once in a
+        hundred launches (both blocks of one group wrong; found by tools/exp/repeat_determinism.py).  Waiting for
+        everything every 16 steps costs 0.5 % and also bounds what is outstanding to 34."""
+        self.e("s_waitcnt vmcnt(0)")
 
     def step(self, parity, windows, prefetch=True, pf=True):
         cur, nxt, sc, scn = regs_of(parity)
@@ -146,7 +140,7 @@ class Gen:
             e("s_cmp_eq_u32 %[bit], 32")
             e(f"s_cbranch_scc0 WL_SAMEWORD_{uid}_%=")
             e("s_mov_b32 %[bit], 0")
-            self.switch_wait(counted=bool(PFW and self.nb == 2 and pf))
+            self.switch_wait()
             for word, nextw, gaddr in (("word", "nextw", "gaddr"), ("wordb", "nextwb", "gaddrb"))[:self.nb]:
                 e(f"v_mov_b32_e32 %[{word}], %[{nextw}]")
                 e(f"global_load_dword %[{nextw}], %[{gaddr}], off")
@@ -240,6 +234,7 @@ class StripGen(Gen):
                 e(f"s_cbranch_vccz WL_NOPF_{uid}_%=")
                 for off in (0, 64, 124)[:PFW_LOADS]:
                     e(f"global_load_dword %[vd], %[vz], s[{S_DP}:{S_DP + 1}] offset:{off}")
+                e("s_waitcnt vmcnt(32)")      # the touches are this loop's only vector loads: never more than the VM counter holds
                 e(f"WL_NOPF_{uid}_%=:")
         scb = "scb" if sc == "sc" else "scnb"
         for r in windows:
