@@ -914,6 +914,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // blocks' term rows enter a CU once per strip (wlod_strip_kernel.hpp)
     const int strip_waves = (W + 15 - 16 * WS_WAVES <= 16 || getenv("GARLIC_WLOD_STRIP_NARROW_ONLY")) ? WS_WAVES : WS_WAVES_WIDE;
     const bool wlod_gl_strip = wlod_gl_ring && W + 15 - 16 * strip_waves <= 16 && !getenv("GARLIC_WLOD_GL_NO_STRIP");
+    bool strip_now = wlod_gl_strip;        // false for the rerun after a strip launch that reported a stalled wave
     const size_t wlod_lds = wlod_gl_ring ? WLOD_GL_RING_OFF + (size_t)WLOD_WAVES * GARLIC_WLOD_GL_RING_ROWS * WAVE * 8
                                    : wlod_rows + 16 + (wlod_use_patch ? wlod_patch : 0);   // 16: the patch lock
 
@@ -1101,11 +1102,12 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                                                   : (const void *)wlod_tile_small_kernel<WLOD_R, false>);
             void *kargs[] = {(void *)&a_packed, (void *)&a_wtab, (void *)&a_skew, (void *)&d_out, (void *)&a};
             HIP_TRY(hipLaunchKernel(fn, dim3(wl_grid), wl_block, kargs, wlod_lds, ctx->stream));
-        } else if (wlod_gl_strip) {
+        } else if (strip_now) {
             const int n_pairs = (nblk + 1) / 2;
             WlodStripArgs sa{p->d_valid.p, p->d_chrs.p, p->d_strips.p, p->d_glterms.p, a_skew, d_out,
                              (int64_t)(GOFF + p->nloci + GPAD_BACK), ind_begin, ind_count, W, strip_waves, n_pairs,
-                             ring_patch ? 1 : 0, (uint32_t)((int64_t)p->plan.n_strips * n_pairs)};
+                             ring_patch ? 1 : 0, (uint32_t)((int64_t)p->plan.n_strips * n_pairs), p->d_counter.p + 3};
+            HIP_TRY(hipMemsetAsync(p->d_counter.p + 3, 0, sizeof(int32_t), ctx->stream));
             const unsigned grid = (sa.n_work + 7u) / 8u * 8u;
             const bool wide = strip_waves == WS_WAVES_WIDE;
             const void *fn = wide ? (aligned16 ? (const void *)wlod_strip_gl_kernel<true, WS_WAVES_WIDE>
@@ -1248,6 +1250,17 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         p->last_chain_kind = found ? 2 : 1;
         if (found) {
             exact = true;
+            if ((rc = enqueue())) return rc;
+        }
+    }
+    if (strip_now) {
+        // a wave of the strip kernel that ran out of its poll budget has flagged the launch (its scores are wrong):
+        // the tile form computes the same values without waits between waves
+        int32_t stalled = 0;
+        HIP_TRY(hipMemcpyAsync(&stalled, p->d_counter.p + 3, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (stalled || getenv("GARLIC_WLOD_STRIP_FORCE_RERUN")) {
+            strip_now = false;
             if ((rc = enqueue())) return rc;
         }
     }

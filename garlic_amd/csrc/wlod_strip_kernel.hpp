@@ -62,6 +62,9 @@ struct WlodStripArgs {
     int64_t term_rows;
     int32_t ind_begin, ind_count, winsize, n_waves, n_pairs, use_patch;
     uint32_t n_work;           // strips x pairs
+    int32_t *stalled;          // set to 1 when a wave gives up waiting (its results are then wrong): the host reruns the
+                               // call with the tile form.  A poll budget measures time, not progress -- under a
+                               // counter-serialising profiler a correct run may exhaust it -- so nothing traps.
 };
 
 // flag rows: lane i's copy at row + 8 i
@@ -145,13 +148,15 @@ __device__ __forceinline__ void ws_wait_pairs(int pairs)
 }
 
 // loader wave: rows 0 .. n_rows-1 (n_rows even) of both blocks into the rings, two rows per request
-__device__ __forceinline__ void ws_loader(const double *srcA, const double *srcB, int n_rows, uint32_t ring_lds, int lane)
+__device__ __forceinline__ void ws_loader(const double *srcA, const double *srcB, int n_rows, uint32_t ring_lds, int lane,
+                                          int32_t *stalled)
 {
+    bool gave_up = false;
     const uint32_t lane16 = (uint32_t)lane * 16u, lane8b = ring_lds + (uint32_t)lane * 8u;
     uint32_t slot_off = 0;
     int inflight = 0, published = 0, min_need = 0;
     for (int r = 0; r < n_rows; r += 2) {
-        if (r + 2 - min_need > WS_RING) {
+        if (!gave_up && r + 2 - min_need > WS_RING) {
             // no room: meanwhile retire and publish what is in flight, oldest first (a compute wave may be waiting
             // for exactly those rows -- never block with unpublished rows)
             int budget = 1 << 22;
@@ -161,7 +166,11 @@ __device__ __forceinline__ void ws_loader(const double *srcA, const double *srcB
                     published += 2;
                     ws_row_write(lane8b, WS_LANDED_OFF, published);
                 } else {
-                    if (--budget == 0) __builtin_trap();
+                    if (--budget == 0) {     // say so and stream on without waiting: every wave drains, the host reruns
+                        if (lane == 0) __hip_atomic_store(stalled, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gave_up = true;
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
@@ -218,7 +227,7 @@ wlod_strip_gl_kernel(WlodStripArgs p)
         const double *srcB = activeB ? srcA + p.term_rows * WAVE : srcA;   // no second block: the first one again
         const int n_rows = (16 * (st.n_groups - 1) + W + 15 + 1) & ~1;
         __builtin_amdgcn_s_setprio(3);     // few instructions, and everybody waits for them
-        ws_loader(srcA, srcB, n_rows, ring_lds, lane);
+        ws_loader(srcA, srcB, n_rows, ring_lds, lane, p.stalled);
         return;
     }
     const uint32_t lane8b = ring_lds + (uint32_t)lane * 8u;
@@ -235,7 +244,11 @@ wlod_strip_gl_kernel(WlodStripArgs p)
             uint32_t polls = 1u << 20;
             wlod_group_gls(lane8b, needoff, p.D + (c.loc_base + s) * (int64_t)W, W, (uint32_t)(16 * g),
                            (uint32_t)next_row, landed_seen, polls, acc, bcc);
-            if (polls == 0) __builtin_trap();
+            if (polls == 0) {            // rows that never came: flag the launch, release the loader, leave
+                if (lane == 0) __hip_atomic_store(p.stalled, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ws_row_write(lane8b, needoff, WS_NEVER);
+                break;
+            }
         }
         ws_row_write(lane8b, needoff, next_row);
         wlod_write_group<WLOD_R, ALIGNED16>(acc, gm, c, p, p.out, patch, patch_lock, ind0A, s, 0, lane);

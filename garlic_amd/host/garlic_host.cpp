@@ -6,6 +6,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -609,7 +610,7 @@ void writeFreqData(const std::string &freqOutfile, std::vector<FreqData *> *freq
         for (int l0 = 0; l0 < maps->at(c)->nloci; l0 += 100000)
             chunks.push_back(Chunk{c, l0, std::min(maps->at(c)->nloci, l0 + 100000)});
     const unsigned nthreads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-    bool failed = false;
+    std::atomic<bool> failed{false};   // set by the compression threads
     {
         const std::string m = gzip_member("CHR\tSNP\tPOS\tALLELE\tFREQ\n");
         failed = fwrite(m.data(), 1, m.size(), f) != m.size();
@@ -1470,7 +1471,7 @@ void writeWinData(std::vector<WinData *> *wins, IndData *indData, std::vector<Ma
             const int ntasks = std::min<int>((int)nthreads, (w->nind - i0 + per - 1) / per);
             std::vector<std::string> members((size_t)ntasks);
             std::vector<std::thread> pool;
-            bool failed = false;
+            std::atomic<bool> failed{false};   // set by the compression threads
             for (int t = 0; t < ntasks; t++)
                 pool.emplace_back([&, t]() {
                     std::string text;
