@@ -26,18 +26,16 @@ def same(a, b):
     return np.array_equal(a[ok].view(np.uint64), b[ok].view(np.uint64))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--trials", type=int, default=150)
-    ap.add_argument("--seed", type=int, default=1)
-    args = ap.parse_args()
+def soak(ctx, trials, seed, verbose=True):
+    """`trials` random panels through every variant on context `ctx`; returns (checks, failures).
+    tests/test_gpu_soak.py runs a 60-panel slice of this in the -m gpu suite."""
     import oracle_lib as ol
     from garlic_amd import abi
 
-    rng = np.random.default_rng(args.seed)
-    ctx = abi.Context(0)
+    rng = np.random.default_rng(seed)
     fails, checks, t0 = 0, 0, time.time()
-    for trial in range(args.trials):
+    strip_env = os.environ.get("GARLIC_WLOD_STRIP_GROUPS")
+    for trial in range(trials):
         nchr = int(rng.integers(1, 4))
         W = int(rng.choice([2, 5, 16, 17, 31, 32, 33, 64, 100, 130]))
         sizes = [int(rng.choice([1, W - 1, W, W + 1, int(rng.integers(2 * W, 40 * W + 300))])) for _ in range(nchr)]
@@ -132,8 +130,31 @@ def main():
                 if not ol.bits_equal(np.ascontiguousarray(out[c]), ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, err, mg, 1e-9, 7, gl=gl[c])):
                     fails += 1
                     print("FAIL wlod+gl", c, tag)
-        if trial % 10 == 9:
+            # a multi-size feed: the sizes the single calls above have checked
+            W2 = int(rng.choice([4, 9, 40, 70]))
+            feeds, per_chr = panel.lod_feed_multi([W, W2], err, mg, steps=[max(4, W), 5])
+            for k, (Wk, sk) in enumerate(((W, max(4, W)), (W2, 5))):
+                want = [ol.oracle_flatten(ol.oracle_calc_lod(g, f, p, cs, ce, Wk, err, mg), sk) for g, f, p, cs, ce in chroms]
+                checks += 1
+                if [len(w) for w in want] != list(per_chr[k]) or not ol.bits_equal(feeds[k], np.concatenate(want)):
+                    fails += 1
+                    print("FAIL feed_multi", Wk, sk, tag)
+        if verbose and trial % 10 == 9:
             print(f"trial {trial + 1}: {checks} checks, {fails} failures, {time.time() - t0:.0f} s", flush=True)
+    if strip_env is None:
+        os.environ.pop("GARLIC_WLOD_STRIP_GROUPS", None)
+    else:
+        os.environ["GARLIC_WLOD_STRIP_GROUPS"] = strip_env
+    return checks, fails
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    from garlic_amd import abi
+    checks, fails = soak(abi.Context(0), args.trials, args.seed)
     print(f"soak: {args.trials} panels, {checks} checks, {fails} failures")
     sys.exit(1 if fails else 0)
 
