@@ -29,7 +29,8 @@ SYMBOLS = [
     "garlic_panel_release_scratch",
     "garlic_lod_feed", "garlic_ctx_set_async",
     "garlic_recent_kernel_ms", "garlic_panel_tgls_mode", "garlic_lod_feed_subset", "garlic_lod_feed_multi",
-    "garlic_device_alloc", "garlic_device_free", "garlic_panel_chain_kind",
+    "garlic_device_alloc", "garlic_device_free", "garlic_panel_chain_kind", "garlic_device_alloc_stats",
+    "garlic_panel_alloc_scores",
 ]
 
 
@@ -74,6 +75,9 @@ def lib():
     L.garlic_ctx_synchronize.argtypes = [_vp]
     L.garlic_ctx_set_async.argtypes = [_vp, C.c_int32]
     L.garlic_device_alloc.argtypes = [_vp, C.c_int64, C.POINTER(_vp)]
+    L.garlic_device_alloc_stats.argtypes = [_vp, _i64p, _i64p, _i64p]
+    L.garlic_panel_alloc_scores.argtypes = [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.POINTER(_vp),
+                                            C.POINTER(C.c_float)]
     L.garlic_device_free.argtypes = [_vp, _vp]
     L.garlic_recent_kernel_ms.argtypes = [_vp, C.POINTER(C.c_float), C.c_int32, _i32p]
     L.garlic_panel_create.argtypes = [_vp, C.c_int32, _i32p, C.c_int32, C.POINTER(_vp)]
@@ -149,8 +153,14 @@ class Context:
         check(lib().garlic_ctx_set_async(self.handle, int(on)))
 
     def alloc_scores(self, n_doubles):
-        """device memory for a score matrix through garlic_device_alloc (reproducible placement, see garlic_hip.h)"""
+        """device memory for a score matrix through garlic_device_alloc (pooled; see garlic_hip.h)"""
         return DeviceBuffer(self, int(n_doubles) * 8)
+
+    def alloc_stats(self):
+        """garlic_device_alloc_stats: (live, pooled, reserved) bytes of score memory on this context's device"""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib().garlic_device_alloc_stats(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def close(self):
         if self.handle:
@@ -167,11 +177,13 @@ class Context:
 class DeviceBuffer:
     """garlic_device_alloc / garlic_device_free; `.ptr` for the device-output calls, `.tensor()` to look at it"""
 
-    def __init__(self, ctx, nbytes):
+    def __init__(self, ctx, nbytes, ptr=None):
         self.ctx, self.nbytes = ctx, nbytes
-        p = _vp()
-        check(lib().garlic_device_alloc(ctx.handle, nbytes, C.byref(p)))
-        self.ptr = p.value
+        if ptr is None:
+            p = _vp()
+            check(lib().garlic_device_alloc(ctx.handle, nbytes, C.byref(p)))
+            ptr = p.value
+        self.ptr = ptr
 
     def data_ptr(self):
         return self.ptr
@@ -464,6 +476,18 @@ class Panel:
                                           _ptr(idx, _i32p), 0 if idx is None else n_rows, ptrs, _ptr(caps, _i64p),
                                           _ptr(counts, _i64p), _ptr(per_chr, _i64p)))
         return [b[: int(n)] for b, n in zip(bufs, counts)], per_chr
+
+    def alloc_scores(self, winsize, error, max_gap, pitch_align=32, nind_out=None, candidates=0):
+        """garlic_panel_alloc_scores: score memory in the chain kernel's fast placement (the real kernel timed into
+        `candidates` buffers, the fastest kept).  Returns (DeviceBuffer, [kernel ms per candidate])."""
+        nind_out = self.nind if nind_out is None else nind_out
+        n = candidates if candidates > 0 else 4
+        ms = (C.c_float * n)()
+        ptr = _vp()
+        check(lib().garlic_panel_alloc_scores(self.handle, pitch_align, nind_out, winsize, error, max_gap, candidates,
+                                              C.byref(ptr), ms))
+        _, _, total = self.out_layout(pitch_align, nind_out)
+        return DeviceBuffer(self.ctx, int(total) * 8, ptr=ptr.value), [float(x) for x in ms]
 
     def chain_kind(self):
         """0 tuned chain, 1 tuned chain + scan for the value -9999.0 (none found), 2 by-value chain (garlic_hip.h)"""

@@ -130,6 +130,9 @@ struct garlic_ctx {
     int log10_state = 0;
 };
 
+static int score_alloc(garlic_ctx *ctx, size_t bytes, void **out);   // pooled score memory (below)
+static int score_free(garlic_ctx *ctx, void *ptr);
+
 struct garlic_panel {
     garlic_ctx *ctx = nullptr;
     int32_t nchr = 0;
@@ -223,7 +226,31 @@ struct garlic_panel {
     bool decay_valid = false;
     int32_t decay_M = 0;
     double decay_mu = 0;
-    DevBuf<double> d_out, d_feed;
+    // full-score scratch of the host-output and feed calls: pooled score memory, for big unweighted panels chosen by
+    // placement at first use (garlic_panel_alloc_scores) -- a caller that hands over host buffers cannot do that itself
+    struct ScoreBuf {
+        double *p = nullptr;
+        size_t cap = 0;
+        garlic_ctx *ctx = nullptr;
+        int reserve(garlic_ctx *c, size_t n)
+        {
+            if (n <= cap) return GARLIC_OK;
+            release();
+            void *q = nullptr;
+            int rc = score_alloc(c, n * sizeof(double), &q);
+            if (rc) return rc;
+            p = (double *)q; cap = n; ctx = c;
+            return GARLIC_OK;
+        }
+        void adopt(garlic_ctx *c, void *q, size_t n) { release(); p = (double *)q; cap = n; ctx = c; }
+        void release()
+        {
+            if (p) (void)score_free(ctx, p);
+            p = nullptr; cap = 0;
+        }
+    } d_out;
+    bool placing = false;                          // inside the placement probe of d_out
+    DevBuf<double> d_feed;
     // garlic_lod_feed_multi: one set of scratch and one stream per window size of the call, kept for the next call
     struct FeedSlot {
         hipStream_t stream = nullptr;
@@ -255,6 +282,150 @@ struct garlic_panel {
 };
 
 static int ensure_rld(garlic_panel *p);   // plain reciprocals of the LD weights, made when the generic wLOD kernel needs them
+
+// ---- Score buffers.  Where 8 GB of scores sit in VRAM decides between two speeds of lod_chain_kernel at 1M SNPs x
+// 1000 individuals (1.36 and 1.62 ms: DESIGN.md section 4, "placement"); a virtual range backed by physical chunks
+// of its own (HIP virtual memory management, 1 GB each) was in the fast mode more often than plain hipMalloc
+// memory.  Falls back to hipMalloc where the driver has no virtual memory management.
+//
+// Freed buffers stay MAPPED in a pool and are handed out again for requests they fit: measured on ROCm 7.2 / MI355X,
+// a virtual range that is unmapped and given new physical memory loses part of the first kernel's writes
+// (tools/exp/alloc_dbg.py, tools/exp/vmm_remap_repro.hip); a buffer that keeps its mapping has nothing to lose, and a
+// caller that allocates per sweep reuses the same few ranges instead of growing its address space.  The pool is
+// capped (GARLIC_ALLOC_POOL_GB, default a quarter of the device memory); what does not fit is unmapped and its
+// physical memory released, its range stays reserved (never mapped again: address space only, reported by
+// garlic_device_alloc_stats).
+struct ScoreAlloc {
+    void *ptr;
+    size_t size;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    int device;
+    bool pooled;          // free, still mapped
+    uint64_t stamp;       // when it was pooled (oldest goes first)
+};
+static std::mutex g_score_mutex;
+static std::vector<ScoreAlloc> g_score_allocs;
+static int64_t g_score_retired[16] = {};   // bytes of ranges kept reserved after their memory was released, per device
+static uint64_t g_score_clock = 0;
+
+static void release_score_alloc(ScoreAlloc &a, size_t mapped, bool keep_range)
+{
+    if (mapped) (void)hipMemUnmap(a.ptr, mapped);
+    for (auto h : a.handles) (void)hipMemRelease(h);
+    if (a.ptr && !keep_range) (void)hipMemAddressFree(a.ptr, a.size);
+}
+
+static int score_alloc(garlic_ctx *ctx, size_t bytes, void **out)
+{
+    *out = nullptr;
+    int vmm = 0;
+    (void)hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, ctx->device);
+    if (vmm && !getenv("GARLIC_ALLOC_PLAIN")) {
+        hipMemAllocationProp prop{};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = ctx->device;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran) {
+            const size_t chunk = (((size_t)1 << 30) + gran - 1) / gran * gran;
+            const size_t size = (bytes + gran - 1) / gran * gran;
+            {   // a pooled buffer that fits without wasting more than an eighth
+                std::lock_guard<std::mutex> lock(g_score_mutex);
+                int pick = -1;
+                for (size_t k = 0; k < g_score_allocs.size(); k++) {
+                    const ScoreAlloc &a = g_score_allocs[k];
+                    if (a.pooled && a.device == ctx->device && a.size >= size && a.size - size <= size / 8 &&
+                        (pick < 0 || a.size < g_score_allocs[(size_t)pick].size))
+                        pick = (int)k;
+                }
+                if (pick >= 0) {
+                    g_score_allocs[(size_t)pick].pooled = false;
+                    *out = g_score_allocs[(size_t)pick].ptr;
+                    return GARLIC_OK;
+                }
+            }
+            ScoreAlloc a{nullptr, size, {}, ctx->device, false, 0};
+            size_t mapped = 0;
+            bool ok = hipMemAddressReserve(&a.ptr, size, 0, nullptr, 0) == hipSuccess;
+            for (size_t off = 0; ok && off < size; off += chunk) {
+                const size_t n = std::min(chunk, size - off);
+                hipMemGenericAllocationHandle_t h;
+                ok = hipMemCreate(&h, n, &prop, 0) == hipSuccess;
+                if (!ok) break;
+                a.handles.push_back(h);
+                ok = hipMemMap((char *)a.ptr + off, n, 0, h, 0) == hipSuccess;
+                if (ok) mapped = off + n;
+            }
+            if (ok) {
+                hipMemAccessDesc acc{};
+                acc.location = prop.location;
+                acc.flags = hipMemAccessFlagsProtReadWrite;
+                ok = hipMemSetAccess(a.ptr, size, &acc, 1) == hipSuccess;
+            }
+            if (ok) {
+                *out = a.ptr;
+                std::lock_guard<std::mutex> lock(g_score_mutex);
+                g_score_allocs.push_back(std::move(a));
+                return GARLIC_OK;
+            }
+            release_score_alloc(a, mapped, mapped != 0);
+            (void)hipGetLastError();
+            {   // out of device memory with buffers idle in the pool: give those back and try once more
+                std::unique_lock<std::mutex> lock(g_score_mutex);
+                bool any = false;
+                for (size_t k = 0; k < g_score_allocs.size();) {
+                    ScoreAlloc &b = g_score_allocs[k];
+                    if (b.pooled && b.device == ctx->device) {
+                        release_score_alloc(b, b.size, true);
+                        g_score_retired[ctx->device < 16 ? ctx->device : 15] += (int64_t)b.size;
+                        g_score_allocs.erase(g_score_allocs.begin() + (long)k);
+                        any = true;
+                    } else k++;
+                }
+                lock.unlock();
+                if (any) return score_alloc(ctx, bytes, out);
+            }
+        }
+    }
+    HIP_TRY(hipMalloc(out, bytes));
+    return GARLIC_OK;
+}
+
+static int score_free(garlic_ctx *ctx, void *ptr)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_score_mutex);
+        for (size_t k = 0; k < g_score_allocs.size(); k++)
+            if (g_score_allocs[k].ptr == ptr && !g_score_allocs[k].pooled) {
+                HIP_TRY(hipDeviceSynchronize());
+                g_score_allocs[k].pooled = true;
+                g_score_allocs[k].stamp = ++g_score_clock;
+                // cap the pool: the oldest idle buffers give their memory back (their ranges stay reserved, unmapped for good)
+                size_t total_mem = 0, free_mem = 0;
+                (void)hipMemGetInfo(&free_mem, &total_mem);
+                int64_t cap = (int64_t)(total_mem / 4);
+                if (const char *e = getenv("GARLIC_ALLOC_POOL_GB")) cap = (int64_t)(atof(e) * 1073741824.0);
+                for (;;) {
+                    int64_t pooled = 0;
+                    int oldest = -1;
+                    for (size_t j = 0; j < g_score_allocs.size(); j++) {
+                        const ScoreAlloc &a = g_score_allocs[j];
+                        if (!a.pooled || a.device != ctx->device) continue;
+                        pooled += (int64_t)a.size;
+                        if (oldest < 0 || a.stamp < g_score_allocs[(size_t)oldest].stamp) oldest = (int)j;
+                    }
+                    if (pooled <= cap || oldest < 0) break;
+                    ScoreAlloc &b = g_score_allocs[(size_t)oldest];
+                    release_score_alloc(b, b.size, true);
+                    g_score_retired[ctx->device < 16 ? ctx->device : 15] += (int64_t)b.size;
+                    g_score_allocs.erase(g_score_allocs.begin() + oldest);
+                }
+                return GARLIC_OK;
+            }
+    }
+    HIP_TRY(hipFree(ptr));
+    return GARLIC_OK;
+}
 
 namespace {
 
@@ -921,6 +1092,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // Host output: the device always computes into the padded layout the tuned kernels need; the
     // rows are copied out into the caller's (possibly dense) layout by strided D2H copies.
     const Layout Lhost = make_layout(p, pitch_align, ind_count);
+    const int32_t pitch_align_host = pitch_align;
     if (where == GARLIC_HOST) pitch_align = std::max(pitch_align, 32);
     Layout L = make_layout(p, pitch_align, ind_count, thin_step);
     for (int c = 0; c < p->nchr; c++)
@@ -1028,7 +1200,19 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
 
     double *d_out = out;
     if (where == GARLIC_HOST) {
-        if ((rc = p->d_out.reserve((size_t)L.total))) return rc;
+        // big unweighted score scratch: several candidates, the real kernel timed into each, the fastest kept
+        // (the same kernel runs 1.36 or 1.62 ms at 1M x 1000 depending on where its scores sit: DESIGN.md section 4)
+        if (p->d_out.cap < (size_t)L.total && mode == MODE_LOD && thin_step == 0 && !p->placing &&
+            (size_t)L.total * sizeof(double) >= ((size_t)1 << 30) && !getenv("GARLIC_NO_PLACEMENT")) {
+            p->placing = true;
+            void *best = nullptr;
+            rc = garlic_panel_alloc_scores(p, pitch_align, ind_count, W, error, max_gap, 0, &best, nullptr);
+            p->placing = false;
+            if (rc) return rc;
+            p->d_out.adopt(ctx, best, (size_t)L.total);
+            return launch_lod(p, mode, W, error, max_gap, M, mu, ind_begin, ind_count, pitch_align_host, out, where, thin_step, blocks);
+        }
+        if ((rc = p->d_out.reserve(ctx, (size_t)L.total))) return rc;
         d_out = p->d_out.p;
     }
     const bool aligned16 = (pitch_align % 2 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15) == 0);
@@ -2307,9 +2491,9 @@ static int feed_single(garlic_panel *p, int32_t winsize, double error, int32_t m
         if (lod_exact_needed(p, MODE_LOD, winsize)) thinned = 0;
     }
     const Layout L = make_layout(p, 32, p->nind, thinned);
-    DevBuf<double> &scores = p->d_out;
+    garlic_panel::ScoreBuf &scores = p->d_out;
     DevBuf<double> &d_feed = p->d_feed;            // kept with the panel: window-size sweeps call this repeatedly
-    if ((rc = scores.reserve((size_t)L.total))) return done(rc);
+    if ((rc = scores.reserve(p->ctx, (size_t)L.total))) return done(rc);
     if (weighted) p->wlod_use_gl = use_gl != 0;
     rc = launch_lod(p, weighted ? MODE_WLOD : (use_gl ? MODE_LOD_GL : MODE_LOD), winsize, error, max_gap, M, mu, 0,
                     p->nind, 32, scores.p, GARLIC_DEVICE, thinned, ind_idx ? &blocks : nullptr);
@@ -2591,73 +2775,12 @@ int garlic_recent_kernel_ms(garlic_ctx *ctx, float *ms, int32_t n, int32_t *got)
     return GARLIC_OK;
 }
 
-// Score buffers.  Where 8 GB of scores sit in VRAM decides between two speeds of lod_chain_kernel at 1M SNPs x
-// 1000 individuals (1.36 and 1.62 ms: DESIGN.md section 4, "placement"); a virtual range backed by physical chunks
-// of its own (HIP virtual memory management, 1 GB each) was in the fast mode more often than plain hipMalloc
-// memory (33 of 36 allocations measured, against two out of three).  Falls back to hipMalloc where the driver has
-// no virtual memory management.
-struct ScoreAlloc { void *ptr; size_t size; std::vector<hipMemGenericAllocationHandle_t> handles; };
-static std::mutex g_score_mutex;
-static std::vector<ScoreAlloc> g_score_allocs;
-
-// keep_range: the virtual range stays reserved, so that no later allocation gets the same addresses.  Measured on
-// ROCm 7.2 / MI355X: a range that is unmapped, freed and handed out again by hipMemAddressReserve with new
-// physical memory behind it loses part of the first kernel's writes (stale translations) -- fresh addresses do
-// not.  An unmapped reservation costs address space only.
-static void release_score_alloc(ScoreAlloc &a, size_t mapped, bool keep_range)
-{
-    if (mapped) (void)hipMemUnmap(a.ptr, mapped);
-    for (auto h : a.handles) (void)hipMemRelease(h);
-    if (a.ptr && !keep_range) (void)hipMemAddressFree(a.ptr, a.size);
-}
-
 int garlic_device_alloc(garlic_ctx *ctx, int64_t bytes, void **out)
 {
     if (!ctx || !out || bytes < 1) return fail(GARLIC_ERR_INVALID, "context, size and result pointer are required");
     int rc;
     if ((rc = set_device(ctx))) return rc;
-    *out = nullptr;
-    int vmm = 0;
-    (void)hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, ctx->device);
-    if (vmm && !getenv("GARLIC_ALLOC_PLAIN")) {
-        hipMemAllocationProp prop{};
-        prop.type = hipMemAllocationTypePinned;
-        prop.location.type = hipMemLocationTypeDevice;
-        prop.location.id = ctx->device;
-        size_t gran = 0;
-        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran) {
-            const size_t chunk = (((size_t)1 << 30) + gran - 1) / gran * gran;
-            const size_t size = ((size_t)bytes + gran - 1) / gran * gran;
-            ScoreAlloc a{nullptr, size, {}};
-            size_t mapped = 0;
-            bool ok = hipMemAddressReserve(&a.ptr, size, 0, nullptr, 0) == hipSuccess;
-            for (size_t off = 0; ok && off < size; off += chunk) {
-                const size_t n = std::min(chunk, size - off);
-                hipMemGenericAllocationHandle_t h;
-                ok = hipMemCreate(&h, n, &prop, 0) == hipSuccess;
-                if (!ok) break;
-                a.handles.push_back(h);
-                ok = hipMemMap((char *)a.ptr + off, n, 0, h, 0) == hipSuccess;
-                if (ok) mapped = off + n;
-            }
-            if (ok) {
-                hipMemAccessDesc acc{};
-                acc.location = prop.location;
-                acc.flags = hipMemAccessFlagsProtReadWrite;
-                ok = hipMemSetAccess(a.ptr, size, &acc, 1) == hipSuccess;
-            }
-            if (ok) {
-                *out = a.ptr;
-                std::lock_guard<std::mutex> lock(g_score_mutex);
-                g_score_allocs.push_back(std::move(a));
-                return GARLIC_OK;
-            }
-            release_score_alloc(a, mapped, mapped != 0);
-            (void)hipGetLastError();
-        }
-    }
-    HIP_TRY(hipMalloc(out, (size_t)bytes));
-    return GARLIC_OK;
+    return score_alloc(ctx, (size_t)bytes, out);
 }
 
 int garlic_device_free(garlic_ctx *ctx, void *ptr)
@@ -2666,17 +2789,59 @@ int garlic_device_free(garlic_ctx *ctx, void *ptr)
     if (!ptr) return GARLIC_OK;
     int rc;
     if ((rc = set_device(ctx))) return rc;
-    {
-        std::lock_guard<std::mutex> lock(g_score_mutex);
-        for (size_t k = 0; k < g_score_allocs.size(); k++)
-            if (g_score_allocs[k].ptr == ptr) {
-                HIP_TRY(hipDeviceSynchronize());
-                release_score_alloc(g_score_allocs[k], g_score_allocs[k].size, true);
-                g_score_allocs.erase(g_score_allocs.begin() + k);
-                return GARLIC_OK;
-            }
+    return score_free(ctx, ptr);
+}
+
+int garlic_device_alloc_stats(garlic_ctx *ctx, int64_t *live_bytes, int64_t *pooled_bytes, int64_t *reserved_bytes)
+{
+    if (!ctx) return fail(GARLIC_ERR_INVALID, "context is required");
+    std::lock_guard<std::mutex> lock(g_score_mutex);
+    int64_t live = 0, pooled = 0;
+    for (const ScoreAlloc &a : g_score_allocs)
+        if (a.device == ctx->device) (a.pooled ? pooled : live) += (int64_t)a.size;
+    if (live_bytes) *live_bytes = live;
+    if (pooled_bytes) *pooled_bytes = pooled;
+    if (reserved_bytes) *reserved_bytes = live + pooled + g_score_retired[ctx->device < 16 ? ctx->device : 15];
+    return GARLIC_OK;
+}
+
+// Score memory in the chain kernel's fast placement: `candidates` buffers side by side, the real
+// kernel for `winsize` timed into each (one warm-up pass, two timed), the fastest kept, the others returned to the pool.
+int garlic_panel_alloc_scores(garlic_panel *p, int32_t pitch_align, int32_t nind_out, int32_t winsize, double error,
+                              int32_t max_gap, int32_t candidates, void **out, float *candidate_ms)
+{
+    if (!p || !out) return fail(GARLIC_ERR_INVALID, "panel and result pointer are required");
+    if (nind_out < 1 || nind_out > p->nind) return fail(GARLIC_ERR_INVALID, "nind_out outside the panel");
+    int rc;
+    if ((rc = set_device(p->ctx))) return rc;
+    *out = nullptr;
+    if (candidates <= 0) candidates = 4;
+    candidates = std::min(candidates, 16);
+    const Layout L = make_layout(p, pitch_align, nind_out);
+    std::vector<void *> cand((size_t)candidates, nullptr);
+    std::vector<float> ms((size_t)candidates, 0.f);
+    auto cleanup = [&](int keep) {
+        for (int k = 0; k < candidates; k++)
+            if (k != keep && cand[(size_t)k]) (void)score_free(p->ctx, cand[(size_t)k]);
+    };
+    for (int k = 0; k < candidates; k++)
+        if ((rc = score_alloc(p->ctx, sizeof(double) * (size_t)L.total, &cand[(size_t)k]))) { cleanup(-1); return rc; }
+    int best = 0;
+    for (int k = 0; k < candidates; k++) {
+        float acc = 0.f;
+        for (int pass = 0; pass < 3; pass++) {
+            if ((rc = launch_lod(p, MODE_LOD, winsize, error, max_gap, 0, 0.0, 0, nind_out, pitch_align, (double *)cand[(size_t)k],
+                                 GARLIC_DEVICE))) { cleanup(-1); return rc; }
+            garlic_call_stats st;
+            if ((rc = garlic_last_call_stats(p, &st))) { cleanup(-1); return rc; }
+            if (pass) acc += st.chain_kernel_ms;
+        }
+        ms[(size_t)k] = acc / 2;
+        if (ms[(size_t)k] < ms[(size_t)best]) best = k;
     }
-    HIP_TRY(hipFree(ptr));
+    if (candidate_ms) memcpy(candidate_ms, ms.data(), sizeof(float) * (size_t)candidates);
+    cleanup(best);
+    *out = cand[(size_t)best];
     return GARLIC_OK;
 }
 

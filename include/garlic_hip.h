@@ -41,7 +41,8 @@ extern "C" {
  * 3: likelihoods may be continuous (no 256-value limit), garlic_panel_tgls_mode; an LD subsample may be
  *    empty (sub_idx != NULL, n_sub = 0); garlic_lod_feed_subset
  * 4: garlic_device_alloc / garlic_device_free (score matrices), garlic_panel_chain_kind
- * 5: garlic_lod_feed_multi (the feeds of several window sizes in one call) */
+ * 5: garlic_lod_feed_multi (the feeds of several window sizes in one call); garlic_panel_alloc_scores,
+ *    garlic_device_alloc_stats */
 #define GARLIC_HIP_ABI_VERSION 5
 
 #define GARLIC_OK 0
@@ -79,16 +80,10 @@ int garlic_ctx_synchronize(garlic_ctx *ctx);
  * back (benchmarks, pipelines that consume the scores on the same stream). */
 int garlic_ctx_set_async(garlic_ctx *ctx, int32_t on);
 
-/* Device memory for score matrices (the `out` of garlic_lod_windows & co. with GARLIC_DEVICE).  Any device
- * pointer works as `out`.  Where 8 GB of scores sit in VRAM relative to the panel decides between two speeds of
- * the unweighted kernel at 1M SNPs x 1000 individuals (1.36 and 1.62 ms per pass: a property of the allocation,
- * DESIGN.md section 4); a virtual range backed by physical chunks of its own (HIP virtual memory management),
- * which this returns, was in the fast mode more often than plain hipMalloc memory (33 of 36 against two out of
- * three) -- a caller that cares times a few buffers and keeps the best, as bench.py does.  GARLIC itself has no
- * counterpart (WinData rows are host memory, garlic-data.cpp:1690); keep the buffer across window sizes as
- * GARLIC keeps its WinData.  Falls back to hipMalloc when the driver offers no virtual memory management. */
-int garlic_device_alloc(garlic_ctx *ctx, int64_t bytes, void **out);
-int garlic_device_free(garlic_ctx *ctx, void *ptr);
+/* Device memory for score matrices (the `out` of garlic_lod_windows & co. with GARLIC_DEVICE): any device pointer
+ * works as `out`; garlic_device_alloc / garlic_device_free / garlic_panel_alloc_scores (below, by the other score
+ * calls) hand out memory the unweighted kernel runs fastest into.  GARLIC itself has no counterpart (WinData rows
+ * are host memory, garlic-data.cpp:1690); keep the buffer across window sizes as GARLIC keeps its WinData. */
 /* HIP-event durations (ms) of the dominant kernel of the context's most recent window-score calls,
  * oldest first, at most 32: lets a caller time asynchronous passes without waiting for each.  Waits
  * for the stream.  *got = number of values written (<= n). */
@@ -314,6 +309,22 @@ int garlic_last_call_stats(garlic_panel *panel, garlic_call_stats *stats);
  * tuned chain; 1: possible -- the tuned chain ran, its scored windows were scanned, none was -9999.0; 2: one was
  * (or the environment forces it): the chain that follows the reference to the letter ran (11-17 x slower). */
 int garlic_panel_chain_kind(garlic_panel *panel, int32_t *kind);
+
+/* Score memory for where = GARLIC_DEVICE calls.  garlic_device_alloc: a virtual range backed by physical chunks of
+ * its own (HIP virtual memory management; hipMalloc where the driver has none).  Freed buffers stay mapped in a pool
+ * and are handed out again for requests they fit (a caller that allocates per sweep reuses the same few ranges; the
+ * pool is capped at a quarter of the device memory, GARLIC_ALLOC_POOL_GB).  garlic_device_alloc_stats: bytes handed
+ * out, bytes idle in the pool, bytes of address space reserved in all (any of the three may be NULL).
+ * Where a score buffer sits in VRAM decides between two speeds of the unweighted kernel (1.36 / 1.62 ms at 1M SNPs x
+ * 1000 individuals).  garlic_panel_alloc_scores allocates `candidates` (0 = 4) buffers for the
+ * layout garlic_lod_out_layout(pitch_align, nind_out), times the real kernel for `winsize` into each and keeps the
+ * fastest; candidate_ms (may be NULL): the kernel time into each candidate.  Free with garlic_device_free.  The
+ * library's own full-score scratch (host-output calls) is chosen the same way at first use. */
+int garlic_device_alloc(garlic_ctx *ctx, int64_t bytes, void **out);
+int garlic_device_free(garlic_ctx *ctx, void *ptr);
+int garlic_device_alloc_stats(garlic_ctx *ctx, int64_t *live_bytes, int64_t *pooled_bytes, int64_t *reserved_bytes);
+int garlic_panel_alloc_scores(garlic_panel *panel, int32_t pitch_align, int32_t nind_out, int32_t winsize, double error,
+                              int32_t max_gap, int32_t candidates, void **out, float *candidate_ms);
 
 #ifdef __cplusplus
 }
