@@ -2120,9 +2120,17 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
         loc = d_loc.p; pair = d_pair.p;
     }
     // pair counts: LDS-tiled (thread = distance, W - 1 <= 256; writes every entry of the table) or streamed from L2
-    const bool pair_tiled = winsize - 1 <= 256 && !getenv("GARLIC_LD_PAIR_L2");
+    // pair counts: a lane per SNP while the tile's plane words fit LDS (ld_pair_lane_kernel); else a thread per distance
+    // (ld_pair_tiled_kernel, W - 1 <= 256; writes every entry of the table too) or streamed from L2
+    const bool pair_flat = getenv("GARLIC_LD_PAIR_FLAT") && winsize <= 32;
+    const int lane_stage = std::min(nblk, getenv("GARLIC_LD_LANE_STAGE") ? atoi(getenv("GARLIC_LD_LANE_STAGE")) : 4);
+    const int lane_dc = winsize - 1 <= 16 ? 16 : 32;
+    const size_t lane_lds = sizeof(uint64_t) * (phased ? 4 : 2) * (size_t)lane_stage * (LD_LANE_T + winsize - 1);
+    const bool pair_lane = !pair_flat && winsize - 1 <= 256 && lane_lds <= 150 * 1024 && !getenv("GARLIC_LD_PAIR_TILED") &&
+                           !getenv("GARLIC_LD_PAIR_L2");
+    const bool pair_tiled = !pair_flat && !pair_lane && winsize - 1 <= 256 && !getenv("GARLIC_LD_PAIR_L2");
     hipError_t e = hipMemcpyAsync(d_sub.p, sub.data(), sizeof(uint64_t) * nblk, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && !pair_tiled) e = hipMemsetAsync(pair, 0, sizeof(int32_t) * npair, s);
+    if (e == hipSuccess && !pair_tiled && !pair_flat && !pair_lane) e = hipMemsetAsync(pair, 0, sizeof(int32_t) * npair, s);
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
     if (phased)
         hipLaunchKernelGGL(ld_planes_kernel<true>, dim3((unsigned)p->nwordrows), dim3(256), 0, s, p->d_packed.p,
@@ -2159,7 +2167,40 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
         if (e == hipSuccess) e = hipStreamSynchronize(s);   // pc (host) is read by the copy above
         if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
     }
-    for (int c = 0; !pair_tiled && c < p->nchr; c++) {
+    if (pair_lane) {   // all chromosomes in one grid, tiles of 256 SNPs
+        std::vector<LdPairChr> pc;
+        int64_t blocks = 0;
+        for (int c = 0; c < p->nchr; c++) {
+            pc.push_back(LdPairChr{p->chr_off[c], p->chr_off[c + 1], blocks});
+            blocks += (p->chr_nloci[c] + LD_LANE_T - 1) / LD_LANE_T;
+        }
+        DevBuf<LdPairChr> &d_pc = p->lds.pair_chrs;
+        if ((rc = d_pc.reserve(pc.size()))) return done(rc);
+        e = hipMemcpyAsync(d_pc.p, pc.data(), sizeof(LdPairChr) * pc.size(), hipMemcpyHostToDevice, s);
+        const void *fn = lane_dc == 16 ? (phased ? (const void *)ld_pair_lane_kernel<true, 16> : (const void *)ld_pair_lane_kernel<false, 16>)
+                                       : (phased ? (const void *)ld_pair_lane_kernel<true, 32> : (const void *)ld_pair_lane_kernel<false, 32>);
+        if (e == hipSuccess && lane_lds > 48 * 1024) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lane_lds);
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
+        const uint64_t *a_m = d_m.p, *a_h = d_h.p, *a_o = phased ? d_o.p : nullptr, *a_f = phased ? p->d_phase.p : nullptr;
+        const LdPairChr *a_pc = d_pc.p;
+        int a_nblk = nblk, a_nchr = p->nchr, a_w = winsize, a_stage = lane_stage;
+        int64_t a_nloci = p->nloci;
+        void *kargs[] = {(void *)&a_m, (void *)&a_h, (void *)&a_o, (void *)&a_f, (void *)&a_nblk, (void *)&a_nloci, (void *)&a_pc,
+                         (void *)&a_nchr, (void *)&a_w, (void *)&a_stage, (void *)&pair};
+        e = hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(LD_LANE_T), kargs, lane_lds, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);   // pc (host) is read by the copy above
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
+    }
+    if (pair_flat) {
+        const unsigned grid = (unsigned)(((int64_t)p->nloci * winsize + 255) / 256);
+        if (phased)
+            hipLaunchKernelGGL(ld_pair_flat_kernel<true>, dim3(grid), dim3(256), 0, s, d_m.p, d_h.p, d_o.p, p->d_phase.p, nblk,
+                               p->nloci, p->d_chr_off.p, p->nchr, winsize, pair);
+        else
+            hipLaunchKernelGGL(ld_pair_flat_kernel<false>, dim3(grid), dim3(256), 0, s, d_m.p, d_h.p, (const uint64_t *)nullptr,
+                               (const uint64_t *)nullptr, nblk, p->nloci, p->d_chr_off.p, p->nchr, winsize, pair);
+    }
+    for (int c = 0; !pair_tiled && !pair_flat && !pair_lane && c < p->nchr; c++) {
         if (phased)
             hipLaunchKernelGGL(ld_pair_phased_kernel, dim3((unsigned)p->chr_nloci[c]), dim3(256), 0, s, d_m.p,
                                d_h.p, d_o.p, p->d_phase.p, nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1],
@@ -2199,6 +2240,36 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
         if (e == hipSuccess)
             e = hipMemcpyAsync(d_pair.p, pair_counts, sizeof(int32_t) * n * 2, hipMemcpyHostToDevice, s);
         loc = d_loc.p; pair = d_pair.p;
+    }
+    // narrow windows (GARLIC's default --winsize is 10): hr2 evaluated in place, one thread per (window start, column)
+    if (winsize <= LD_SMALL_MAX_W && !getenv("GARLIC_LD_NO_FLAT")) {
+        if ((rc = d_hf.reserve(p->nloci))) return done(rc);
+        double *ld = ld_out;
+        if (where == GARLIC_HOST || !ld_out) {
+            if ((rc = d_ld.reserve(n))) return done(rc);
+            ld = d_ld.p;
+        }
+        if (e == hipSuccess) e = hipMemsetAsync(ld, 0, sizeof(double) * n, s);      // initLDData zero-fills
+        if (e == hipSuccess && phased) e = hipMemcpyAsync(d_hf.p, p->freq.data(), sizeof(double) * p->nloci, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
+        if (!phased)
+            hipLaunchKernelGGL(ld_homfreq_kernel, dim3((unsigned)((p->nloci + 255) / 256)), dim3(256), 0, s, loc, p->nloci, d_hf.p);
+        garlic_ctx *ctx = p->ctx;
+        const int slot = (int)(ctx->n_calls % garlic_ctx::HIST);
+        (void)hipEventRecord(ctx->hist0[slot], s);
+        hipLaunchKernelGGL(ld_sum_flat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, pair, d_hf.p, p->d_chr_off.p,
+                           p->nchr, p->nloci, winsize, ld);
+        (void)hipEventRecord(ctx->hist1[slot], s);
+        ctx->n_calls++;
+        e = hipGetLastError();
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
+        if ((rc = install_ld(p, winsize, ld, false))) return done(rc);
+        if (where == GARLIC_HOST && ld_out) {
+            e = hipMemcpyAsync(ld_out, ld, sizeof(double) * n, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
+        }
+        return done(GARLIC_OK);
     }
     // ordered sums: LDS-tiled kernel (one thread per column of the LD row) unless the window is too wide
     // ... thread = SNP of the window, accumulators = window starts (ld_sum_col_kernel: 32 < W <= 512) unless switched off

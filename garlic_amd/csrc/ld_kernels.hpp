@@ -202,6 +202,8 @@ ld_pair_tiled_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__rest
                 if (q + d >= nsnp) continue;                   // partner outside the chromosome: stays 0
                 int32_t t = 0, h = 0;
                 for (int b = 0; b < nb; b++) {
+                    // (the SNP's own words through the scalar cache instead of the broadcast LDS read: measured, 11.7 ->
+                    // 16.4 ms -- the scalar loads are waited for where they are issued)
                     const uint64_t *a = ld_planes + (size_t)(b * span + q) * NP, *c = a + (size_t)d * NP;
                     const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(a);
                     const ulonglong2 c0 = *reinterpret_cast<const ulonglong2 *>(c);
@@ -321,6 +323,147 @@ ld_hr2_kernel(const int32_t *__restrict__ pair, const double *__restrict__ hf, i
             bwd[j * W + d] = hr2_from_counts(HB, HA, hab, tot);
         }
     }
+}
+
+// Pair counts with a lane per SNP.  ld_pair_tiled_kernel gives a thread to a distance: every (SNP, block) costs it
+// two LDS reads -- the SNP's own words, broadcast, and the partner's -- and it runs at the pace of those (0.35 of the
+// AND + popcount rate), with nine lanes of a wave at work when W = 10.  Here thread = SNP i of a tile of 256: its own
+// words are read once per block, the partner words of SNP i + d are the neighbouring lanes' entries (consecutive
+// 16-B reads, conflict-free), 16 or 32 distances at a time in registers.  The plane words of the tile's 256 + W - 1
+// SNPs are staged `nb_stage` blocks at a time (a few: 22 KB of LDS at W = 100, six workgroups per CU) and staged again
+// for every pass over the distances (from L2: 3 passes at W = 100; keeping all blocks resident instead left one
+// workgroup per CU and ran at half the pace).  SNPs past the chromosome are staged as zero words: their pairs count 0, as the table wants.
+constexpr int LD_LANE_T = 256;      // distances per pass: 16 (narrow windows: one pass) or 32
+template <bool PHASED, int LD_LANE_DC>
+__global__ void __launch_bounds__(LD_LANE_T)
+ld_pair_lane_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__ planeH,
+                    const uint64_t *__restrict__ planeO, const uint64_t *__restrict__ planeF, int nblk, int64_t nloci,
+                    const LdPairChr *__restrict__ chrs, int nchr, int W, int nb_stage, int32_t *__restrict__ pair)
+{
+    constexpr int NP = PHASED ? 4 : 2;
+    extern __shared__ uint64_t ld_planes[];                    // [nb_stage][span][NP]
+    const int span = LD_LANE_T + W - 1;
+    int c = 0;
+    while (c + 1 < nchr && (int64_t)blockIdx.x >= chrs[c + 1].block0) c++;
+    const int64_t hi = chrs[c].hi;
+    const int64_t i0 = chrs[c].lo + ((int64_t)blockIdx.x - chrs[c].block0) * LD_LANE_T;
+    const int nsnp = (int)min<int64_t>(span, hi - i0);         // staged SNPs that exist
+    const int i = threadIdx.x;
+    const bool mine = i0 + i < hi;
+    for (int d0 = 1; d0 < W; d0 += LD_LANE_DC) {
+        int32_t tot[LD_LANE_DC], hab[LD_LANE_DC];
+#pragma unroll
+        for (int r = 0; r < LD_LANE_DC; r++) { tot[r] = 0; hab[r] = 0; }
+        for (int b0 = 0; b0 < nblk; b0 += nb_stage) {
+            const int nb = min(nb_stage, nblk - b0);
+            if (d0 == 1 || nb_stage < nblk) {                  // (all blocks resident: staged once)
+                __syncthreads();
+                for (int b = 0; b < nb; b++)
+                    for (int x = threadIdx.x; x < span; x += LD_LANE_T) {
+                        const int64_t g = (int64_t)(b0 + b) * nloci + i0 + x;
+                        uint64_t *e = ld_planes + (size_t)(b * span + x) * NP;
+                        const bool in = x < nsnp;
+                        e[0] = in ? planeM[g] : 0;
+                        e[1] = in ? planeH[g] : 0;
+                        if (PHASED) { e[2] = in ? planeO[g] : 0; e[3] = in ? planeF[g] : 0; }
+                    }
+                __syncthreads();
+            }
+            for (int b = 0; b < nb; b++) {
+                const uint64_t *a = ld_planes + (size_t)(b * span + i) * NP;
+                const ulonglong2 a0 = *reinterpret_cast<const ulonglong2 *>(a);
+                ulonglong2 a1 = make_ulonglong2(0, 0);
+                if (PHASED) a1 = *reinterpret_cast<const ulonglong2 *>(a + 2);
+#pragma unroll
+                for (int r = 0; r < LD_LANE_DC; r++) {
+                    if (d0 + r >= W) break;                    // wave-uniform
+                    const uint64_t *cp = a + (size_t)(d0 + r) * NP;
+                    const ulonglong2 c0 = *reinterpret_cast<const ulonglong2 *>(cp);
+                    if (PHASED) {
+                        const ulonglong2 c1 = *reinterpret_cast<const ulonglong2 *>(cp + 2);
+                        tot[r] += 2 * __popcll(a0.x & c0.x);
+                        hab[r] += 2 * __popcll(a0.y & c0.y) + __popcll(a1.x & c0.y) + __popcll(a0.y & c1.x) +
+                                  __popcll(a1.x & c1.x & ~(a1.y ^ c1.y));
+                    } else {
+                        tot[r] += __popcll(a0.x & c0.x);
+                        hab[r] += __popcll(a0.y & c0.y);
+                    }
+                }
+            }
+        }
+        if (mine) {
+            int32_t *row = pair + (i0 + i) * (int64_t)W * 2;
+            if (d0 == 1) *reinterpret_cast<int2 *>(row) = make_int2(0, 0);       // d = 0 is not a pair
+#pragma unroll
+            for (int r = 0; r < LD_LANE_DC; r++)
+                if (d0 + r < W) *reinterpret_cast<int2 *>(row + (d0 + r) * 2) = make_int2(tot[r], hab[r]);
+        }
+    }
+}
+
+// Narrow windows (W <= LD_SMALL_MAX_W; GARLIC's default --winsize is 10): the tiled kernels above give a thread to
+// every distance or column and a workgroup to a few SNPs -- at W = 10 nine lanes of a wave work.  Flat forms:
+// one thread per (SNP, distance) for the pair counts, one per (window start, column) for the sums, the plane words
+// and the pair counts straight from memory (neighbouring threads share them: L1 / L2 hits).
+constexpr int LD_SMALL_MAX_W = 16;     // (the in-place hr2 evaluations grow with W^2: 3.5 ms at W = 10, 31 ms at 32)
+
+template <bool PHASED>
+__global__ void __launch_bounds__(256)
+ld_pair_flat_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__ planeH,
+                    const uint64_t *__restrict__ planeO, const uint64_t *__restrict__ planeF, int nblk, int64_t nloci,
+                    const int64_t *__restrict__ chr_off, int nchr, int W, int32_t *__restrict__ pair)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (i, d), d = 0 .. W-1
+    if (e >= nloci * W) return;
+    const int64_t i = e / W;
+    const int d = (int)(e - i * W);
+    const int64_t j = i + d;
+    int32_t tot = 0, hab = 0;
+    if (d > 0 && j < nloci && j < chr_off[find_chr(chr_off, nchr, i) + 1]) {   // pairs leaving the chromosome stay 0
+        for (int blk = 0; blk < nblk; blk++) {
+            const int64_t base = (int64_t)blk * nloci;
+            if (PHASED) {
+                const uint64_t ti = planeH[base + i], tj = planeH[base + j], oi = planeO[base + i], oj = planeO[base + j];
+                tot += 2 * __popcll(planeM[base + i] & planeM[base + j]);
+                hab += 2 * __popcll(ti & tj) + __popcll(oi & tj) + __popcll(ti & oj) +
+                       __popcll(oi & oj & ~(planeF[base + i] ^ planeF[base + j]));
+            } else {
+                tot += __popcll(planeM[base + i] & planeM[base + j]);
+                hab += __popcll(planeH[base + i] & planeH[base + j]);
+            }
+        }
+    }
+    *reinterpret_cast<int2 *>(pair + e * 2) = make_int2(tot, hab);
+}
+
+// LD[s][k] = sum over the window's SNPs i = s .. s+W-1, in that order from 0.0, of hr2(i, s + k) (1.0 for i = s + k):
+// garlic-data.cpp:521-527 with hr2 / r2 evaluated in place from the pair counts (W^2 evaluations per window start: at
+// W <= 32 cheaper than a table of them and the passes that write and read it).  Window starts without a full window
+// keep initLDData's zeros (the caller clears the table).
+__global__ void __launch_bounds__(256)
+ld_sum_flat_kernel(const int32_t *__restrict__ pair, const double *__restrict__ hf, const int64_t *__restrict__ chr_off,
+                   int nchr, int64_t nloci, int W, double *__restrict__ ld)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // (s, k)
+    if (e >= nloci * W) return;
+    const int64_t s = e / W;
+    const int k = (int)(e - s * W);
+    if (s + W > chr_off[find_chr(chr_off, nchr, s) + 1]) return;
+    const int64_t t = s + k;
+    const double HT = hf[t];
+    double acc = 0.0;
+    for (int64_t i = s; i < s + W; i++) {
+        double term = 1.0;
+        if (i < t) {
+            const int2 c = *reinterpret_cast<const int2 *>(pair + (i * W + (t - i)) * 2);
+            term = hr2_from_counts(hf[i], HT, c.y, c.x);
+        } else if (i > t) {
+            const int2 c = *reinterpret_cast<const int2 *>(pair + (t * W + (i - t)) * 2);
+            term = hr2_from_counts(hf[i], HT, c.y, c.x);
+        }
+        acc += term;
+    }
+    ld[e] = x86_nan_if_nan(acc);
 }
 
 // The combined table from LDS tiles.  ld_hr2_kernel<true> writes hr2(i + d, i) into row i + d with one 8-B store
