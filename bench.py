@@ -249,6 +249,24 @@ def leg_ns(ctx, dev, steps):
     dt, k = timed_passes(ctx, lambda: panel.lod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP), steps, 1,
                          torch.cuda.synchronize)
     res["lod"] = dict(rate(k, dt), roofline=hbm_roofline("lod_chain_kernel", BYTES_LOD * win, k))
+    # the first half of assembleROHWindows on the resident scores (garlic_roh_coverage): 8 B of scores in, 2 B of counts out
+    _, _, tcov = panel.out_layout(1, nind)
+    cov = torch.empty(tcov, dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    panel.roh_coverage_device(out.data_ptr(), W, 2.5, cov.data_ptr())
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+    ts = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        panel.roh_coverage_device(out.data_ptr(), W, 2.5, cov.data_ptr())     # synchronous call: wall = kernel + two tiny uploads
+        ts.append(time.perf_counter() - t0)
+    tcv = float(np.min(ts))
+    res["roh_coverage"] = {"call_ms": tcv * 1e3, "sliding_windows_per_s": win / tcv,
+                           "roofline": hbm_roofline("roh_coverage_kernel", 10.0 * win, tcv * 1e3,
+                                                    note="10 B per window (8 B score in, 2 B count out); timed as the whole synchronous "
+                                                         "call (wall clock, best of 3): kernel + two small uploads")}
+    del cov, evs
     # LD weights: integer pair counts (AND + popcount on bit planes) + W^2 ordered FP64 adds per window start
     for name, sub in (("ld_all_individuals", None),
                       ("ld_subsample_500", np.sort(np.random.default_rng(1).choice(nind, 500, replace=False)).astype(np.int32))):

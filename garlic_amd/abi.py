@@ -513,6 +513,12 @@ class Panel:
         return [out[base[c]: base[c] + nind_out * pitch[c]].reshape(nind_out, pitch[c])
                 for c in range(self.nchr)]
 
+    def roh_coverage_device(self, scores_ptr, winsize, cutoff, out_ptr, pitch_align=32, nind_out=None):
+        """the same counts into device memory (int16, dense rows: out_layout(1, nind_out))"""
+        nind_out = self.nind if nind_out is None else nind_out
+        check(lib().garlic_roh_coverage(self.handle, _vp(scores_ptr), pitch_align, nind_out, winsize, cutoff,
+                                        _vp(out_ptr), 1, DEVICE))
+
     def stats(self):
         st = CallStats()
         check(lib().garlic_last_call_stats(self.handle, C.byref(st)))

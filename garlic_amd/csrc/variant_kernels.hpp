@@ -1159,7 +1159,7 @@ feed_write_kernel(const double *scores, const ChrDev *chrs, int nchr, int nrows,
 // (row, 2048-SNP segment) one workgroup marks the windows of the segment and of the W-1 SNPs in
 // front of it, takes a prefix count and differences it.  Scores stay on the device; 2 bytes per
 // (individual, SNP) come back instead of 8.
-constexpr int COV_SEG = 2048, COV_THREADS = 256;
+constexpr int COV_SEG = 8192, COV_THREADS = 256;   // (2048-window segments: 1.25 M workgroups at 2M x 1280, and the kernel ran at the pace of their dispatch)
 __global__ void __launch_bounds__(COV_THREADS)
 roh_coverage_kernel(const double *__restrict__ scores, const ChrDev *__restrict__ chrs,
                     const ChrDev *__restrict__ ochrs, const int32_t *__restrict__ seg_base, int nchr,
@@ -1182,12 +1182,23 @@ roh_coverage_kernel(const double *__restrict__ scores, const ChrDev *__restrict_
     const int per = ((n + 3) / 4 + WAVE - 1) / WAVE * WAVE;     // windows per wave, whole steps
     const int lo = wave * per, hi = min(n, lo + per);
     int cnt = 0;
-    for (int k0 = lo; k0 < hi; k0 += WAVE) {
-        const int k = k0 + lane, w = first + k;
-        const bool q = (k < hi) && (w >= 0) && (row[w] >= cutoff);  // NaN >= x is false
-        const uint64_t m = __ballot(q);
-        if (k < hi) pre[k + 1] = cnt + __popcll(m & (((uint64_t)2 << lane) - 1));   // inclusive count
-        cnt += __popcll(m);
+    // eight steps' scores requested before the first is looked at (one load in flight per wave ran at the pace of
+    // the memory latency: 0.55 of the HBM rate)
+    for (int k0 = lo; k0 < hi; k0 += 8 * WAVE) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = k0 + u * WAVE + lane, w = first + k;
+            v[u] = (k < hi && w >= 0) ? __builtin_nontemporal_load(row + w) : MISSING_D;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = k0 + u * WAVE + lane, w = first + k;
+            const bool q = (k < hi) && (w >= 0) && (v[u] >= cutoff);    // NaN >= x is false
+            const uint64_t m = __ballot(q);
+            if (k < hi) pre[k + 1] = cnt + __popcll(m & (((uint64_t)2 << lane) - 1));   // inclusive count
+            cnt += __popcll(m);
+        }
     }
     if (lane == 0) part[wave] = cnt;
     if (threadIdx.x == 0) pre[0] = 0;
