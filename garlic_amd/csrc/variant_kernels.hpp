@@ -803,16 +803,32 @@ __device__ __forceinline__ void wlod_group_small(ScoreFn score, const double *Ds
 template <int R, bool ALIGNED16, class Args>
 __device__ __forceinline__ void wlod_write_group(double (&acc)[R], uint32_t gm, const ChrDev &c, const Args &p,
                                                  double *__restrict__ out, double *patch, int *patch_lock,
-                                                 int ind0, int s0, int grp, int lane)
+                                                 int ind0, int s0, int grp, int lane_hint)
 {
+    // the lane index afresh (opaque to the compiler): everything per-lane below is then computed here instead of being
+    // kept alive across the hand-scheduled loop, whose register budget leaves no room -- hipcc spilled those values and
+    // reloaded them in here behind s_waitcnt vmcnt(0), i.e. behind the previous block's score stores
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    (void)lane_hint;
     const bool row_ok = ind0 + lane < p.ind_count;
+#ifdef GARLIC_WLOD_ABL_NO_WRITE        // timing experiment: only one value per lane leaves (results wrong)
+    if (acc[0] == 1.2345e-300 && row_ok) out[ind0 + lane] = acc[0];
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = (gm != 0 && ((gm >> r) & 1u)) ? acc[r] : MISSING_D;
     const int sg = s0 + grp * R;
     if (ALIGNED16 && (p.use_patch & 1)) {
+        // The lock guards LDS only, and a CU serves the LDS operations of its waves in the order they arrive: the
+        // holder's patch reads are issued before its unlock, the next holder's writes after its successful CAS.  So the
+        // fences are wavefront-scope (compiler ordering only).  Workgroup-scope acquire / release also wait for the
+        // wave's GLOBAL operations (s_waitcnt vmcnt(0)): every write-out then waited until memory had taken the 16
+        // stores it had just issued -- 12 % of the kernel at W = 100 (tools/exp/wlod_abl2.sh: 18.1 ms, 15.9 without
+        // the write-out).
         if (lane == 0)
             while (atomicCAS(patch_lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < R; r += 2)
@@ -836,7 +852,7 @@ __device__ __forceinline__ void wlod_write_group(double (&acc)[R], uint32_t gm, 
                 dst[0] = v.x;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) atomicExch(patch_lock, 0);
     } else if (row_ok) {
