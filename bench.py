@@ -191,6 +191,7 @@ def leg_c3(ctx, dev, steps):
                                  note="the four launches of one --winsize-multi call together")}
     out.free()
     torch.cuda.empty_cache()
+    ctx.trim()
     for W in sizes:
         panel.lod_feed(W, ERROR, MAX_GAP, W, copy=False)             # plan + scratch
         ks, ws = [], []
@@ -332,6 +333,7 @@ def leg_ns(ctx, dev, steps):
     panel.close()
     out.free()
     torch.cuda.empty_cache()
+    ctx.trim()
     return res
 
 
@@ -455,6 +457,7 @@ def main():
         plain_ms = three_passes(plain.data_ptr())
         del plain
         torch.cuda.empty_cache()
+        ctx.trim()
         placement = {"candidates_kernel_ms": times, "kept_ms": float(min(times)),
                      "median_ms": float(np.median(times)), "worst_ms": float(max(times)),
                      "one_plain_hipmalloc_buffer_ms": plain_ms,
@@ -486,6 +489,7 @@ def main():
         setup["ld_weights_s"] = time.perf_counter() - t0
         del loc, pair
         torch.cuda.empty_cache()
+        ctx.trim()
 
     def step():
         if args.mode == "lod":
@@ -589,6 +593,7 @@ def main():
     if out_buf is not None:
         out_buf.free()
     torch.cuda.empty_cache()
+    ctx.trim()
 
     if rank == 0 and world == 1 and args.also != "none":
         want = ["e2e", "ns", "c3"] if args.also == "auto" else [x for x in args.also.split(",") if x]

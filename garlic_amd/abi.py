@@ -30,7 +30,7 @@ SYMBOLS = [
     "garlic_lod_feed", "garlic_ctx_set_async",
     "garlic_recent_kernel_ms", "garlic_panel_tgls_mode", "garlic_lod_feed_subset", "garlic_lod_feed_multi",
     "garlic_device_alloc", "garlic_device_free", "garlic_panel_chain_kind", "garlic_device_alloc_stats",
-    "garlic_panel_alloc_scores",
+    "garlic_panel_alloc_scores", "garlic_device_trim",
 ]
 
 
@@ -155,6 +155,10 @@ class Context:
     def alloc_scores(self, n_doubles):
         """device memory for a score matrix through garlic_device_alloc (pooled; see garlic_hip.h)"""
         return DeviceBuffer(self, int(n_doubles) * 8)
+
+    def trim(self):
+        """garlic_device_trim: idle pooled score buffers give their memory back"""
+        check(lib().garlic_device_trim(self.handle))
 
     def alloc_stats(self):
         """garlic_device_alloc_stats: (live, pooled, reserved) bytes of score memory on this context's device"""

@@ -51,6 +51,8 @@ int fail(int code, const char *fmt, ...)
                         __LINE__);                                                          \
     } while (0)
 
+int score_pool_trim();    // idle score buffers (garlic_device_free keeps them mapped) give their memory back
+
 template <class T> struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;
@@ -60,6 +62,14 @@ template <class T> struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            (void)score_pool_trim();                 // out of memory with score buffers idle in the pool: once more without them
+        } else {
+            cap = n;
+            return GARLIC_OK;
+        }
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), n * sizeof(T)));
         cap = n;
         return GARLIC_OK;
@@ -371,24 +381,39 @@ static int score_alloc(garlic_ctx *ctx, size_t bytes, void **out)
             release_score_alloc(a, mapped, mapped != 0);
             (void)hipGetLastError();
             {   // out of device memory with buffers idle in the pool: give those back and try once more
-                std::unique_lock<std::mutex> lock(g_score_mutex);
                 bool any = false;
-                for (size_t k = 0; k < g_score_allocs.size();) {
-                    ScoreAlloc &b = g_score_allocs[k];
-                    if (b.pooled && b.device == ctx->device) {
-                        release_score_alloc(b, b.size, true);
-                        g_score_retired[ctx->device < 16 ? ctx->device : 15] += (int64_t)b.size;
-                        g_score_allocs.erase(g_score_allocs.begin() + (long)k);
-                        any = true;
-                    } else k++;
+                {
+                    std::lock_guard<std::mutex> lock(g_score_mutex);
+                    for (const ScoreAlloc &b : g_score_allocs) any = any || (b.pooled && b.device == ctx->device);
                 }
-                lock.unlock();
-                if (any) return score_alloc(ctx, bytes, out);
+                if (any) {
+                    (void)score_pool_trim();
+                    return score_alloc(ctx, bytes, out);
+                }
             }
         }
     }
     HIP_TRY(hipMalloc(out, bytes));
     return GARLIC_OK;
+}
+
+namespace {
+int score_pool_trim()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return GARLIC_OK;
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lock(g_score_mutex);
+    for (size_t k = 0; k < g_score_allocs.size();) {
+        ScoreAlloc &b = g_score_allocs[k];
+        if (b.pooled && b.device == dev) {
+            release_score_alloc(b, b.size, true);
+            g_score_retired[dev < 16 ? dev : 15] += (int64_t)b.size;
+            g_score_allocs.erase(g_score_allocs.begin() + (long)k);
+        } else k++;
+    }
+    return GARLIC_OK;
+}
 }
 
 static int score_free(garlic_ctx *ctx, void *ptr)
@@ -2861,6 +2886,14 @@ int garlic_device_free(garlic_ctx *ctx, void *ptr)
     int rc;
     if ((rc = set_device(ctx))) return rc;
     return score_free(ctx, ptr);
+}
+
+int garlic_device_trim(garlic_ctx *ctx)
+{
+    if (!ctx) return fail(GARLIC_ERR_INVALID, "context is required");
+    int rc;
+    if ((rc = set_device(ctx))) return rc;
+    return score_pool_trim();
 }
 
 int garlic_device_alloc_stats(garlic_ctx *ctx, int64_t *live_bytes, int64_t *pooled_bytes, int64_t *reserved_bytes)

@@ -42,7 +42,7 @@ extern "C" {
  *    empty (sub_idx != NULL, n_sub = 0); garlic_lod_feed_subset
  * 4: garlic_device_alloc / garlic_device_free (score matrices), garlic_panel_chain_kind
  * 5: garlic_lod_feed_multi (the feeds of several window sizes in one call); garlic_panel_alloc_scores,
- *    garlic_device_alloc_stats */
+ *    garlic_device_alloc_stats, garlic_device_trim */
 #define GARLIC_HIP_ABI_VERSION 5
 
 #define GARLIC_OK 0
@@ -323,6 +323,8 @@ int garlic_panel_chain_kind(garlic_panel *panel, int32_t *kind);
 int garlic_device_alloc(garlic_ctx *ctx, int64_t bytes, void **out);
 int garlic_device_free(garlic_ctx *ctx, void *ptr);
 int garlic_device_alloc_stats(garlic_ctx *ctx, int64_t *live_bytes, int64_t *pooled_bytes, int64_t *reserved_bytes);
+int garlic_device_trim(garlic_ctx *ctx);   /* idle pooled buffers give their memory back now (the library does this itself
+                                              when one of its own allocations runs out of memory) */
 int garlic_panel_alloc_scores(garlic_panel *panel, int32_t pitch_align, int32_t nind_out, int32_t winsize, double error,
                               int32_t max_gap, int32_t candidates, void **out, float *candidate_ms);
 

@@ -27,6 +27,7 @@ def load_panel(ctx, spec, nind, sample, gq_seed=None, slices=()):
     import torch
     dev = torch.device("cuda", 0)
     torch.cuda.empty_cache()
+    ctx.trim()            # score buffers idle in the library's pool: these tests need nearly all of the device memory
     kept = [np.empty((n, nind), dtype=np.int16) for _, n in slices]
     panel = abi.Panel(ctx, spec.chr_nloci, nind)
     panel.set_map(spec.pos, spec.centro_start, spec.centro_end, gpos=spec.gpos)
