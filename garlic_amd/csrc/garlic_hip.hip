@@ -2931,16 +2931,29 @@ int garlic_panel_alloc_scores(garlic_panel *p, int32_t pitch_align, int32_t nind
     for (int k = 0; k < candidates; k++)
         if ((rc = score_alloc(p->ctx, sizeof(double) * (size_t)L.total, &cand[(size_t)k]))) { cleanup(-1); return rc; }
     int best = 0;
+    // passes enqueued back to back, as a caller that keeps the scores on the device issues them (a pass that is waited
+    // for runs ~5 % faster than one in a queue: DESIGN.md section 4): one pass to build the plan, then four in a row, the
+    // last three timed by their HIP events
+    garlic_ctx *ctx = p->ctx;
+    const bool was_async = ctx->async_device;
     for (int k = 0; k < candidates; k++) {
+        ctx->async_device = false;
+        rc = launch_lod(p, MODE_LOD, winsize, error, max_gap, 0, 0.0, 0, nind_out, pitch_align, (double *)cand[(size_t)k], GARLIC_DEVICE);
+        ctx->async_device = true;
+        for (int pass = 0; pass < 4 && !rc; pass++)
+            rc = launch_lod(p, MODE_LOD, winsize, error, max_gap, 0, 0.0, 0, nind_out, pitch_align, (double *)cand[(size_t)k], GARLIC_DEVICE);
+        ctx->async_device = was_async;
+        if (rc) { cleanup(-1); return rc; }
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { cleanup(-1); return fail(GARLIC_ERR_HIP, "alloc_scores: %s", hipGetErrorString(e)); }
         float acc = 0.f;
-        for (int pass = 0; pass < 3; pass++) {
-            if ((rc = launch_lod(p, MODE_LOD, winsize, error, max_gap, 0, 0.0, 0, nind_out, pitch_align, (double *)cand[(size_t)k],
-                                 GARLIC_DEVICE))) { cleanup(-1); return rc; }
-            garlic_call_stats st;
-            if ((rc = garlic_last_call_stats(p, &st))) { cleanup(-1); return rc; }
-            if (pass) acc += st.chain_kernel_ms;
+        for (int q = 1; q <= 3; q++) {
+            const int slot = (int)((ctx->n_calls - q) % garlic_ctx::HIST);
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, ctx->hist0[slot], ctx->hist1[slot]);
+            acc += t;
         }
-        ms[(size_t)k] = acc / 2;
+        ms[(size_t)k] = acc / 3;
         if (ms[(size_t)k] < ms[(size_t)best]) best = k;
     }
     if (candidate_ms) memcpy(candidate_ms, ms.data(), sizeof(float) * (size_t)candidates);

@@ -18,4 +18,8 @@ echo "pmc fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -- python3 $ARGS > $OUT/${TAG}_pmc_write_bench.json 2> $OUT/${TAG}_pmc_write.err
 echo "pmc write done"
 python3 bench.py --steps 20 --warmup 5 --no-cpu --also none > $OUT/${TAG}_bench_plain2.json 2>> $OUT/${TAG}_bench_plain.err
-find $OUT/${TAG}_trace $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write -name "*.csv" | head -20
+# the raw traces exceed what gpurun brings back (64 MiB): condense here, keep the summaries
+GARLIC_PROF_OUT=$OUT/profiles_${TAG} python3 tools/summarize_profiles.py $TAG
+cp $OUT/${TAG}_bench_plain.json $OUT/profiles_${TAG}/${TAG}_bench_plain.json
+cp $OUT/${TAG}_bench_plain2.json $OUT/profiles_${TAG}/${TAG}_bench_plain_second_run.json
+rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write

@@ -23,4 +23,5 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_tgls_write -- pyth
 WG="tools/bench_variants.py --snps $SNPS --inds $INDS --modes wlodgl --steps 3"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_wlodgl_fetch -- python3 $WG > $OUT/${TAG}_wlodgl_fetch.json 2>> $OUT/${TAG}_variants.err
 echo "pmc done"
-find $OUT/${TAG}_variants -name "*_kernel_stats.csv"
+GARLIC_PROF_OUT=$OUT/profiles_${TAG} python3 tools/summarize_variants.py $TAG
+rm -rf $OUT/${TAG}_variants $OUT/${TAG}_tgls_fetch $OUT/${TAG}_tgls_write $OUT/${TAG}_wlodgl_fetch

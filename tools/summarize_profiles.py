@@ -14,7 +14,7 @@ import sys
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 OUT = os.path.join(ROOT, "gpurun_out")
-PROF = os.path.join(ROOT, "profiles")
+PROF = os.environ.get("GARLIC_PROF_OUT") or os.path.join(ROOT, "profiles")
 
 
 def one(pattern):

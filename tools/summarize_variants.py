@@ -13,7 +13,7 @@ import sys
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 OUT = os.path.join(ROOT, "gpurun_out")
-PROF = os.path.join(ROOT, "profiles")
+PROF = os.environ.get("GARLIC_PROF_OUT") or os.path.join(ROOT, "profiles")
 
 
 def newest(pattern):
@@ -34,6 +34,7 @@ def pmc(counter_dir, counter, kernel):
 
 
 def main():
+    os.makedirs(PROF, exist_ok=True)
     plain, traced = lines(os.path.join(OUT, f"{TAG}_variants_plain.json")), lines(os.path.join(OUT, f"{TAG}_variants_bench.json"))
     shape = f"{plain[0]['snps']} SNPs x {plain[0]['inds']} individuals, W={plain[0]['winsize']}"
     rows = [r for r in csv.DictReader(open(newest(f"{TAG}_variants/**/*_kernel_stats.csv"))) if "garlic::" in r["Name"]]
