@@ -268,6 +268,7 @@ def leg_ns(ctx, dev, steps):
                                                     note="10 B per window (8 B score in, 2 B count out); timed as the whole synchronous "
                                                          "call (wall clock, best of 3): kernel + two small uploads")}
     del cov, evs
+    torch.cuda.empty_cache()      # 25 GB of counts: the likelihood legs below need the room
     # LD weights: integer pair counts (AND + popcount on bit planes) + W^2 ordered FP64 adds per window start
     for name, sub in (("ld_all_individuals", None),
                       ("ld_subsample_500", np.sort(np.random.default_rng(1).choice(nind, 500, replace=False)).astype(np.int32))):
