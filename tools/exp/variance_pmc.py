@@ -9,6 +9,7 @@ import torch
 from garlic_amd import abi, synth
 import bench
 
+PASSES = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 nloci, nind, W = 1_000_000, 1000, 100
@@ -22,7 +23,7 @@ for trial in range(8):
         pads.append(torch.empty(int(np.random.default_rng(trial).integers(1, 1 << 28)), dtype=torch.uint8, device=dev))
     out = torch.empty(total, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
-    for _ in range(12):
+    for _ in range(PASSES):
         panel.lod_windows_device(out.data_ptr(), W, 0.001, 200000)
     torch.cuda.synchronize()
     del out
