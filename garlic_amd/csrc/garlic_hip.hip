@@ -11,6 +11,7 @@
 #include "ld_kernels.hpp"
 #include "tgls_ring_kernel.hpp"
 #include "wlod_strip_kernel.hpp"
+#include "wlod_small_kernel.hpp"
 #include "feed_kernel.hpp"
 
 #include <algorithm>
@@ -226,7 +227,7 @@ struct garlic_panel {
     // tuned wLOD path: skewed reciprocal weights, per-SNP score rows, window mask, tile index
     DevBuf<double> d_skew, d_wtab;
     DevBuf<uint8_t> d_valid;
-    DevBuf<int2> d_tiles;
+    DevBuf<int2> d_tiles, d_segs;        // wLOD work lists: 32-window tiles; WSM_T-window segments (narrow windows)
     DevBuf<WlodStrip> d_strips;
     std::vector<double> h_tab, h_decay;            // host copies the score rows are built from
     bool wtab_valid = false;
@@ -286,7 +287,7 @@ struct garlic_panel {
         int32_t thin_step = 0;
         size_t n_feed_items = 0;
         uint64_t blocks_hash = 0;                  // 0: every 64-individual block; else a hash of the block subset
-        int32_t n_tiles = 0, n_strips = 0;
+        int32_t n_tiles = 0, n_segs = 0, n_strips = 0;
         int64_t n_runs = 0, n_valid = 0;
     } plan;
 };
@@ -1096,6 +1097,10 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     if (wlod_fast && !wlod_gl && sizeof(double) * (size_t)(W + TILE) * 4 + 16 > 150 * 1024) wlod_fast = false;
     if (wlod_fast && !wlod_gl && (rc = ensure_score_rows(p, error, M, mu, W))) return rc;
     if (mode == MODE_WLOD && !wlod_fast && (rc = ensure_rld(p))) return rc;
+    // narrow windows, plain scores: the streaming kernel (wlod_small_kernel.hpp) reads the plain reciprocals, a window's
+    // W weights contiguous
+    const bool wlod_stream = wlod_fast && wlod_small && !wlod_gl && !getenv("GARLIC_WLOD_SMALL_TILES");
+    if (wlod_stream && (rc = ensure_rld(p))) return rc;
     // continuous likelihoods have no code table: the generic kernel takes its terms from the raw matrix
     if (mode == MODE_WLOD && use_gl && p->gl_cont && !wlod_fast && (rc = ensure_gl_terms(p))) return rc;
     // transposed write-out patch only while rows + patch keep 8 workgroups (32 waves) on a CU
@@ -1187,7 +1192,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         p->plan.valid = false;
     }
     std::vector<uint8_t> valid;
-    std::vector<int2> tiles;
+    std::vector<int2> tiles, segs;
     if (wlod_fast && !reuse) {
         valid.assign((size_t)p->nloci, 0);
         for (const Run &r : runs)
@@ -1195,8 +1200,11 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         for (int c = 0; c < p->nchr; c++)
             for (int s0 = 0; s0 < p->chr_nloci[c]; s0 += TILE) tiles.push_back(make_int2(c, s0));
         p->plan.n_tiles = (int32_t)tiles.size();
+        for (int c = 0; c < p->nchr; c++)
+            for (int s0 = 0; s0 < p->chr_nloci[c]; s0 += WSM_T) segs.push_back(make_int2(c, s0));
+        p->plan.n_segs = (int32_t)segs.size();
         if ((rc = p->d_valid.reserve(valid.size()))) return rc;
-        if ((rc = p->d_tiles.reserve(tiles.size()))) return rc;
+        if ((rc = p->d_tiles.reserve(tiles.size())) || (rc = p->d_segs.reserve(segs.size()))) return rc;
     }
     std::vector<WlodStrip> strips;
     if (wlod_gl_strip && !reuse) {
@@ -1264,6 +1272,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                                    ctx->stream));
             HIP_TRY(hipMemcpyAsync(p->d_tiles.p, tiles.data(), sizeof(int2) * tiles.size(),
                                    hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(p->d_segs.p, segs.data(), sizeof(int2) * segs.size(),
+                                   hipMemcpyHostToDevice, ctx->stream));
             if (!strips.empty())
                 HIP_TRY(hipMemcpyAsync(p->d_strips.p, strips.data(), sizeof(WlodStrip) * strips.size(),
                                        hipMemcpyHostToDevice, ctx->stream));
@@ -1304,7 +1314,21 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                                                   : (const void *)wlod_tile_kernel<WLOD_R, false>);
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlod_lds));
         }
-        if (wlod_small) {
+        if (wlod_stream && aligned16) {
+            // segments of WSM_T windows x eight blocks per workgroup, everything the window loop reads staged in LDS
+            const int nquad8 = (nblk + WLOD2_BLOCKS - 1) / WLOD2_BLOCKS;
+            WlodArgs as = a;
+            as.tiles = p->d_segs.p;
+            as.nquad = nquad8;
+            as.n_work = (uint32_t)((int64_t)p->plan.n_segs * nquad8);
+            as.use_patch = 1;
+            const void *fn = wlod_stream_small_fn(W);
+            const size_t lds = wlod_small_lds_bytes(W);
+            if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const double *a_rld = p->d_rld.p;
+            void *kargs[] = {(void *)&a_packed, (void *)&a_wtab, (void *)&a_rld, (void *)&d_out, (void *)&as};
+            HIP_TRY(hipLaunchKernel(fn, dim3((as.n_work + 7u) / 8u * 8u), wl_block, kargs, lds, ctx->stream));
+        } else if (wlod_small) {
             const void *fn = wlod_gl ? (aligned16 ? (const void *)wlod_tile_small_gl_kernel<WLOD_R, true>
                                                   : (const void *)wlod_tile_small_gl_kernel<WLOD_R, false>)
                                      : (aligned16 ? (const void *)wlod_tile_small_kernel<WLOD_R, true>
@@ -1661,7 +1685,7 @@ int garlic_panel_destroy(garlic_panel *p)
     p->d_blk_offsets.release(); p->d_total.release(); p->d_boundaries.release();
     p->d_items.release(); p->d_fill.release(); p->d_counter.release(); p->d_chrs.release(); p->d_stage16.release(); p->d_row_counts.release(); p->d_codes.release(); p->d_tabgl.release();
     p->d_rld.release(); p->d_decay.release(); p->d_stage64.release(); p->d_phase.release(); p->lds.release();
-    p->d_glterms.release(); p->d_glval.release(); p->d_freq.release(); p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release(); p->d_strips.release();
+    p->d_glterms.release(); p->d_glval.release(); p->d_freq.release(); p->d_skew.release(); p->d_wtab.release(); p->d_valid.release(); p->d_tiles.release(); p->d_segs.release(); p->d_strips.release();
     p->d_out.release(); p->d_feed.release(); p->d_feed_items.release();
     release_feed_slots(p);
     delete p;
