@@ -328,7 +328,7 @@ def leg_ns(ctx, dev, steps):
     dt, k = timed_passes(ctx, lambda: panel.wlod_windows_device(out.data_ptr(), W10, ERROR, MAX_GAP, M_GEN, MU), steps, 1,
                          torch.cuda.synchronize)
     res["wlod_winsize10"] = dict(rate(k, dt), ld_call_ms=ld10 * 1e3,
-                                 roofline=hbm_roofline("wlod_tile_small_kernel", BYTES_LOD * win, k,
+                                 roofline=hbm_roofline("wlod_stream_small_kernel", BYTES_LOD * win, k,
                                                        note="2 * 10 flops per window: the 8 B of score per window bound it"))
     res["wlod_winsize10"]["lod_windows_per_s"] = win / W10 / (dt / steps)
     panel.close()

@@ -209,19 +209,25 @@ struct garlic_panel {
     int32_t ld_winsize = 0;
     DevBuf<double> d_rld, d_decay, d_stage64;
     DevBuf<uint64_t> d_phase;                      // HapData::firstCopy as bit planes [blk][nloci] (--phased LD)
+    uint64_t geno_epoch = 0;                       // bumped by every genotype upload (LD plane cache)
     bool have_phase = false;
     // scratch of the LD-weight kernels, kept between calls (window-size sweeps): at 10M SNPs the six
     // 8-GB allocations and frees of a call cost 9x its kernels.  garlic_panel_release_scratch drops it.
     struct {
         DevBuf<uint64_t> sub, m, h, o;
-        DevBuf<int32_t> loc, pair;
+        DevBuf<int32_t> loc, pair, loc_planes;
         DevBuf<double> hf, fwd, bwd, ld;
         DevBuf<LdSumChr> sum_chrs;
         DevBuf<LdPairChr> pair_chrs;
+        // the bit planes (and the per-SNP counts made with them) depend on the genotypes and the LD subsample only, not
+        // on the window size: kept across calls (--winsize-multi with --weighted: 3.5 of a call's 32 ms at 10M x 1250)
+        uint64_t planes_key = 0;
+        bool planes_valid = false;
         void release()
         {
-            sub.release(); m.release(); h.release(); o.release(); loc.release(); pair.release();
+            sub.release(); m.release(); h.release(); o.release(); loc.release(); pair.release(); loc_planes.release();
             hf.release(); fwd.release(); bwd.release(); ld.release(); sum_chrs.release(); pair_chrs.release();
+            planes_valid = false;
         }
     } lds;
     // tuned wLOD path: skewed reciprocal weights, per-SNP score rows, window mask, tile index
@@ -1771,6 +1777,7 @@ int garlic_panel_set_genotypes(garlic_panel *p, const int16_t *geno, int64_t ld,
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s));
     p->have_geno = true;
+    p->geno_epoch++;
     p->glterms_valid = false;
     return GARLIC_OK;
 }
@@ -1815,6 +1822,7 @@ int garlic_panel_set_genotypes_2bit(garlic_panel *p, const uint8_t *rows, int64_
     }
     stage.release();
     p->have_geno = true;
+    p->geno_epoch++;
     p->glterms_valid = false;
     return GARLIC_OK;
 }
@@ -2175,18 +2183,37 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
     const int lane_stage = std::min(nblk, getenv("GARLIC_LD_LANE_STAGE") ? atoi(getenv("GARLIC_LD_LANE_STAGE")) : 4);
     const int lane_dc = winsize - 1 <= 16 ? 16 : 32;
     const size_t lane_lds = sizeof(uint64_t) * (phased ? 4 : 2) * (size_t)lane_stage * (LD_LANE_T + winsize - 1);
-    const bool pair_lane = !pair_flat && winsize - 1 <= 256 && lane_lds <= 150 * 1024 && !getenv("GARLIC_LD_PAIR_TILED") &&
+    // unphased, 16 < W <= 129: the counts as banded Gram matrices on the matrix cores (ld_pair_mfma_kernel)
+    const int mfma_nj = 1 + (30 + winsize) / 32;
+    const bool pair_mfma = !phased && !pair_flat && winsize > LD_SMALL_MAX_W && mfma_nj <= 5 && !getenv("GARLIC_LD_PAIR_NO_MFMA") &&
+                           !getenv("GARLIC_LD_PAIR_TILED") && !getenv("GARLIC_LD_PAIR_L2");
+    const bool pair_lane = !pair_mfma && !pair_flat && winsize - 1 <= 256 && lane_lds <= 150 * 1024 && !getenv("GARLIC_LD_PAIR_TILED") &&
                            !getenv("GARLIC_LD_PAIR_L2");
-    const bool pair_tiled = !pair_flat && !pair_lane && winsize - 1 <= 256 && !getenv("GARLIC_LD_PAIR_L2");
+    const bool pair_tiled = !pair_mfma && !pair_flat && !pair_lane && winsize - 1 <= 256 && !getenv("GARLIC_LD_PAIR_L2");
     hipError_t e = hipMemcpyAsync(d_sub.p, sub.data(), sizeof(uint64_t) * nblk, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && !pair_tiled && !pair_flat && !pair_lane) e = hipMemsetAsync(pair, 0, sizeof(int32_t) * npair, s);
+    if (e == hipSuccess && !pair_tiled && !pair_flat && !pair_lane && !pair_mfma) e = hipMemsetAsync(pair, 0, sizeof(int32_t) * npair, s);
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
-    if (phased)
-        hipLaunchKernelGGL(ld_planes_kernel<true>, dim3((unsigned)p->nwordrows), dim3(256), 0, s, p->d_packed.p,
-                           p->nwordrows, nblk, d_sub.p, p->nloci, d_m.p, d_h.p, d_o.p, loc);
-    else
-        hipLaunchKernelGGL(ld_planes_kernel<false>, dim3((unsigned)p->nwordrows), dim3(256), 0, s, p->d_packed.p,
-                           p->nwordrows, nblk, d_sub.p, p->nloci, d_m.p, d_h.p, (uint64_t *)nullptr, loc);
+    uint64_t planes_key = 0xCBF29CE484222325ull;
+    for (uint64_t w : sub) planes_key = (planes_key ^ w) * 0x100000001B3ull;
+    planes_key = (planes_key ^ (uint64_t)(phased ? 2 : 1)) * 0x100000001B3ull;
+    planes_key = (planes_key ^ p->geno_epoch) * 0x100000001B3ull;
+    planes_key = (planes_key ^ (uint64_t)nblk) * 0x100000001B3ull;
+    if ((rc = p->lds.loc_planes.reserve((size_t)p->nloci * 2))) return done(rc);
+    if (!(p->lds.planes_valid && p->lds.planes_key == planes_key) || getenv("GARLIC_LD_NO_PLANE_CACHE")) {
+        p->lds.planes_valid = false;
+        if (phased)
+            hipLaunchKernelGGL(ld_planes_kernel<true>, dim3((unsigned)p->nwordrows), dim3(256), 0, s, p->d_packed.p,
+                               p->nwordrows, nblk, d_sub.p, p->nloci, d_m.p, d_h.p, d_o.p, p->lds.loc_planes.p);
+        else
+            hipLaunchKernelGGL(ld_planes_kernel<false>, dim3((unsigned)p->nwordrows), dim3(256), 0, s, p->d_packed.p,
+                               p->nwordrows, nblk, d_sub.p, p->nloci, d_m.p, d_h.p, (uint64_t *)nullptr, p->lds.loc_planes.p);
+        e = hipGetLastError();
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD planes: %s", hipGetErrorString(e)));
+        p->lds.planes_key = planes_key;
+        p->lds.planes_valid = true;
+    }
+    e = hipMemcpyAsync(loc, p->lds.loc_planes.p, sizeof(int32_t) * p->nloci * 2, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
     const int pair_threads = (winsize - 1 + WAVE - 1) / WAVE * WAVE;
     const size_t pair_lds = sizeof(uint64_t) * (phased ? 4 : 2) * LD_PAIR_BLK * (LD_PAIR_T + winsize - 1);
     if (pair_tiled && pair_lds > 48 * 1024) {
@@ -2213,6 +2240,31 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
                                d_h.p, (const uint64_t *)nullptr, (const uint64_t *)nullptr, nblk, p->nloci, d_pc.p,
                                p->nchr, winsize, pair);
         e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s);   // pc (host) is read by the copy above
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
+    }
+    if (pair_mfma) {   // all chromosomes in one grid, 256 SNPs i per workgroup
+        std::vector<LdPairChr> pc;
+        int64_t blocks = 0;
+        for (int c = 0; c < p->nchr; c++) {
+            pc.push_back(LdPairChr{p->chr_off[c], p->chr_off[c + 1], blocks});
+            blocks += (p->chr_nloci[c] + LDM_TI - 1) / LDM_TI;
+        }
+        DevBuf<LdPairChr> &d_pc = p->lds.pair_chrs;
+        if ((rc = d_pc.reserve(pc.size()))) return done(rc);
+        e = hipMemcpyAsync(d_pc.p, pc.data(), sizeof(LdPairChr) * pc.size(), hipMemcpyHostToDevice, s);
+        const void *fn = mfma_nj <= 2 ? (const void *)ld_pair_mfma_kernel<2> : mfma_nj == 3 ? (const void *)ld_pair_mfma_kernel<3>
+                       : mfma_nj == 4 ? (const void *)ld_pair_mfma_kernel<4> : (const void *)ld_pair_mfma_kernel<5>;
+        const int nj = std::max(2, mfma_nj);
+        const size_t lds = (size_t)2 * 2 * (4 + nj - 1) * 2 * WAVE * 16;
+        if (e == hipSuccess && lds > 48 * 1024) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
+        const uint64_t *a_m = d_m.p, *a_h = d_h.p;
+        const LdPairChr *a_pc = d_pc.p;
+        int a_nblk = nblk, a_nchr = p->nchr, a_w = winsize;
+        int64_t a_nloci = p->nloci;
+        void *kargs[] = {(void *)&a_m, (void *)&a_h, (void *)&a_nblk, (void *)&a_nloci, (void *)&a_pc, (void *)&a_nchr, (void *)&a_w, (void *)&pair};
+        e = hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), kargs, lds, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);   // pc (host) is read by the copy above
         if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
     }
@@ -2249,7 +2301,7 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
             hipLaunchKernelGGL(ld_pair_flat_kernel<false>, dim3(grid), dim3(256), 0, s, d_m.p, d_h.p, (const uint64_t *)nullptr,
                                (const uint64_t *)nullptr, nblk, p->nloci, p->d_chr_off.p, p->nchr, winsize, pair);
     }
-    for (int c = 0; !pair_tiled && !pair_flat && !pair_lane && c < p->nchr; c++) {
+    for (int c = 0; !pair_tiled && !pair_flat && !pair_lane && !pair_mfma && c < p->nchr; c++) {
         if (phased)
             hipLaunchKernelGGL(ld_pair_phased_kernel, dim3((unsigned)p->chr_nloci[c]), dim3(256), 0, s, d_m.p,
                                d_h.p, d_o.p, p->d_phase.p, nblk, p->nloci, p->chr_off[c], p->chr_off[c + 1],

@@ -871,3 +871,128 @@ ld_sum_col_kernel(const double *__restrict__ C, const LdSumChr *__restrict__ chr
 }
 
 } // namespace garlic
+
+namespace garlic {
+
+// Pair counts on the matrix cores.  tot(i, j) = |M_i & M_j| and HAB(i, j) = |H_i & H_j| are dot products of 0/1
+// vectors over the individuals -- a banded Gram matrix M M^T, H H^T (|i - j| < W): a contraction, so it belongs on
+// MFMA (v_mfma_i32_32x32x32_i8: exact integers).  ld_pair_lane_kernel does AND + popcount per (pair, block) from
+// LDS, 9.6 ms at 10M SNPs x 1250, W = 100; here: 2 x 2 x NJ MFMAs per 64 individuals and tile of 32 SNPs.
+//   workgroup = 128 SNPs i (4 waves x a tile of 32) against their 128 + 32 (NJ - 1) partners j, NJ = 1 + (30 + W) / 32
+//   per 64-individual block: every thread turns one SNP's plane words (1 bit per individual) into bytes -- 4 vector
+//   instructions per 4 individuals -- and stores them in MFMA fragment order [plane][tile][k step][lane][16 B]
+//   (conflict-free both ways); each wave then reads its 1 + NJ fragments per plane and k step and issues NJ MFMAs
+//   on them.  Two LDS buffers: the bytes of block b + 1 are made while block b is multiplied.  One tile per wave:
+//   2 NJ accumulator tiles = 160 registers at W = 100 (two tiles per wave, 320, did not fit the accumulation
+//   registers and hipcc moved them in and out around every MFMA: 590 v_accvgpr moves per block).
+//   The k order inside a fragment does not matter (both operands use the same one: the sum runs over all of it).
+// SNPs past the chromosome are staged as zero words (their pairs count 0, as the table wants); d = 0 is written as 0.
+constexpr int LDM_TI = 128;
+typedef int ldm_i32x4 __attribute__((ext_vector_type(4)));
+typedef int ldm_i32x16 __attribute__((ext_vector_type(16)));
+
+// 64 individuals' bits -> 64 bytes (0 / 1), individuals 4 d .. 4 d + 3 in dword d
+__device__ __forceinline__ void ldm_expand(uint64_t w, uint32_t (&out)[16])
+{
+    const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+#pragma unroll
+    for (int d = 0; d < 16; d++) {
+        const uint32_t x = ((d < 8 ? lo : hi) >> (4 * (d & 7))) & 0xFFu;     // bits 4 .. 7 never reach a kept position
+        const uint32_t t1 = (x << 7) | x;
+        const uint32_t t2 = (t1 << 14) | t1;
+        out[d] = t2 & 0x01010101u;
+    }
+}
+
+template <int NJ>
+__global__ void __launch_bounds__(256, 2)
+ld_pair_mfma_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__ planeH, int nblk, int64_t nloci,
+                    const LdPairChr *__restrict__ chrs, int nchr, int W, int32_t *__restrict__ pair)
+{
+    constexpr int NT = 4 + NJ - 1;                 // staged tiles of 32 SNPs (<= 8: one SNP per thread)
+    static_assert(NT * 32 <= 256, "one staged SNP per thread");
+    constexpr int BUF = 2 * NT * 2 * WAVE * 16;    // bytes per buffer: [plane][tile][k step][lane][16]
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldm_lds[];      // two buffers
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int c = 0;
+    while (c + 1 < nchr && (int64_t)blockIdx.x >= chrs[c + 1].block0) c++;
+    const int64_t hi = chrs[c].hi;
+    const int64_t i0 = chrs[c].lo + ((int64_t)blockIdx.x - chrs[c].block0) * LDM_TI;
+    const bool mine = tid < NT * 32;                            // this thread stages SNP i0 + tid
+    const bool in = mine && i0 + tid < hi;
+    uint64_t wm = 0, wh = 0;
+    auto fetch = [&](int b) {
+        const int64_t g = (int64_t)b * nloci + i0 + (in ? tid : 0);
+        wm = in ? planeM[g] : 0;
+        wh = in ? planeH[g] : 0;
+    };
+    auto stage = [&](int buf) {
+        if (!mine) return;
+        const int tile = tid >> 5, r = tid & 31;
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+            uint32_t e[16];
+            ldm_expand(pl ? wh : wm, e);
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) {                   // chunk = (k step, lane half): individuals 16 ch ..
+                unsigned char *dst = ldm_lds + buf * BUF + ((((pl * NT + tile) * 2 + (ch >> 1)) * WAVE) + (ch & 1) * 32 + r) * 16;
+                *reinterpret_cast<uint4 *>(dst) = make_uint4(e[4 * ch], e[4 * ch + 1], e[4 * ch + 2], e[4 * ch + 3]);
+            }
+        }
+    };
+    ldm_i32x16 acc[NJ][2];
+#pragma unroll
+    for (int q = 0; q < NJ; q++)
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) acc[q][pl][k] = 0;
+    fetch(0);
+    stage(0);
+    if (nblk > 1) fetch(1);
+    __syncthreads();
+    for (int b = 0; b < nblk; b++) {
+        const int buf = b & 1;
+#ifndef GARLIC_LDM_ABL_NO_STAGE       // timing experiment (results wrong)
+        if (b + 1 < nblk) stage(buf ^ 1);                       // (its words were requested a block ago)
+#endif
+        if (b + 2 < nblk) fetch(b + 2);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++) {
+                ldm_i32x4 fb[NJ];
+#pragma unroll
+                for (int q = 0; q < NJ; q++)
+                    fb[q] = *reinterpret_cast<const ldm_i32x4 *>(ldm_lds + buf * BUF +
+                                                                 ((((pl * NT + wave + q) * 2 + ks) * WAVE) + lane) * 16);
+#pragma unroll
+                for (int q = 0; q < NJ; q++)
+                    acc[q][pl] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[0], fb[q], acc[q][pl], 0, 0, 0);
+            }
+        __syncthreads();
+    }
+    // C layout (dtype-independent): column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int col = lane & 31, rh = 4 * (lane >> 5);
+    const int64_t it = i0 + wave * 32;
+#pragma unroll
+    for (int q = 0; q < NJ; q++) {
+        const int64_t j = it + q * 32 + col;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int64_t i = it + (k & 3) + 8 * (k >> 2) + rh;
+            const int64_t d = j - i;
+            if (i < hi && d >= 0 && d < W) {
+                int2 v = make_int2(acc[q][0][k], acc[q][1][k]);
+                if (d == 0) v = make_int2(0, 0);
+#ifdef GARLIC_LDM_ABL_NO_STORE      // timing experiment (results wrong)
+                if (v.x != 0x7FFFFFF1) continue;
+#endif
+                *reinterpret_cast<int2 *>(pair + (i * W + d) * 2) = v;
+            }
+        }
+    }
+}
+
+} // namespace garlic
