@@ -63,12 +63,71 @@ def hbm_roofline(kernel, bytes_per_launch, kernel_ms, **extra):
     return r
 
 
+class ClockSampler:
+    """Shader clock and socket power from rocm-smi while a kernel loops (a thread polling every ~0.3 s).  The FP64-bound
+    wLOD kernels run power-capped: `peak` in their roofline object is the spec figure at 2.4 GHz, this says what clock
+    the chip actually held ("wLOD is power-bound")."""
+
+    def __init__(self, smi_index=0):
+        import threading
+        self.idx, self.samples, self._stop = smi_index, [], threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                txt = subprocess.run(["rocm-smi", "-d", str(self.idx), "--showclocks", "--showpower"], capture_output=True,
+                                     text=True, timeout=5).stdout
+                m = re.search(r"sclk clock level:\s*\d+:\s*\((\d+)Mhz\)", txt)
+                w = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
+                if m:
+                    self.samples.append((float(m.group(1)), float(w.group(1)) if w else float("nan")))
+            except Exception:
+                return
+            self._stop.wait(0.2)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=10)
+
+    def summary(self):
+        busy = [x for x in self.samples[1:] if x[0] > 1000.0]         # first sample: the clock is still ramping
+        if len(busy) < 2:
+            return None
+        return {"sclk_mhz_under_load": float(np.mean([x[0] for x in busy])), "socket_power_w": float(np.mean([x[1] for x in busy])),
+                "samples": len(busy), "source": "rocm-smi -d %d --showclocks --showpower, polled while the kernel looped" % self.idx}
+
+
+def clock_under_load(call, sync, seconds=2.5):
+    """loops `call` for a few seconds with the sampler running; None when rocm-smi is not there"""
+    import shutil
+    if not shutil.which("rocm-smi"):
+        return None
+    with ClockSampler() as cs:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(4):
+                call()
+            sync()
+    return cs.summary()
+
+
 def fp64_roofline(kernel, windows, W, kernel_ms, **extra):
     flops = 2.0 * windows * W        # one v_mul_f64 + one v_add_f64 per (window, term): the product rounds before the add
     a = flops / (kernel_ms * 1e-3) / 1e12
     r = {"bound": "fp64 valu (separately rounded multiply + add per term: no FMA, no MFMA)", "kernel": kernel,
          "achieved": a, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": a / FP64_PEAK_TFLOPS, "traffic": None,
          "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops}
+    clk = extra.pop("clock", None)
+    if clk:
+        r["clock_under_load"] = clk
+        r["frac_at_measured_clock"] = r["frac"] * 2400.0 / clk["sclk_mhz_under_load"]
     r.update(extra)
     return r
 
@@ -284,9 +343,9 @@ def leg_ns(ctx, dev, steps):
         adds = float(nloci) * W * W
         res[name] = {"call_ms": t * 1e3, "snps_per_s": nloci / t,
                      "roofline": {"bound": "fp64 valu adds (W^2 ordered adds per window start, ld_sum_col_kernel: one LDS read per "
-                                           "up to 32 of them); the counts are AND + popcount over the subsample's bit planes, "
-                                           "hr2 two FP64 divisions per SNP pair",
-                                  "kernel": "ld_* (planes, pair counts, hr2 table, ordered sums + wLOD weights) -- the whole call",
+                                           "up to 32 of them); the pair counts are banded Gram matrices of the subsample's bit "
+                                           "planes on the matrix cores (ld_pair_mfma_kernel, i8), hr2 two FP64 divisions per SNP pair",
+                                  "kernel": "ld_* (planes -- kept across calls --, pair counts, hr2 table, ordered sums + wLOD weights) -- the whole warm call",
                                   "achieved": adds / t / 1e12, "peak": FP64_PEAK_TFLOPS / 2, "unit": "TFLOP/s (adds only)",
                                   "frac": adds / t / 1e12 / (FP64_PEAK_TFLOPS / 2), "traffic": None,
                                   "ordered_adds_per_call": adds,
@@ -297,7 +356,8 @@ def leg_ns(ctx, dev, steps):
                                   "popcounts_per_call": float(nloci) * (W - 1) * 2 * ((nsub + 63) // 64)}}
     dt, k = timed_passes(ctx, lambda: panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU), steps, 1,
                          torch.cuda.synchronize)
-    res["wlod"] = dict(rate(k, dt), roofline=fp64_roofline("wlod_tile2_kernel", win, W, k))
+    clk = clock_under_load(lambda: panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU), torch.cuda.synchronize)
+    res["wlod"] = dict(rate(k, dt), roofline=fp64_roofline("wlod_tile2_kernel", win, W, k, clock=clk))
     panel.release_scratch()
     dt, k = timed_passes(ctx, lambda: panel.lod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, use_gl=True), steps, 1,
                          torch.cuda.synchronize)
@@ -305,7 +365,9 @@ def leg_ns(ctx, dev, steps):
                                                           note="term matrix built once per panel (gl_terms_kernel), not in the pass"))
     dt, k = timed_passes(ctx, lambda: panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU, use_gl=True),
                          steps, 1, torch.cuda.synchronize)
-    res["wlod_gl"] = dict(rate(k, dt), roofline=fp64_roofline("wlod_strip_gl_kernel", win, W, k))
+    clk = clock_under_load(lambda: panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU, use_gl=True),
+                           torch.cuda.synchronize)
+    res["wlod_gl"] = dict(rate(k, dt), roofline=fp64_roofline("wlod_strip_gl_kernel", win, W, k, clock=clk))
     # GARLIC's default --winsize 10 (windows narrower than the kernels' 16-window groups): bound by the scores written
     W10 = 10
     panel.compute_ld(W10, want_output=False)                     # scratch for this window size

@@ -2256,7 +2256,7 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
         const void *fn = mfma_nj <= 2 ? (const void *)ld_pair_mfma_kernel<2> : mfma_nj == 3 ? (const void *)ld_pair_mfma_kernel<3>
                        : mfma_nj == 4 ? (const void *)ld_pair_mfma_kernel<4> : (const void *)ld_pair_mfma_kernel<5>;
         const int nj = std::max(2, mfma_nj);
-        const size_t lds = (size_t)2 * 2 * (4 + nj - 1) * 2 * WAVE * 16;
+        const size_t lds = (size_t)2 * 2 * (4 + nj - 1) * WAVE * 16;
         if (e == hipSuccess && lds > 48 * 1024) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
         const uint64_t *a_m = d_m.p, *a_h = d_h.p;

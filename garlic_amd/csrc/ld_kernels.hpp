@@ -876,32 +876,34 @@ namespace garlic {
 
 // Pair counts on the matrix cores.  tot(i, j) = |M_i & M_j| and HAB(i, j) = |H_i & H_j| are dot products of 0/1
 // vectors over the individuals -- a banded Gram matrix M M^T, H H^T (|i - j| < W): a contraction, so it belongs on
-// MFMA (v_mfma_i32_32x32x32_i8: exact integers).  ld_pair_lane_kernel does AND + popcount per (pair, block) from
-// LDS, 9.6 ms at 10M SNPs x 1250, W = 100; here: 2 x 2 x NJ MFMAs per 64 individuals and tile of 32 SNPs.
+// MFMA.  ld_pair_lane_kernel does AND + popcount per (pair, block) from LDS: 9.6 ms at 10M SNPs x 1250, W = 100;
+// on v_mfma_i32_32x32x32_i8 (bits as bytes) 5.6 ms; on fp4 operands (below) 4.8 ms.
 //   workgroup = 128 SNPs i (4 waves x a tile of 32) against their 128 + 32 (NJ - 1) partners j, NJ = 1 + (30 + W) / 32
-//   per 64-individual block: every thread turns one SNP's plane words (1 bit per individual) into bytes -- 4 vector
-//   instructions per 4 individuals -- and stores them in MFMA fragment order [plane][tile][k step][lane][16 B]
-//   (conflict-free both ways); each wave then reads its 1 + NJ fragments per plane and k step and issues NJ MFMAs
-//   on them.  Two LDS buffers: the bytes of block b + 1 are made while block b is multiplied.  One tile per wave:
-//   2 NJ accumulator tiles = 160 registers at W = 100 (two tiles per wave, 320, did not fit the accumulation
-//   registers and hipcc moved them in and out around every MFMA: 590 v_accvgpr moves per block).
-//   The k order inside a fragment does not matter (both operands use the same one: the sum runs over all of it).
+//   per 64-individual block: every thread turns one SNP's plane words (1 bit per individual) into 4-bit operands
+//   and stores them in MFMA fragment order [plane][tile][lane][16 B] (conflict-free both ways); each wave then reads
+//   its NJ fragments per plane and issues NJ MFMAs on them (its own tile is fragment 0).  Two LDS buffers: the
+//   operands of block b + 1 are made while block b is multiplied.  One tile per wave: 2 NJ accumulator tiles = 160
+//   registers at W = 100 (two tiles per wave, 320, did not fit the accumulation registers and hipcc moved them in
+//   and out around every MFMA: 590 v_accvgpr moves per block).  The k order inside a fragment does not matter (both
+//   operands use the same one: the sum runs over all of it).  Ablated at 10M x 1250 (i8 form, tools/exp/ld_mfma_abl.sh):
+//   5.5 ms; without the table's stores 4.55; without the expansion 3.4; without both 2.6.
 // SNPs past the chromosome are staged as zero words (their pairs count 0, as the table wants); d = 0 is written as 0.
 constexpr int LDM_TI = 128;
 typedef int ldm_i32x4 __attribute__((ext_vector_type(4)));
-typedef int ldm_i32x16 __attribute__((ext_vector_type(16)));
 
-// 64 individuals' bits -> 64 bytes (0 / 1), individuals 4 d .. 4 d + 3 in dword d
-__device__ __forceinline__ void ldm_expand(uint64_t w, uint32_t (&out)[16])
+// 4-bit operands: v_mfma_scale_f32_32x32x64_f8f6f4 on fp4 (e2m1) takes a whole 64-individual block per
+// instruction in the cycles the i8 form needs for 32 individuals.  A set bit becomes the nibble 0001 = 0.5, the block
+// scales are 2^0, the products 0.25 and the f32 sums exact (counts below 2^22): count = 4 * sum.  Half the MFMAs,
+// half the LDS bytes, 7 instead of 10 vector instructions per 8 individuals for the expansion.
+typedef int ldm_i32x8 __attribute__((ext_vector_type(8)));
+typedef float ldm_f32x16 __attribute__((ext_vector_type(16)));
+
+// 8 bits -> 8 nibbles (bit m -> nibble m = 0 / 1)
+__device__ __forceinline__ uint32_t ldm_spread8(uint32_t x)
 {
-    const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
-#pragma unroll
-    for (int d = 0; d < 16; d++) {
-        const uint32_t x = ((d < 8 ? lo : hi) >> (4 * (d & 7))) & 0xFFu;     // bits 4 .. 7 never reach a kept position
-        const uint32_t t1 = (x << 7) | x;
-        const uint32_t t2 = (t1 << 14) | t1;
-        out[d] = t2 & 0x01010101u;
-    }
+    uint32_t t = (x | (x << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    return (t | (t << 3)) & 0x11111111u;
 }
 
 template <int NJ>
@@ -911,7 +913,7 @@ ld_pair_mfma_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restr
 {
     constexpr int NT = 4 + NJ - 1;                 // staged tiles of 32 SNPs (<= 8: one SNP per thread)
     static_assert(NT * 32 <= 256, "one staged SNP per thread");
-    constexpr int BUF = 2 * NT * 2 * WAVE * 16;    // bytes per buffer: [plane][tile][k step][lane][16]
+    constexpr int BUF = 2 * NT * WAVE * 16;        // bytes per buffer: [plane][tile][lane][16]: 32 individuals per lane
     extern __shared__ __attribute__((aligned(16))) unsigned char ldm_lds[];      // two buffers
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -932,26 +934,28 @@ ld_pair_mfma_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restr
         const int tile = tid >> 5, r = tid & 31;
 #pragma unroll
         for (int pl = 0; pl < 2; pl++) {
-            uint32_t e[16];
-            ldm_expand(pl ? wh : wm, e);
+            const uint64_t w = pl ? wh : wm;
 #pragma unroll
-            for (int ch = 0; ch < 4; ch++) {                   // chunk = (k step, lane half): individuals 16 ch ..
-                unsigned char *dst = ldm_lds + buf * BUF + ((((pl * NT + tile) * 2 + (ch >> 1)) * WAVE) + (ch & 1) * 32 + r) * 16;
-                *reinterpret_cast<uint4 *>(dst) = make_uint4(e[4 * ch], e[4 * ch + 1], e[4 * ch + 2], e[4 * ch + 3]);
+            for (int h = 0; h < 2; h++) {                      // lane half = individuals 32 h .. 32 h + 31
+                const uint32_t x = (uint32_t)(w >> (32 * h));
+                unsigned char *dst = ldm_lds + buf * BUF + (((pl * NT + tile) * WAVE) + h * 32 + r) * 16;
+                *reinterpret_cast<uint4 *>(dst) = make_uint4(ldm_spread8(x & 0xFFu), ldm_spread8((x >> 8) & 0xFFu),
+                                                             ldm_spread8((x >> 16) & 0xFFu), ldm_spread8(x >> 24));
             }
         }
     };
-    ldm_i32x16 acc[NJ][2];
+    ldm_f32x16 acc[NJ][2];
 #pragma unroll
     for (int q = 0; q < NJ; q++)
 #pragma unroll
         for (int pl = 0; pl < 2; pl++)
 #pragma unroll
-            for (int k = 0; k < 16; k++) acc[q][pl][k] = 0;
+            for (int k = 0; k < 16; k++) acc[q][pl][k] = 0.0f;
     fetch(0);
     stage(0);
     if (nblk > 1) fetch(1);
     __syncthreads();
+    const int one = 0x7F7F7F7F;                                 // E8M0 block scales: 2^0
     for (int b = 0; b < nblk; b++) {
         const int buf = b & 1;
 #ifndef GARLIC_LDM_ABL_NO_STAGE       // timing experiment (results wrong)
@@ -959,18 +963,17 @@ ld_pair_mfma_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restr
 #endif
         if (b + 2 < nblk) fetch(b + 2);
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++)
+        for (int pl = 0; pl < 2; pl++) {
+            ldm_i32x8 fb[NJ];
 #pragma unroll
-            for (int pl = 0; pl < 2; pl++) {
-                ldm_i32x4 fb[NJ];
-#pragma unroll
-                for (int q = 0; q < NJ; q++)
-                    fb[q] = *reinterpret_cast<const ldm_i32x4 *>(ldm_lds + buf * BUF +
-                                                                 ((((pl * NT + wave + q) * 2 + ks) * WAVE) + lane) * 16);
-#pragma unroll
-                for (int q = 0; q < NJ; q++)
-                    acc[q][pl] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fb[0], fb[q], acc[q][pl], 0, 0, 0);
+            for (int q = 0; q < NJ; q++) {
+                const ldm_i32x4 f = *reinterpret_cast<const ldm_i32x4 *>(ldm_lds + buf * BUF + (((pl * NT + wave + q) * WAVE) + lane) * 16);
+                fb[q] = ldm_i32x8{f[0], f[1], f[2], f[3], 0, 0, 0, 0};
             }
+#pragma unroll
+            for (int q = 0; q < NJ; q++)
+                acc[q][pl] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[0], fb[q], acc[q][pl], 4, 4, 0, one, 0, one);
+        }
         __syncthreads();
     }
     // C layout (dtype-independent): column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -984,7 +987,7 @@ ld_pair_mfma_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restr
             const int64_t i = it + (k & 3) + 8 * (k >> 2) + rh;
             const int64_t d = j - i;
             if (i < hi && d >= 0 && d < W) {
-                int2 v = make_int2(acc[q][0][k], acc[q][1][k]);
+                int2 v = make_int2((int)(acc[q][0][k] * 4.0f), (int)(acc[q][1][k] * 4.0f));
                 if (d == 0) v = make_int2(0, 0);
 #ifdef GARLIC_LDM_ABL_NO_STORE      // timing experiment (results wrong)
                 if (v.x != 0x7FFFFFF1) continue;

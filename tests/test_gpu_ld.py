@@ -274,3 +274,22 @@ def test_phased_ld_golden_from_the_reference_build(gpu_ctx):
         for W in (10, 30):
             assert same(panel.compute_ld(W, phased=True), d[f"ld_W{W}"]), W
             assert same(panel.compute_ld(W, sub_idx=d["sub"], phased=True), d[f"ldsub_W{W}"]), W
+
+
+def test_ld_plane_cache_follows_genotypes_and_subsample(gpu_ctx):
+    """the bit planes are kept across calls: new genotypes, another subsample or another window size must not see stale
+    ones; W = 40 and 100 run the matrix-core pair counts (ld_pair_mfma_kernel), chromosomes around its 128-SNP tiles"""
+    rng = np.random.default_rng(2026)
+    nind = 200
+    sizes = [127, 128, 129, 300, 41]
+    chroms = [ol.random_panel(rng, n, nind, max_gap=10 ** 9, gaps=0, miss=0.04) for n in sizes]
+    sub = np.sort(rng.choice(nind, size=90, replace=False)).astype(np.int32)
+    with make_panel(gpu_ctx, chroms, nind) as panel:
+        for W in (40, 100, 40):
+            assert same(panel.compute_ld(W), oracle_ld(chroms, W)), W
+            assert same(panel.compute_ld(W, sub_idx=sub), oracle_ld(chroms, W, sub)), W
+        chroms2 = [ol.random_panel(rng, n, nind, max_gap=10 ** 9, gaps=0, miss=0.04) for n in sizes]
+        chroms2 = [(c2[0],) + tuple(c[1:]) for c, c2 in zip(chroms, chroms2)]       # same map, new genotypes
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms2], axis=0))
+        assert same(panel.compute_ld(40, sub_idx=sub), oracle_ld(chroms2, 40, sub))
+        assert same(panel.compute_ld(40), oracle_ld(chroms2, 40))
