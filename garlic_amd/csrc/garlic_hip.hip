@@ -2902,7 +2902,7 @@ int garlic_roh_coverage(garlic_panel *p, const double *scores, int32_t pitch_ali
     if (e == hipSuccess)
         e = hipMemcpyAsync(d_seg.p, seg_base.data(), sizeof(int32_t) * seg_base.size(), hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
-    const size_t lds = sizeof(int32_t) * ((size_t)winsize + COV_SEG + 1);
+    const size_t lds = sizeof(uint16_t) * ((size_t)winsize + COV_SEG + 2);      // (counts <= COV_SEG + W - 1: 16 bits, W < 57000)
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(roh_coverage_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
