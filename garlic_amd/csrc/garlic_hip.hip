@@ -2456,8 +2456,9 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
             const LdSumChr *a_chrs = d_sum_chrs.p;
             int a_nchr = (int)sum_chrs.size(), a_w = winsize, a_b = sum_b;
             double *a_ld = ld, *a_d = p->d_skew.p + SKEW_FRONT;
-            void *kargs[] = {(void *)&a_c, (void *)&a_chrs, (void *)&a_nchr, (void *)&a_w, (void *)&a_b, (void *)&a_ld, (void *)&a_d};
-            e = hipLaunchKernel(fn, dim3((unsigned)sum_blocks), dim3(threads), kargs, lds, s);
+            unsigned a_nwork = (unsigned)sum_blocks;
+            void *kargs[] = {(void *)&a_c, (void *)&a_chrs, (void *)&a_nchr, (void *)&a_w, (void *)&a_b, (void *)&a_ld, (void *)&a_d, (void *)&a_nwork};
+            e = hipLaunchKernel(fn, dim3((a_nwork + 7u) / 8u * 8u), dim3(threads), kargs, lds, s);
             if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD finish: %s", hipGetErrorString(e)));
         }
         else

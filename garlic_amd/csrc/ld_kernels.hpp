@@ -638,7 +638,10 @@ ld_sum_tiled_kernel(const double *__restrict__ fwd, const double *__restrict__ b
 // The rows come from ld_hr2_kernel<true>'s combined table (one contiguous row of 2W doubles per SNP).
 constexpr int LD_COL_B = 32;
 constexpr int LD_COL_MAX_THREADS = 576;      // W + B - 1 SNPs in whole waves: W <= 512
-constexpr int LD_COL_BATCH = 4;      // rows per wait + barrier
+#ifndef GARLIC_LD_COL_BATCH
+#define GARLIC_LD_COL_BATCH 4
+#endif
+constexpr int LD_COL_BATCH = GARLIC_LD_COL_BATCH;      // rows per wait + barrier (8: measured, see DESIGN section 3 LD)
 constexpr int LD_COL_NBATCH = 4;     // batches in the LDS ring (NBATCH - 1 requested ahead)
 constexpr int LD_COL_MAX_PIECES = 5; // 1-KB requests per row (8 B per thread, 576 threads at most)
 
@@ -759,8 +762,16 @@ __device__ __forceinline__ void ld_col_adds(double (&a)[LD_COL_B], double h, boo
 template <int PIECES>
 __global__ void __launch_bounds__(LD_COL_MAX_THREADS)
 ld_sum_col_kernel(const double *__restrict__ C, const LdSumChr *__restrict__ chrs, int nchr, int W, int B,
-                  double *__restrict__ ld, double *__restrict__ D)
+                  double *__restrict__ ld, double *__restrict__ D, unsigned nwork)
 {
+    // Neighbouring workgroups read the same rows of C (a row serves (B + W - 1) / B = 4.4 of them at W = 100).  Workgroups
+    // are dealt round-robin over the 8 XCDs, each with an L2 of its own: numbered plainly, the neighbours sat on eight
+    // different L2s and every one of them fetched its rows from memory -- 44 GB instead of 16 at 10M SNPs, and the
+    // kernel ran at that rate (its skeleton, no adds and no stores: 7.2 of 10.7 ms).  Give every XCD a contiguous
+    // range of the work instead (gridDim.x is a multiple of 8).
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned vblock = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (vblock >= nwork) return;
     // Step j (SNP i = s0 + j) needs of row i only the elements x = W-1 + tl - j of the workgroup's threads: blockDim
     // consecutive doubles from a_j = (W-1 - j) rounded down to even (16-B aligned for the DMA) -- 1 KB for 128
     // threads instead of the row's 2W doubles.  Thread tl finds its element at tl + ((W-1-j) & 1).  Elements in
@@ -776,8 +787,8 @@ ld_sum_col_kernel(const double *__restrict__ C, const LdSumChr *__restrict__ chr
     const int tl = threadIdx.x, P = 2 * W;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int c = 0;
-    while (c + 1 < nchr && (int64_t)blockIdx.x >= chrs[c + 1].block0) c++;
-    const int64_t s0 = chrs[c].lo + ((int64_t)blockIdx.x - chrs[c].block0) * B;
+    while (c + 1 < nchr && (int64_t)vblock >= chrs[c + 1].block0) c++;
+    const int64_t s0 = chrs[c].lo + ((int64_t)vblock - chrs[c].block0) * B;
     const int ns = (int)min<int64_t>(B, chrs[c].lo + chrs[c].nstarts - s0);
     const int nsteps = ns + W - 1, nbatches = (nsteps + BATCH - 1) / BATCH;
     // wave 0 streams the pieces into the ring by LDS-DMA, NB - 1 batches ahead, no registers in between
@@ -836,18 +847,29 @@ ld_sum_col_kernel(const double *__restrict__ C, const LdSumChr *__restrict__ chr
 #pragma unroll
         for (int u = 0; u < BATCH; u++) {
             const int j = j0 + u;
+#ifdef GARLIC_LDS_ABL_NO_ADDS
+            if (j < nsteps && h[u] == 1.2345e-300) {
+#else
             if (j < nsteps) {
+#endif
                 const bool leaving = j >= W;
                 ld_col_adds(acc, h[u], leaving,                                 // entering: q = min(j, 31) .. 0
                             leaving ? j - W + 1 : (j < LD_COL_B - 1 ? LD_COL_B - 1 - j : 0));   // leaving: q = j-W+1 .. 31
             }
         }
     }
+#ifndef GARLIC_LDS_ABL_NO_LD          // timing experiments (results wrong)
 #pragma unroll
     for (int q = 0; q < LD_COL_B; q++) {
         const int k = tl - q;
         if (q < ns && k >= 0 && k < W) ld[(s0 + q) * W + k] = x86_nan_if_nan(acc[q]);
     }
+#else
+    if (acc[0] == 1.2345e-300) ld[s0 * W + tl] = acc[1] + acc[2] + acc[3] + acc[31] + acc[16];
+#endif
+#ifdef GARLIC_LDS_ABL_NO_D
+    if (acc[5] != 1.2345e-300) return;
+#endif
     // ... and the weight the tuned wLOD kernels read, D[l][k] = 1 / LD[l - k][k] (skew_reciprocal_kernel): SNP
     // l = s0 + tl is this thread's, its row takes the thread's values back to front.  Through an LDS tile
     // [thread][16 starts], so that 16 lanes write 128 contiguous bytes of one row (straight from the registers every

@@ -37,7 +37,7 @@ def soak(ctx, trials, seed, verbose=True):
     strip_env = os.environ.get("GARLIC_WLOD_STRIP_GROUPS")
     for trial in range(trials):
         nchr = int(rng.integers(1, 4))
-        W = int(rng.choice([2, 5, 16, 17, 31, 32, 33, 64, 100, 130]))
+        W = int(rng.choice([2, 5, 10, 15, 16, 17, 31, 32, 33, 64, 100, 129, 130]))
         sizes = [int(rng.choice([1, W - 1, W, W + 1, int(rng.integers(2 * W, 40 * W + 300))])) for _ in range(nchr)]
         sizes = [max(1, n) for n in sizes]
         nind = int(rng.choice([1, 63, 64, 65, int(rng.integers(2, 260))]))
