@@ -472,7 +472,10 @@ ld_sum_flat_kernel(const int32_t *__restrict__ pair, const double *__restrict__ 
 // along d as before; the values for the partner rows go through an LDS tile [i][d] and leave as pieces of
 // LD_HR2_T consecutive doubles per row (C[j][W-1 - (j - i)], i ascending).  The two values of a pair share
 // HAB / total and H * H -- the same operations in the same order as two calls of hr2_from_counts.
-constexpr int LD_HR2_T = 32;
+#ifndef GARLIC_LD_HR2_T
+#define GARLIC_LD_HR2_T 32
+#endif
+constexpr int LD_HR2_T = GARLIC_LD_HR2_T;
 __global__ void __launch_bounds__(256)
 ld_hr2_tile_kernel(const int32_t *__restrict__ pair, const double *__restrict__ hf, int64_t lo, int64_t hi,
                    int W, double *__restrict__ C)
