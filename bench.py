@@ -326,7 +326,32 @@ def leg_ns(ctx, dev, steps):
                            "roofline": hbm_roofline("roh_coverage_kernel", 10.0 * win, tcv * 1e3,
                                                     note="10 B per window (8 B score in, 2 B count out); timed as the whole synchronous "
                                                          "call (wall clock, best of 3): kernel + two small uploads")}
-    del cov, evs
+    # ... and the same counts WITHOUT the scores (garlic_roh_coverage_fused: chain + compare + sliding count in one kernel,
+    # 2 B per window leave the chip, no score matrix resident) -- what GARLIC's final pass needs when --raw-lod is not asked for
+    _, _, tcov8 = panel.out_layout(8, nind)
+    cov8 = torch.empty(tcov8, dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    panel.roh_coverage_fused_device(W, ERROR, MAX_GAP, 2.5, cov8.data_ptr(), pitch_align=8)
+    tf = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        panel.roh_coverage_fused_device(W, ERROR, MAX_GAP, 2.5, cov8.data_ptr(), pitch_align=8)
+        tf.append(time.perf_counter() - t0)
+    tfu = float(np.min(tf))
+    b1, p1, _ = panel.out_layout(1, nind)
+    b8, p8, _ = panel.out_layout(8, nind)
+    same = all(bool(torch.equal(cov[b1[c]: b1[c] + nind * p1[c]].view(nind, p1[c])[:, :spec.chr_nloci[c]],
+                                cov8[b8[c]: b8[c] + nind * p8[c]].view(nind, p8[c])[:, :spec.chr_nloci[c]]))
+               for c in range(len(b1)))
+    res["roh_coverage_fused"] = {"call_ms": tfu * 1e3, "sliding_windows_per_s": win / tfu,
+                                 "scores_then_counts_ms": res["lod"]["kernel_ms"] + tcv * 1e3,
+                                 "equals_scores_then_counts": same,
+                                 "roofline": hbm_roofline("lod_coverage_kernel", 2.25 * win, tfu * 1e3,
+                                                          note="2.25 B per window (0.25 B genotype in, 2 B count out): not an HBM-bound kernel -- "
+                                                               "the sequential chain of the longest run, ~18 instructions per window on one "
+                                                               "wave, is its critical path; no 8 B per window of scores written, read or resident")}
+    del cov, evs, cov8
     torch.cuda.empty_cache()      # 25 GB of counts: the likelihood legs below need the room
     # LD weights: integer pair counts (AND + popcount on bit planes) + W^2 ordered FP64 adds per window start
     for name, sub in (("ld_all_individuals", None),

@@ -12,6 +12,7 @@
 #include "tgls_ring_kernel.hpp"
 #include "wlod_strip_kernel.hpp"
 #include "wlod_small_kernel.hpp"
+#include "coverage_kernel.hpp"
 #include "feed_kernel.hpp"
 
 #include <algorithm>
@@ -2858,6 +2859,121 @@ int garlic_lod_feed_multi(garlic_panel *p, const int32_t *winsizes, const int32_
     p->stats = garlic_call_stats{};
     p->stats.chain_kernel_ms = ms_sum;    // (the sizes overlap: the sum of their spans, not wall time)
     p->stats_pending = false;
+    return done(GARLIC_OK);
+}
+
+// Coverage counts of the unweighted --error scores without the scores: chain + compare + sliding count in one kernel
+// (coverage_kernel.hpp).  Where that kernel does not apply -- a cutoff at or below MISSING, terms that are not all
+// finite, a window sum that can be -9999.0, W > COVF_MAX_W -- the scores are computed into the panel's scratch and
+// counted by garlic_roh_coverage.
+int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, double cutoff,
+                              int16_t *inwin, int32_t inwin_pitch_align, int32_t where)
+{
+    if (!p || !inwin) return fail(GARLIC_ERR_INVALID, "panel and inwin are required");
+    if (winsize <= 1 || inwin_pitch_align < 1) return fail(GARLIC_ERR_INVALID, "winsize must be > 1, inwin_pitch_align >= 1");
+    if (winsize > 32767) return fail(GARLIC_ERR_INVALID, "coverage counts are 16-bit: winsize <= 32767");
+    garlic_ctx *ctx = p->ctx;
+    int rc;
+    if ((rc = set_device(ctx))) return rc;
+    if (!p->have_map || !p->have_freq || !p->have_geno)
+        return fail(GARLIC_ERR_STATE, "panel needs map, freq and genotypes before computing LOD");
+    if ((rc = ensure_segments(p, max_gap))) return rc;
+    if ((rc = ensure_term_table(p, error))) return rc;
+    const int32_t W = winsize;
+    const bool fused = W <= COVF_MAX_W && cutoff > MISSING_D && p->tab_all_finite && !lod_exact_needed(p, MODE_LOD, W) &&
+                       !getenv("GARLIC_COVERAGE_UNFUSED");
+    if (!fused) {
+        const Layout L = make_layout(p, 32, p->nind);
+        if ((rc = p->d_out.reserve(ctx, (size_t)L.total))) return rc;
+        if ((rc = garlic_lod_windows(p, W, error, max_gap, 0, 0, p->nind, 32, p->d_out.p, GARLIC_DEVICE))) return rc;
+        return garlic_roh_coverage(p, p->d_out.p, 32, p->nind, W, cutoff, inwin, inwin_pitch_align, where);
+    }
+    hipStream_t s = ctx->stream;
+    const int nblk = (p->nind + WAVE - 1) / WAVE;
+    std::vector<Run> runs;
+    std::vector<FillItem> fill;
+    int64_t n_valid = 0;
+    plan_runs(p, W, runs, fill, n_valid);              // in chromosome and position order
+    std::vector<int> order(runs.size());
+    for (size_t k = 0; k < runs.size(); k++) order[k] = (int)k;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return (runs[x].b - runs[x].a) > (runs[y].b - runs[y].a); });
+    std::vector<int32_t> col0(runs.size(), 0);
+    std::vector<FeedItem> items;
+    build_feed_items(runs, order, nullptr, nblk, col0, items);
+    // what no run covers: zeroed by a kernel of its own (a run [a, b] covers the SNPs a .. b + W - 1)
+    std::vector<CovRange> ranges;
+    {
+        size_t r = 0;
+        for (int c = 0; c < p->nchr; c++) {
+            int32_t cursor = 0;
+            const int32_t n = (int32_t)p->chr_nloci[c];
+            for (; r < runs.size() && runs[r].chr == c; r++) {
+                if (runs[r].a > cursor) ranges.push_back(CovRange{c, cursor, runs[r].a});
+                cursor = std::max<int32_t>(cursor, std::min<int32_t>(runs[r].b + W, n));
+            }
+            if (cursor < n) ranges.push_back(CovRange{c, cursor, n});
+        }
+    }
+    const Layout Lo = make_layout(p, inwin_pitch_align, p->nind);
+    std::vector<ChrDev> chrs((size_t)p->nchr);
+    for (int c = 0; c < p->nchr; c++) chrs[(size_t)c] = ChrDev{p->chr_off[c], Lo.base[c], Lo.pitch[c], p->chr_nloci[c], 0};
+    DevBuf<FeedItem> d_items;
+    DevBuf<ChrDev> d_chrs;
+    DevBuf<CovRange> d_ranges;
+    DevBuf<int32_t> d_counter;
+    DevBuf<int16_t> d_cov;
+    auto done = [&](int code) { d_items.release(); d_chrs.release(); d_ranges.release(); d_counter.release(); d_cov.release(); return code; };
+    if ((rc = d_items.reserve(std::max<size_t>(items.size(), 1))) || (rc = d_chrs.reserve(chrs.size())) ||
+        (rc = d_ranges.reserve(std::max<size_t>(ranges.size(), 1))) || (rc = d_counter.reserve(4)))
+        return done(rc);
+    int16_t *dst = inwin;
+    if (where == GARLIC_HOST) {
+        if ((rc = d_cov.reserve((size_t)Lo.total))) return done(rc);
+        dst = d_cov.p;
+    }
+    hipError_t e = hipMemcpyAsync(d_chrs.p, chrs.data(), sizeof(ChrDev) * chrs.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && !items.empty())
+        e = hipMemcpyAsync(d_items.p, items.data(), sizeof(FeedItem) * items.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && !ranges.empty())
+        e = hipMemcpyAsync(d_ranges.p, ranges.data(), sizeof(CovRange) * ranges.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_counter.p, 0, 4 * sizeof(int32_t), s);
+    if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+    const int ring = (W + 32 + 31) / 32 * 32;
+    const size_t lds = GARLIC_FEED_LDS_TOTAL + sizeof(uint64_t) * (size_t)ring * FEED_G;
+    bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    for (int c = 0; c < p->nchr; c++) vec_ok = vec_ok && Lo.base[c] % 8 == 0 && Lo.pitch[c] % 8 == 0;
+    const int slot = (int)(ctx->n_calls % garlic_ctx::HIST);
+    (void)hipEventRecord(ctx->hist0[slot], s);
+    if (!ranges.empty())
+        hipLaunchKernelGGL(fill_i16_ranges_kernel, dim3((unsigned)ranges.size(), (unsigned)std::min(p->nind, 1024)), dim3(256), 0, s,
+                           d_ranges.p, d_chrs.p, p->nind, dst);
+    if (!items.empty()) {
+        CovArgs a{p->d_packed.p, p->d_tab.p, d_items.p, d_chrs.p, dst, p->nwordrows, p->nind, W, (int32_t)items.size(), ring,
+                  vec_ok ? 1 : 0, cutoff, d_counter.p};
+        // 32 <= W <= 224: the lanes' qualifying bits in registers; else the waves' ballot masks in LDS rings
+        const bool reghist = W >= 32 && W <= COVF_REG_MAX_W && !getenv("GARLIC_COVERAGE_LDS_RING");
+        const void *fn = reghist ? (const void *)lod_coverage_kernel<true> : (const void *)lod_coverage_kernel<false>;
+        if (lds > 48 * 1024) {
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+        }
+        int per_cu = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FEED_G * WAVE, lds);
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+        per_cu = std::max(1, std::min(per_cu, 16 / FEED_G));
+        const int grid = (int)std::min<size_t>(items.size(), (size_t)ctx->n_cu * per_cu);
+        void *kargs[] = {(void *)&a};
+        e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(FEED_G * WAVE), kargs, lds, s);
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+    }
+    (void)hipEventRecord(ctx->hist1[slot], s);
+    ctx->n_calls++;
+    e = hipGetLastError();
+    if (e == hipSuccess && where == GARLIC_HOST)
+        e = hipMemcpyAsync(inwin, dst, sizeof(int16_t) * (size_t)Lo.total, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+    p->plan.valid = false;
     return done(GARLIC_OK);
 }
 

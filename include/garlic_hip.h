@@ -42,8 +42,9 @@ extern "C" {
  *    empty (sub_idx != NULL, n_sub = 0); garlic_lod_feed_subset
  * 4: garlic_device_alloc / garlic_device_free (score matrices), garlic_panel_chain_kind
  * 5: garlic_lod_feed_multi (the feeds of several window sizes in one call); garlic_panel_alloc_scores,
- *    garlic_device_alloc_stats, garlic_device_trim */
-#define GARLIC_HIP_ABI_VERSION 5
+ *    garlic_device_alloc_stats, garlic_device_trim
+ * 6: garlic_roh_coverage_fused (coverage counts without the score matrix) */
+#define GARLIC_HIP_ABI_VERSION 6
 
 #define GARLIC_OK 0
 #define GARLIC_ERR_INVALID 1  /* bad argument (e.g. winsize <= 1: src/garlic-cli.cpp:433-442) */
@@ -290,6 +291,16 @@ int garlic_lod_feed_multi(garlic_panel *panel, const int32_t *winsizes, const in
 int garlic_roh_coverage(garlic_panel *panel, const double *scores, int32_t pitch_align, int32_t nind_out,
                         int32_t winsize, double cutoff, int16_t *inwin, int32_t inwin_pitch_align,
                         int32_t where);
+
+/* The same counts for the unweighted --error scores of every individual of the panel, computed WITHOUT the scores:
+ * calcLOD's chain (src/garlic-roh.cpp:18-132) and the inWin[] loop (:446-454) in one kernel -- a window's score lives
+ * in a register, becomes one bit per individual, and the count is a sliding sum over the last winsize bits.  What
+ * GARLIC's final pass needs when --raw-lod is not asked for: 2 bytes per window leave the device and no score matrix
+ * is resident.  inwin as for garlic_roh_coverage (inwin_pitch_align a multiple of 8 lets the kernel store 16 bytes
+ * at a time).  Falls back to scores + garlic_roh_coverage where the fused kernel does not apply (cutoff <= -9999,
+ * winsize > 1024, non-finite terms, window sums that can be -9999.0). */
+int garlic_roh_coverage_fused(garlic_panel *panel, int32_t winsize, double error, int32_t max_gap, double cutoff,
+                              int16_t *inwin, int32_t inwin_pitch_align, int32_t where);
 
 /* Introspection used by tests and the bench (device work of the last garlic_*_windows call). */
 typedef struct garlic_call_stats {

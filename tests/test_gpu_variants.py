@@ -228,6 +228,29 @@ def test_roh_coverage_counts_on_device(gpu_ctx, W):
                 assert np.array_equal(got[c], want), (W, cutoff, c)
 
 
+@pytest.mark.parametrize("W", [2, 30, 100, 250])
+def test_roh_coverage_fused_equals_oracle_scores_then_counts(gpu_ctx, W):
+    """garlic_roh_coverage_fused: chain + compare + sliding count in one kernel, no score matrix -- against the oracle's
+    scores run through the oracle's inWin[] loop; gaps and centromeres (runs a window apart), chromosomes shorter
+    than the window and around the 32-window tiles, ragged individual counts, dense and 16-byte-aligned rows, and
+    the cases that fall back to scores + garlic_roh_coverage (cutoff below MISSING)"""
+    rng = np.random.default_rng(170 + W)
+    mg = 200000
+    sizes = [5000, 1, max(1, W - 1), W, W + 3, 31, 32, 33, 2048 + W]
+    for nind in (1, 37, 130):
+        chroms = [ol.random_panel(rng, n, nind, max_gap=mg, gaps=3 if n > 1000 else 0) for n in sizes]
+        with abi.Panel(gpu_ctx, sizes, nind) as panel:
+            panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms])
+            panel.set_freq(np.concatenate([c[1] for c in chroms]))
+            panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+            scores = [ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg) for (g, f, p, cs, ce) in chroms]
+            for cutoff, align in ((0.0, 1), (-2.5, 8), (3.0, 32), (-10000.0, 8)):
+                got = panel.roh_coverage_fused(W, 0.001, mg, cutoff, pitch_align=align)
+                for c, n in enumerate(sizes):
+                    want = ol.oracle_roh_coverage(np.ascontiguousarray(scores[c]), W, cutoff)
+                    assert np.array_equal(got[c][:, :n], want), (W, nind, cutoff, align, c)
+
+
 def test_lod_feed_one_call(gpu_ctx):
     """garlic_lod_feed = scores + convertWinData2DoubleData on the device, unweighted / TGLS / wLOD"""
     rng = np.random.default_rng(21)

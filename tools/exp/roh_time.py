@@ -22,3 +22,20 @@ for rep in range(3):
     ctx.synchronize(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"roh_coverage device->device: {dt*1e3:.2f} ms  ({total*8/dt/1e12:.2f} TB/s of scores read)")
+# the same counts without the score matrix (garlic_roh_coverage_fused): chain + compare + sliding count in one kernel
+b8, p8, t8 = panel.out_layout(8, nind)
+cov8 = torch.empty(t8, dtype=torch.int16, device=dev)
+for rep in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    panel.roh_coverage_fused_device(W, 0.001, 200000, 2.5, cov8.data_ptr(), pitch_align=8)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"roh_coverage_fused (no scores): {dt*1e3:.2f} ms call, kernel {ctx.recent_kernel_ms(1)[0]:.2f} ms  ({nloci*nind/dt/1e9:.0f} G windows/s)")
+a = cov.view(torch.int16)
+ok = True
+for c in range(len(b1)):
+    n = spec.chr_nloci[c]
+    x = cov[b1[c]: b1[c] + nind * p1[c]].view(nind, p1[c])[:, :n]
+    y = cov8[b8[c]: b8[c] + nind * p8[c]].view(nind, p8[c])[:, :n]
+    ok = ok and bool(torch.equal(x, y))
+print("fused == scores-then-counts:", ok)
