@@ -69,6 +69,16 @@ def soak(ctx, trials, seed, verbose=True):
             if [len(w) for w in want] != list(per_chr) or not ol.bits_equal(feed, np.concatenate(want) if want else feed):
                 fails += 1
                 print("FAIL feed", step, tag)
+            # coverage counts without the score matrix (garlic_roh_coverage_fused) against the oracle's inWin[] of the
+            # oracle's scores; dense and 16-byte-aligned rows
+            cut = float(rng.choice([-3.0, 0.0, 1.5]))
+            pa = int(rng.choice([1, 8]))
+            cov = panel.roh_coverage_fused(W, err, mg, cut, pitch_align=pa)
+            for c in range(nchr):
+                checks += 1
+                if not np.array_equal(cov[c][:, :sizes[c]], ol.oracle_roh_coverage(np.ascontiguousarray(lod[c]), W, cut)):
+                    fails += 1
+                    print("FAIL fused coverage", cut, pa, c, tag)
             # the subset feed (--kde-subsample): drawn individuals in drawn order
             if nind > 1:
                 idx = rng.choice(nind, size=int(rng.integers(1, min(nind, 40) + 1)), replace=False).astype(np.int32)
