@@ -10,8 +10,9 @@
 // chip instead of 8 B out + 8 B in again + 2 B out (garlic_lod_windows + garlic_roh_coverage), and no score matrix
 // (100 GB at 10M SNPs x 1250 individuals) has to be resident.
 //
-//   bits     a wave's ballot masks (bit = individual) of the last W windows live in a ring in LDS of the wave's own;
-//            the window leaving the count is read back W steps later (uniform address: one broadcast read);
+//   bits     32 <= W <= 224: the lane's own bits of the last 256 windows in eight registers (lod_coverage_kernel<true>,
+//            below); other sizes: the wave's ballot masks (bit = individual) of the last W windows in an LDS ring of
+//            the wave's own, the window leaving the count read back W steps later (one broadcast read);
 //   counts   32 per tile and lane, packed two per dword, stored as four 16-byte pieces of the lane's row when the
 //            layout allows (pitch_align a multiple of 8, interior tiles), one by one otherwise;
 //   range    a run [a, b] of scored windows covers the SNPs a .. b + W - 1; runs are at least W - 1 windows apart

@@ -2973,7 +2973,6 @@ int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, in
         e = hipMemcpyAsync(inwin, dst, sizeof(int16_t) * (size_t)Lo.total, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
-    p->plan.valid = false;
     return done(GARLIC_OK);
 }
 
