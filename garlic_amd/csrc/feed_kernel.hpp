@@ -60,6 +60,10 @@ struct FeedArgs {
     int32_t use_asm;          // 0: every tile through the compiler-generated path (GARLIC_FEED_NO_ASM)
     int32_t *next_item;       // [0] queue head, [1] workgroups that have left (zero at launch, reset by the last)
     int64_t *trace;           // optional (GARLIC_TRACE): per item {workgroup, begin, tiles begin, end} in 100 MHz ticks + shader clocks
+    // lod_bits_kernel only: instead of sampled scores ONE BIT per window and individual, score >= cutoff, 32 windows
+    // (a tile) per dword: `out` is then a uint32 matrix, chrs[].out_base / out_pitch in dwords, row = individual,
+    // column = chromosome-local tile index (locus / 32); zeroed by the caller (edge tiles OR their bits in)
+    double cutoff;
 };
 
 __device__ __forceinline__ void feed_barrier()
@@ -102,8 +106,8 @@ __device__ __forceinline__ double feed_lds_double(uint32_t addr)
     return *reinterpret_cast<const __attribute__((address_space(3))) double *>((uintptr_t)addr);
 }
 
-__global__ void __launch_bounds__(FEED_G * WAVE, 4)
-lod_feed_kernel(FeedArgs p)
+template <bool BITS>
+__device__ __forceinline__ void lod_feed_body(const FeedArgs &p)
 {
     // one LDS object at offset 0: the hand-scheduled loop addresses the rings with absolute offsets
     __shared__ __attribute__((aligned(1024))) unsigned char smem[GARLIC_FEED_LDS_TOTAL];
@@ -211,6 +215,24 @@ lod_feed_kernel(FeedArgs p)
                 const uint32_t *ptw = blk + ((Gtrail + TILE) >> 4) * WAVE;
                 const double *out_next = out_chr + col;
                 uint32_t next_rel = (uint32_t)(next - s0);
+                if (BITS) {
+                    // the dword of tile 1 in row 0 of the bit matrix; rows are out_pitch dwords apart
+                    const uint32_t *bits_next = reinterpret_cast<const uint32_t *>(p.out) + c.out_base + (s0 >> 5);
+                    const uint32_t *bits_out;
+                    const uint64_t cutbits = __builtin_bit_cast(uint64_t, p.cutoff);
+                    const uint64_t cut = ((uint64_t)feed_uni((uint32_t)(cutbits >> 32)) << 32) | feed_uni((uint32_t)cutbits);
+                    asm volatile(GARLIC_FEED_BITS_LOOP_ASM
+                                 : [acc] "+v"(acc), [next_out] "=s"(next_rel), [out_out] "=s"(bits_out)
+                                 : [wave] "s"(wave), [lane] "v"(lane), [active] "s"(feed_uni(active ? 1u : 0u)), [plw] "s"(feed_uni(plw)),
+                                   [ptw] "s"(feed_uni(ptw)), [ptl] "s"(feed_uni(lead_chunks + 128)), [ptt] "s"(feed_uni(trail_chunks + 128)),
+                                   [out] "s"(feed_uni(bits_next)), [next] "s"(feed_uni(next_rel)), [step] "s"(feed_uni((uint32_t)step)),
+                                   [shl] "s"(feed_uni((uint32_t)sh_lead)), [sht] "s"(feed_uni((uint32_t)sh_trail)),
+                                   [row] "v"(row), [pitch8] "s"(feed_uni((uint32_t)(c.out_pitch * 4))),
+                                   [niter] "s"(feed_uni((uint32_t)niter)), [cut] "s"(cut)
+                                 : GARLIC_FEED_LOOP_CLOBBERS);
+                    k += 4 * niter;
+                    if (k >= ntiles) break;
+                } else {
                 asm volatile(GARLIC_FEED_LOOP_ASM
                              : [acc] "+v"(acc), [next_out] "=s"(next_rel), [out_out] "=s"(out_next)
                              : [wave] "s"(wave), [lane] "v"(lane), [active] "s"(feed_uni(active ? 1u : 0u)), [plw] "s"(feed_uni(plw)),
@@ -224,6 +246,7 @@ lod_feed_kernel(FeedArgs p)
                 next = first + k * TILE + (int)next_rel;
                 col = (int)(out_next - out_chr);
                 if (k >= ntiles) break;
+                }
             }
             feed_barrier();   // every wave is done with tile k-1; the chunks of tiles <= k + 2 have landed
             {
@@ -241,6 +264,7 @@ lod_feed_kernel(FeedArgs p)
                 const uint32_t trail_w[2] = {__builtin_amdgcn_alignbit(t1, t0, sh_trail), __builtin_amdgcn_alignbit(t2, t1, sh_trail)};
                 const uint32_t lead_rows = lds0 + GARLIC_FEED_LDS_LEAD + (uint32_t)((k + 3) & 3) * 1024u;
                 const uint32_t trail_rows = lds0 + GARLIC_FEED_LDS_TRAIL + (uint32_t)((k + 3) & 3) * 1024u;
+                uint32_t tile_bits = 0;
 #pragma unroll
                 for (int bq = 0; bq < 4; bq++) {
                     double tin[8], tout[8];
@@ -258,13 +282,18 @@ lod_feed_kernel(FeedArgs p)
                         const double to = (s > a && s <= b) ? tout[i] : 0.0;
                         const double ti = (s >= a && s <= b) ? tin[i] : 0.0;
                         acc = (acc - to) + ti;   // two roundings, as garlic-roh.cpp:98-100
-                        if (s == next && s <= b) {
+                        if (BITS) {
+                            if (s >= a && s <= b && acc >= p.cutoff) tile_bits |= 1u << (8 * bq + i);      // NaN >= x is false
+                        } else if (s == next && s <= b) {
                             if (row >= 0) out_chr[(int64_t)row * c.out_pitch + col] = acc;
                             col++;
                             next += step;
                         }
                     }
                 }
+                // (a tile at a run's edge may hold another run's windows too when W < 32: OR, into the zeroed matrix)
+                if (BITS && row >= 0 && tile_bits)
+                    atomicOr(reinterpret_cast<uint32_t *>(p.out) + c.out_base + (int64_t)row * c.out_pitch + (s0 >> 5), tile_bits);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's quarters of the chunks of tile k + 3
         }
@@ -275,6 +304,20 @@ lod_feed_kernel(FeedArgs p)
         }
         __builtin_amdgcn_s_setprio(0);
     }
+}
+
+__global__ void __launch_bounds__(FEED_G * WAVE, 4)
+lod_feed_kernel(FeedArgs p)
+{
+    lod_feed_body<false>(p);
+}
+
+// the same chains leaving one bit per window and individual (score >= cutoff) instead of sampled scores: the first
+// half of the coverage counts without a score matrix (coverage_kernel.hpp)
+__global__ void __launch_bounds__(FEED_G * WAVE, 4)
+lod_bits_kernel(FeedArgs p)
+{
+    lod_feed_body<true>(p);
 }
 
 } // namespace garlic

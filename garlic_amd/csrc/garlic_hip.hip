@@ -2872,6 +2872,7 @@ int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, in
     if (!p || !inwin) return fail(GARLIC_ERR_INVALID, "panel and inwin are required");
     if (winsize <= 1 || inwin_pitch_align < 1) return fail(GARLIC_ERR_INVALID, "winsize must be > 1, inwin_pitch_align >= 1");
     if (winsize > 32767) return fail(GARLIC_ERR_INVALID, "coverage counts are 16-bit: winsize <= 32767");
+    if (p->nind > 65535) return fail(GARLIC_ERR_INVALID, "coverage: at most 65535 individuals per call");
     garlic_ctx *ctx = p->ctx;
     int rc;
     if ((rc = set_device(ctx))) return rc;
@@ -2943,6 +2944,55 @@ int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, in
     bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
     for (int c = 0; c < p->nchr; c++) vec_ok = vec_ok && Lo.base[c] % 8 == 0 && Lo.pitch[c] % 8 == 0;
     const int slot = (int)(ctx->n_calls % garlic_ctx::HIST);
+    if (!getenv("GARLIC_COVERAGE_ONE_KERNEL")) {
+        // two kernels: one bit per window and individual from the hand-scheduled chain (lod_bits_kernel), then the
+        // sliding counts from the bits (cov_counts_from_bits_kernel): a 64th of the score bytes in between
+        std::vector<ChrDev> bchrs((size_t)p->nchr);
+        std::vector<int32_t> word_base((size_t)p->nchr + 1, 0);
+        int64_t boff = 0;
+        for (int c = 0; c < p->nchr; c++) {
+            const int64_t words = (p->chr_nloci[c] + 31) / 32;
+            bchrs[(size_t)c] = ChrDev{p->chr_off[c], boff, words, p->chr_nloci[c], 0};
+            boff += words * p->nind;
+            word_base[(size_t)c + 1] = word_base[(size_t)c] + (int32_t)words;
+            if (words * 4 * (int64_t)p->nind >= (int64_t)1 << 32)
+                return done(fail(GARLIC_ERR_INVALID, "chromosome %d: bit rows beyond 32-bit offsets", c));
+        }
+        DevBuf<uint32_t> d_bits;
+        DevBuf<ChrDev> d_bchrs;
+        DevBuf<int32_t> d_wbase;
+        auto done2 = [&](int code) { d_bits.release(); d_bchrs.release(); d_wbase.release(); return done(code); };
+        if ((rc = d_bits.reserve((size_t)std::max<int64_t>(boff, 1))) || (rc = d_bchrs.reserve(bchrs.size())) ||
+            (rc = d_wbase.reserve(word_base.size())))
+            return done2(rc);
+        e = hipMemcpyAsync(d_bchrs.p, bchrs.data(), sizeof(ChrDev) * bchrs.size(), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_wbase.p, word_base.data(), sizeof(int32_t) * word_base.size(), hipMemcpyHostToDevice, s);
+        (void)hipEventRecord(ctx->hist0[slot], s);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bits.p, 0, sizeof(uint32_t) * (size_t)boff, s);
+        if (e != hipSuccess) return done2(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+        if (!items.empty()) {
+            FeedArgs f{p->d_packed.p, p->d_tab.p, d_items.p, d_bchrs.p, reinterpret_cast<double *>(d_bits.p), nullptr, p->nwordrows, 0,
+                       p->nind, W, (int32_t)items.size(), 1, getenv("GARLIC_FEED_NO_ASM") ? 0 : 1, d_counter.p, nullptr, cutoff};
+            int per_cu = 0;
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)lod_bits_kernel, FEED_G * WAVE, 0);
+            if (e != hipSuccess) return done2(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+            per_cu = std::max(1, std::min(per_cu, 16 / FEED_G));
+            const int grid = (int)std::min<size_t>(items.size(), (size_t)ctx->n_cu * per_cu);
+            void *kargs[] = {(void *)&f};
+            e = hipLaunchKernel((const void *)lod_bits_kernel, dim3((unsigned)grid), dim3(FEED_G * WAVE), kargs, 0, s);
+            if (e != hipSuccess) return done2(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+        }
+        hipLaunchKernelGGL(cov_counts_from_bits_kernel, dim3((unsigned)((word_base[(size_t)p->nchr] + 255) / 256), (unsigned)p->nind),
+                           dim3(256), 0, s, d_bits.p, d_bchrs.p, d_chrs.p, d_wbase.p, p->nchr, W, vec_ok ? 1 : 0, dst);
+        (void)hipEventRecord(ctx->hist1[slot], s);
+        ctx->n_calls++;
+        e = hipGetLastError();
+        if (e == hipSuccess && where == GARLIC_HOST)
+            e = hipMemcpyAsync(inwin, dst, sizeof(int16_t) * (size_t)Lo.total, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return done2(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+        return done2(GARLIC_OK);
+    }
     (void)hipEventRecord(ctx->hist0[slot], s);
     if (!ranges.empty())
         hipLaunchKernelGGL(fill_i16_ranges_kernel, dim3((unsigned)ranges.size(), (unsigned)std::min(p->nind, 1024)), dim3(256), 0, s,

@@ -76,7 +76,12 @@ S_W256 = 55             # wave * 256
 S_TMP = 56
 S_IDX = 57
 S_MASK, S_EXEC = 58, 60   # lanes that have a row in the sample matrix; saved exec
-CLOBBER_S = list(range(40, 62))
+S_CUT = 62              # bits variant: the LOD cutoff (2 registers)
+CLOBBER_S = list(range(40, 64))
+# bits variant (GARLIC_FEED_BITS_LOOP_ASM): instead of sampled scores the loop leaves ONE BIT per window and lane --
+# score >= cutoff -- 32 of them per tile in V_S, stored as one dword per lane and tile; V_S + 1 holds zero, the
+# window's bit goes from VCC into the dword by an add-with-carry
+V_BITS, V_ZERO = V_S, V_S + 1
 
 MASK = "0x18181818"
 
@@ -84,10 +89,11 @@ MASK = "0x18181818"
 class Gen:
     """instruction list + a model of the in-order LGKM counter (LDS reads only)"""
 
-    def __init__(self):
+    def __init__(self, bits=False):
         self.out = []
         self.issued = 0
         self.complete = 0
+        self.bits = bits
 
     def emit(self, s):
         self.out.append(s)
@@ -203,6 +209,18 @@ def gen_capture(g_, u, b):
     e(f"s_branch CAPRET_{u}_{b}_%=")
 
 
+def gen_bits(g_, b):
+    """bits variant, batch b (windows 8b .. 8b+7 of the tile, accumulators in V_ACC): the compare (cutoff <= score; false
+    for a NaN) leaves the window's bit in VCC, and an add-with-carry shifts it into the tile's dword,
+    bits = 2 * bits + carry: two instructions per window.  The first window comes out on top: gen_tile reverses the
+    dword (v_bfrev_b32) before it is stored."""
+    e = g_.emit
+    for j in range(8):
+        e(f"v_cmp_le_f64_e32 vcc, s[{S_CUT}:{S_CUT + 1}], {pair(V_ACC + 2 * j)}")
+        src = V_ZERO if (b == 0 and j == 0) else V_BITS      # the tile's first window starts the dword
+        e(f"v_addc_co_u32_e32 v{V_BITS}, vcc, v{src}, v{src}, vcc")
+
+
 def gen_tile(g_, u):
     """tile t = 4 i + u of the loop"""
     e = g_.emit
@@ -252,13 +270,24 @@ def gen_tile(g_, u):
         gen_C(g_, g, (0, 1))
         r_prev = gen_R(g_, u, g + 1, (2, 3))
         gen_C(g_, g, (2, 3))
-        if g % 2 == 1 and "nocapture" not in ABL:
+        if g % 2 == 1 and g_.bits:
+            gen_bits(g_, g // 2)
+        elif g % 2 == 1 and "nocapture" not in ABL:
             b = g // 2
             e(f"s_sub_u32 s{S_NEXT}, s{S_NEXT}, 8")          # borrow: a sampled locus among the batch's 8 windows
             e(f"s_cbranch_scc1 CAP_{u}_{b}_%=")
             e(f"CAPRET_{u}_{b}_%=:")
     # ---- everything requested during tile t-1 has landed: genotype words of tile t+1, chunks of tile t+2
     nreq = (0 if "nodma" in ABL else 2) + (0 if "nowords" in ABL else 4)
+    if g_.bits:
+        # the tile's 32 bits: one dword per lane (individuals without a row are masked out); it stays in flight too
+        e(f"v_bfrev_b32_e32 v{V_BITS}, v{V_BITS}")
+        e(f"s_mov_b64 exec, s[{S_MASK}:{S_MASK + 1}]")
+        e(f"global_store_dword v{V_STOFF}, v{V_BITS}, s[{S_OUT}:{S_OUT + 1}]")
+        e(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
+        e(f"s_add_u32 s{S_OUT}, s{S_OUT}, 4")
+        e(f"s_addc_u32 s{S_OUT + 1}, s{S_OUT + 1}, 0")
+        nreq += 1
     e(f"s_waitcnt vmcnt({nreq})")
 
 
@@ -285,8 +314,8 @@ def bump(e, ptr, n):
     e(f"s_addc_u32 s{ptr + 1}, s{ptr + 1}, 0")
 
 
-def gen_all():
-    g_ = Gen()
+def gen_all(bits=False):
+    g_ = Gen(bits)
     e = g_.emit
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     e(f"s_mov_b64 s[{S_PTL}:{S_PTL + 1}], %[ptl]")
@@ -310,6 +339,9 @@ def gen_all():
     e(f"s_mov_b64 s[{S_EXEC}:{S_EXEC + 1}], exec")
     e(f"v_cmp_le_i32_e64 s[{S_MASK}:{S_MASK + 1}], 0, %[row]")     # lanes with a row in the sample matrix
     e(f"v_mul_lo_u32 v{V_STOFF}, %[row], %[pitch8]")
+    if bits:
+        e(f"s_mov_b64 s[{S_CUT}:{S_CUT + 1}], %[cut]")
+        e(f"v_mov_b32_e32 v{V_ZERO}, 0")
     e(f"v_mov_b64 {pair(V_ACC + 14)}, %[acc]")
     # words 0..6 of both streams (tile t funnel-shifts words 2t .. 2t + 3); the loop loads from word 7 on
     for ring, ptr in ((V_WL, S_PLW), (V_WT, S_PTW)):
@@ -339,7 +371,7 @@ def gen_all():
     e(f"s_mov_b32 %[next_out], s{S_NEXT}")
     e(f"s_mov_b64 %[out_out], s[{S_OUT}:{S_OUT + 1}]")
     e("s_branch DONE_%=")
-    if "nocapture" not in ABL:
+    if "nocapture" not in ABL and not bits:
         for u in range(4):
             for b in range(4):
                 gen_capture(g_, u, b)
@@ -357,6 +389,7 @@ def gen_all():
 
 def main():
     lines = gen_all()
+    bits_lines = gen_all(bits=True)
     here = os.path.dirname(os.path.abspath(__file__))
     path = os.path.join(os.environ.get("GARLIC_GEN_OUT") or os.path.join(here, "..", "garlic_amd", "csrc"), "feed_loop_gfx950.inc")
     with open(path, "w") as f:
@@ -368,6 +401,11 @@ def main():
         f.write(f"#define GARLIC_FEED_AHEAD {AHEAD}\n")
         f.write("#define GARLIC_FEED_LOOP_ASM \\\n")
         for ln in lines:
+            f.write('    "%s\\n\\t" \\\n' % ln)
+        f.write('    ""\n')
+        f.write("// the same loop leaving one bit per window and lane (score >= cutoff) instead of sampled scores\n")
+        f.write("#define GARLIC_FEED_BITS_LOOP_ASM \\\n")
+        for ln in bits_lines:
             f.write('    "%s\\n\\t" \\\n' % ln)
         f.write('    ""\n')
         f.write("#define GARLIC_FEED_LOOP_CLOBBERS \\\n    ")
