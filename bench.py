@@ -326,8 +326,8 @@ def leg_ns(ctx, dev, steps):
                            "roofline": hbm_roofline("roh_coverage_kernel", 10.0 * win, tcv * 1e3,
                                                     note="10 B per window (8 B score in, 2 B count out); timed as the whole synchronous "
                                                          "call (wall clock, best of 3): kernel + two small uploads")}
-    # ... and the same counts WITHOUT the scores (garlic_roh_coverage_fused: chain + compare + sliding count in one kernel,
-    # 2 B per window leave the chip, no score matrix resident) -- what GARLIC's final pass needs when --raw-lod is not asked for
+    # ... and the same counts WITHOUT the scores (garlic_roh_coverage_fused: the chain leaves one bit per window, a second
+    # kernel counts the bits; 2 B per window leave the chip, no score matrix resident) -- what GARLIC's final pass needs when --raw-lod is not asked for
     _, _, tcov8 = panel.out_layout(8, nind)
     cov8 = torch.empty(tcov8, dtype=torch.int16, device=dev)
     torch.cuda.synchronize()
@@ -347,10 +347,12 @@ def leg_ns(ctx, dev, steps):
     res["roh_coverage_fused"] = {"call_ms": tfu * 1e3, "sliding_windows_per_s": win / tfu,
                                  "scores_then_counts_ms": res["lod"]["kernel_ms"] + tcv * 1e3,
                                  "equals_scores_then_counts": same,
-                                 "roofline": hbm_roofline("lod_coverage_kernel", 2.25 * win, tfu * 1e3,
-                                                          note="2.25 B per window (0.25 B genotype in, 2 B count out): not an HBM-bound kernel -- "
-                                                               "the sequential chain of the longest run, ~18 instructions per window on one "
-                                                               "wave, is its critical path; no 8 B per window of scores written, read or resident")}
+                                 "roofline": hbm_roofline("lod_bits_kernel + cov_counts_from_bits_kernel", 2.5 * win, tfu * 1e3,
+                                                          note="2.5 B per window (0.25 B genotype in, 1 bit out and in again, 2 B count out): not HBM-bound -- "
+                                                               "the first kernel is the hand-scheduled chain of the thinned feed with a compare and an "
+                                                               "add-with-carry per window (10.1 instructions per window on the longest run's wave), the "
+                                                               "second a plain pass over the bits; no 8 B per window of scores written, read or resident; "
+                                                               "timed as the whole call (wall clock incl. its scratch allocations)")}
     del cov, evs, cov8
     torch.cuda.empty_cache()      # 25 GB of counts: the likelihood legs below need the room
     # LD weights: integer pair counts (AND + popcount on bit planes) + W^2 ordered FP64 adds per window start

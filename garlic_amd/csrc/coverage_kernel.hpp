@@ -3,6 +3,8 @@
 //
 //   inWin[l] = #{ windows w in (l - W, l] of this individual with score >= cutoff }
 //
+// (The shipped path is the pair of kernels at the END of this file -- lod_bits_kernel of feed_kernel.hpp + the counts
+// from its bits --; the one-kernel forms below are what led there and stay selectable: GARLIC_COVERAGE_ONE_KERNEL.)
 // GARLIC's final pass computes every window score of the chosen size (8 B per window), keeps them, and counts.  Here
 // the scores never exist in memory: the chain of lod_feed_kernel (every wave a chain of its own, lane = individual,
 // term rows through LDS rings, feed_kernel.hpp) produces a window's score in a register, one compare and a ballot

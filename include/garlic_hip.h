@@ -293,8 +293,8 @@ int garlic_roh_coverage(garlic_panel *panel, const double *scores, int32_t pitch
                         int32_t where);
 
 /* The same counts for the unweighted --error scores of every individual of the panel, computed WITHOUT the scores:
- * calcLOD's chain (src/garlic-roh.cpp:18-132) and the inWin[] loop (:446-454) in one kernel -- a window's score lives
- * in a register, becomes one bit per individual, and the count is a sliding sum over the last winsize bits.  What
+ * calcLOD's chain (src/garlic-roh.cpp:18-132) leaves one bit per window and individual -- score >= cutoff, the score
+ * itself only ever in a register -- and the inWin[] loop (:446-454) becomes a count over the last winsize bits.  What
  * GARLIC's final pass needs when --raw-lod is not asked for: 2 bytes per window leave the device and no score matrix
  * is resident.  inwin as for garlic_roh_coverage (inwin_pitch_align a multiple of 8 lets the kernel store 16 bytes
  * at a time).  Falls back to scores + garlic_roh_coverage where the fused kernel does not apply (cutoff <= -9999,
