@@ -385,6 +385,22 @@ def leg_ns(ctx, dev, steps):
                          torch.cuda.synchronize)
     clk = clock_under_load(lambda: panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU), torch.cuda.synchronize)
     res["wlod"] = dict(rate(k, dt), roofline=fp64_roofline("wlod_tile2_kernel", win, W, k, clock=clk))
+    # the weighted final pass without its score matrix: the same kernel leaves 16 bits per individual and group instead of
+    # 16 scores (garlic_roh_coverage_fused, weighted), then the counts from the bits
+    cov8 = torch.empty(tcov8, dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    panel.roh_coverage_fused_device(W, ERROR, MAX_GAP, 2.5, cov8.data_ptr(), pitch_align=8, weighted=True, M=M_GEN, mu=MU)
+    tw = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        panel.roh_coverage_fused_device(W, ERROR, MAX_GAP, 2.5, cov8.data_ptr(), pitch_align=8, weighted=True, M=M_GEN, mu=MU)
+        tw.append(time.perf_counter() - t0)
+    res["wlod_coverage_fused"] = {"call_ms": float(np.min(tw)) * 1e3, "scores_then_counts_ms": k + tcv * 1e3,
+                                  "note": "wlod_tile2_kernel writing coverage bits (2 B per individual and 16 windows) + "
+                                          "cov_counts_from_bits_kernel, against the score pass + roh_coverage_kernel"}
+    del cov8
+    torch.cuda.empty_cache()
     panel.release_scratch()
     dt, k = timed_passes(ctx, lambda: panel.lod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, use_gl=True), steps, 1,
                          torch.cuda.synchronize)

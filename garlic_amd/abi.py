@@ -107,7 +107,8 @@ def lib():
                                   C.c_double, C.c_int32, _vp, C.c_int64, _i64p, _i64p]
     L.garlic_roh_coverage.argtypes = [_vp, _vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, _vp, C.c_int32,
                                       C.c_int32]
-    L.garlic_roh_coverage_fused.argtypes = [_vp, C.c_int32, C.c_double, C.c_int32, C.c_double, _vp, C.c_int32, C.c_int32]
+    L.garlic_roh_coverage_fused.argtypes = [_vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                            C.c_double, _vp, C.c_int32, C.c_int32]
     L.garlic_lod_feed_subset.argtypes = [_vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_double, C.c_int32, _i32p, C.c_int32, _vp, C.c_int64, _i64p, _i64p]
     L.garlic_lod_feed_multi.argtypes = [_vp, _i32p, _i32p, C.c_int32, C.c_double, C.c_int32, _i32p, C.c_int32,
@@ -518,18 +519,20 @@ class Panel:
         return [out[base[c]: base[c] + nind_out * pitch[c]].reshape(nind_out, pitch[c])
                 for c in range(self.nchr)]
 
-    def roh_coverage_fused(self, winsize, error, max_gap, cutoff, pitch_align=1):
-        """coverage counts of the unweighted scores without computing the score matrix: list of per-chromosome int16
-        [nind][pitch_c] host arrays (pitch_c = nloci_c rounded up to pitch_align)"""
+    def roh_coverage_fused(self, winsize, error, max_gap, cutoff, pitch_align=1, use_gl=False, weighted=False, M=7, mu=1e-9):
+        """coverage counts without computing the score matrix (unweighted --error scores, or --weighted with or without
+        likelihoods): list of per-chromosome int16 [nind][pitch_c] host arrays (pitch_c = nloci_c rounded up to pitch_align)"""
         base, pitch, total = self.out_layout(pitch_align, self.nind)
         out = np.empty(total, dtype=np.int16)
-        check(lib().garlic_roh_coverage_fused(self.handle, winsize, error, max_gap, cutoff, _vp(out.ctypes.data),
-                                              pitch_align, HOST))
+        check(lib().garlic_roh_coverage_fused(self.handle, winsize, error, max_gap, int(use_gl), int(weighted), M, mu, cutoff,
+                                              _vp(out.ctypes.data), pitch_align, HOST))
         return [out[base[c]: base[c] + self.nind * pitch[c]].reshape(self.nind, pitch[c]) for c in range(self.nchr)]
 
-    def roh_coverage_fused_device(self, winsize, error, max_gap, cutoff, out_ptr, pitch_align=8):
+    def roh_coverage_fused_device(self, winsize, error, max_gap, cutoff, out_ptr, pitch_align=8, use_gl=False, weighted=False,
+                                  M=7, mu=1e-9):
         """the same counts into device memory (int16 rows: out_layout(pitch_align, nind))"""
-        check(lib().garlic_roh_coverage_fused(self.handle, winsize, error, max_gap, cutoff, _vp(out_ptr), pitch_align, DEVICE))
+        check(lib().garlic_roh_coverage_fused(self.handle, winsize, error, max_gap, int(use_gl), int(weighted), M, mu, cutoff,
+                                              _vp(out_ptr), pitch_align, DEVICE))
 
     def roh_coverage_device(self, scores_ptr, winsize, cutoff, out_ptr, pitch_align=32, nind_out=None):
         """the same counts into device memory (int16, dense rows: out_layout(1, nind_out))"""

@@ -211,6 +211,7 @@ struct garlic_panel {
     DevBuf<double> d_rld, d_decay, d_stage64;
     DevBuf<uint64_t> d_phase;                      // HapData::firstCopy as bit planes [blk][nloci] (--phased LD)
     uint64_t geno_epoch = 0;                       // bumped by every genotype upload (LD plane cache)
+    CovBits cov_pending{nullptr, nullptr, 0.0};    // set by garlic_roh_coverage_fused around a weighted score call: bits, not scores
     bool have_phase = false;
     // scratch of the LD-weight kernels, kept between calls (window-size sweeps): at 10M SNPs the six
     // 8-GB allocations and frees of a call cost 9x its kernels.  garlic_panel_release_scratch drops it.
@@ -1106,7 +1107,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     if (mode == MODE_WLOD && !wlod_fast && (rc = ensure_rld(p))) return rc;
     // narrow windows, plain scores: the streaming kernel (wlod_small_kernel.hpp) reads the plain reciprocals, a window's
     // W weights contiguous
-    const bool wlod_stream = wlod_fast && wlod_small && !wlod_gl && !getenv("GARLIC_WLOD_SMALL_TILES");
+    const bool wlod_stream = wlod_fast && wlod_small && !wlod_gl && !p->cov_pending.bits && !getenv("GARLIC_WLOD_SMALL_TILES");
+    if (p->cov_pending.bits && !wlod_fast) return fail(GARLIC_ERR_STATE, "internal: coverage bits need the tuned wLOD kernels");
     if (wlod_stream && (rc = ensure_rld(p))) return rc;
     // continuous likelihoods have no code table: the generic kernel takes its terms from the raw matrix
     if (mode == MODE_WLOD && use_gl && p->gl_cont && !wlod_fast && (rc = ensure_gl_terms(p))) return rc;
@@ -1306,7 +1308,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         const int nquad = (nblk + per_wg - 1) / per_wg;
         WlodArgs a{p->d_valid.p, p->d_chrs.p, p->d_tiles.p, p->nwordrows, p->nchr, ind_begin, ind_count, W, nquad,
                    (uint32_t)((int64_t)p->plan.n_tiles * nquad), ((wlod_gl_ring ? ring_patch : wlod_use_patch) ? 1 : 0) | (getenv("GARLIC_WLOD_NO_PF") ? 2 : 0),
-                   (int64_t)(GOFF + p->nloci + GPAD_BACK), wlod_gl_ring ? 1 : 0};
+                   (int64_t)(GOFF + p->nloci + GPAD_BACK), wlod_gl_ring ? 1 : 0, p->cov_pending};
         const uint32_t *a_packed = p->d_packed.p;
         const double *a_wtab = wlod_gl ? p->d_glterms.p : p->d_wtab.p, *a_skew = p->d_skew.p + SKEW_FRONT;
         const unsigned wl_grid = (a.n_work + 7u) / 8u * 8u;
@@ -1346,7 +1348,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
             const int n_pairs = (nblk + 1) / 2;
             WlodStripArgs sa{p->d_valid.p, p->d_chrs.p, p->d_strips.p, p->d_glterms.p, a_skew, d_out,
                              (int64_t)(GOFF + p->nloci + GPAD_BACK), ind_begin, ind_count, W, strip_waves, n_pairs,
-                             ring_patch ? 1 : 0, (uint32_t)((int64_t)p->plan.n_strips * n_pairs), p->d_counter.p + 3};
+                             ring_patch ? 1 : 0, (uint32_t)((int64_t)p->plan.n_strips * n_pairs), p->d_counter.p + 3, p->cov_pending};
             HIP_TRY(hipMemsetAsync(p->d_counter.p + 3, 0, sizeof(int32_t), ctx->stream));
             const unsigned grid = (sa.n_work + 7u) / 8u * 8u;
             const bool wide = strip_waves == WS_WAVES_WIDE;
@@ -2866,8 +2868,24 @@ int garlic_lod_feed_multi(garlic_panel *p, const int32_t *winsizes, const int32_
 // (coverage_kernel.hpp).  Where that kernel does not apply -- a cutoff at or below MISSING, terms that are not all
 // finite, a window sum that can be -9999.0, W > COVF_MAX_W -- the scores are computed into the panel's scratch and
 // counted by garlic_roh_coverage.
-int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, double cutoff,
-                              int16_t *inwin, int32_t inwin_pitch_align, int32_t where)
+static int coverage_bits_layout(garlic_panel *p, std::vector<ChrDev> &bchrs, std::vector<int32_t> &word_base, int64_t &total)
+{
+    bchrs.assign((size_t)p->nchr, ChrDev{});
+    word_base.assign((size_t)p->nchr + 1, 0);
+    total = 0;
+    for (int c = 0; c < p->nchr; c++) {
+        const int64_t words = (p->chr_nloci[c] + 31) / 32;
+        bchrs[(size_t)c] = ChrDev{p->chr_off[c], total, words, p->chr_nloci[c], 0};
+        total += words * p->nind;
+        word_base[(size_t)c + 1] = word_base[(size_t)c] + (int32_t)words;
+        if (words * 4 * (int64_t)p->nind >= (int64_t)1 << 32) return fail(GARLIC_ERR_INVALID, "chromosome %d: bit rows beyond 32-bit offsets", c);
+    }
+    return GARLIC_OK;
+}
+
+int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
+                              int32_t weighted, int32_t M, double mu, double cutoff, int16_t *inwin,
+                              int32_t inwin_pitch_align, int32_t where)
 {
     if (!p || !inwin) return fail(GARLIC_ERR_INVALID, "panel and inwin are required");
     if (winsize <= 1 || inwin_pitch_align < 1) return fail(GARLIC_ERR_INVALID, "winsize must be > 1, inwin_pitch_align >= 1");
@@ -2881,15 +2899,64 @@ int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, in
     if ((rc = ensure_segments(p, max_gap))) return rc;
     if ((rc = ensure_term_table(p, error))) return rc;
     const int32_t W = winsize;
-    const bool fused = W <= COVF_MAX_W && cutoff > MISSING_D && p->tab_all_finite && !lod_exact_needed(p, MODE_LOD, W) &&
-                       !getenv("GARLIC_COVERAGE_UNFUSED");
-    if (!fused) {
+    auto unfused = [&]() -> int {      // scores into the panel's scratch, then garlic_roh_coverage
         const Layout L = make_layout(p, 32, p->nind);
-        if ((rc = p->d_out.reserve(ctx, (size_t)L.total))) return rc;
-        if ((rc = garlic_lod_windows(p, W, error, max_gap, 0, 0, p->nind, 32, p->d_out.p, GARLIC_DEVICE))) return rc;
+        int rc2;
+        if ((rc2 = p->d_out.reserve(ctx, (size_t)L.total))) return rc2;
+        if (weighted) rc2 = garlic_wlod_windows(p, W, error, max_gap, use_gl, M, mu, 0, p->nind, 32, p->d_out.p, GARLIC_DEVICE);
+        else rc2 = garlic_lod_windows(p, W, error, max_gap, use_gl, 0, p->nind, 32, p->d_out.p, GARLIC_DEVICE);
+        if (rc2) return rc2;
         return garlic_roh_coverage(p, p->d_out.p, 32, p->nind, W, cutoff, inwin, inwin_pitch_align, where);
-    }
+    };
     hipStream_t s = ctx->stream;
+    if (weighted && cutoff > MISSING_D && !getenv("GARLIC_COVERAGE_UNFUSED")) {
+        // --weighted (with or without likelihoods): the tuned wLOD kernels leave 16 bits per individual and group instead
+        // of 16 scores (wlod_write_group), the counts come from the bits as for the unweighted scores
+        std::vector<ChrDev> bchrs;
+        std::vector<int32_t> word_base;
+        int64_t boff = 0;
+        if ((rc = coverage_bits_layout(p, bchrs, word_base, boff))) return rc;
+        const Layout Lo = make_layout(p, inwin_pitch_align, p->nind);
+        std::vector<ChrDev> ochrs((size_t)p->nchr);
+        for (int c = 0; c < p->nchr; c++) ochrs[(size_t)c] = ChrDev{p->chr_off[c], Lo.base[c], Lo.pitch[c], p->chr_nloci[c], 0};
+        DevBuf<uint32_t> d_bits;
+        DevBuf<ChrDev> d_bchrs, d_ochrs;
+        DevBuf<int32_t> d_wbase;
+        DevBuf<int16_t> d_cov;
+        auto done = [&](int code) { d_bits.release(); d_bchrs.release(); d_ochrs.release(); d_wbase.release(); d_cov.release(); return code; };
+        if ((rc = d_bits.reserve((size_t)std::max<int64_t>(boff, 4))) || (rc = d_bchrs.reserve(bchrs.size())) ||
+            (rc = d_ochrs.reserve(ochrs.size())) || (rc = d_wbase.reserve(word_base.size())))
+            return done(rc);
+        int16_t *dst = inwin;
+        if (where == GARLIC_HOST) {
+            if ((rc = d_cov.reserve((size_t)Lo.total))) return done(rc);
+            dst = d_cov.p;
+        }
+        hipError_t e = hipMemcpyAsync(d_bchrs.p, bchrs.data(), sizeof(ChrDev) * bchrs.size(), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_ochrs.p, ochrs.data(), sizeof(ChrDev) * ochrs.size(), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_wbase.p, word_base.data(), sizeof(int32_t) * word_base.size(), hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemsetAsync(d_bits.p, 0, sizeof(uint32_t) * (size_t)std::max<int64_t>(boff, 4), s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);      // (the host vectors above)
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+        p->cov_pending = CovBits{d_bits.p, d_bchrs.p, cutoff};
+        rc = garlic_wlod_windows(p, W, error, max_gap, use_gl, M, mu, 0, p->nind, 32, reinterpret_cast<double *>(d_bits.p), GARLIC_DEVICE);
+        p->cov_pending = CovBits{nullptr, nullptr, 0.0};
+        if (rc == GARLIC_ERR_STATE && strstr(garlic_hip_last_error(), "coverage bits need")) return done(unfused());
+        if (rc) return done(rc);
+        bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+        for (int c = 0; c < p->nchr; c++) vec_ok = vec_ok && Lo.base[c] % 8 == 0 && Lo.pitch[c] % 8 == 0;
+        hipLaunchKernelGGL(cov_counts_from_bits_kernel, dim3((unsigned)((word_base[(size_t)p->nchr] + 255) / 256), (unsigned)p->nind),
+                           dim3(256), 0, s, d_bits.p, d_bchrs.p, d_ochrs.p, d_wbase.p, p->nchr, W, vec_ok ? 1 : 0, dst);
+        e = hipGetLastError();
+        if (e == hipSuccess && where == GARLIC_HOST)
+            e = hipMemcpyAsync(inwin, dst, sizeof(int16_t) * (size_t)Lo.total, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+        return done(GARLIC_OK);
+    }
+    const bool fused = !weighted && !use_gl && W <= COVF_MAX_W && cutoff > MISSING_D && p->tab_all_finite &&
+                       !lod_exact_needed(p, MODE_LOD, W) && !getenv("GARLIC_COVERAGE_UNFUSED");
+    if (!fused) return unfused();
     const int nblk = (p->nind + WAVE - 1) / WAVE;
     std::vector<Run> runs;
     std::vector<FillItem> fill;

@@ -614,6 +614,15 @@ constexpr int WLOD_WAVES = 4;  // waves (64-individual blocks) per workgroup (8 
 constexpr int WT_PITCH = 18;   // doubles per row of the write-out patch (16 + pad, 16-B aligned rows)
 constexpr int SKEW_FRONT = 16; // doubles of padding in front of the skewed weight table
 
+// coverage bits instead of scores (garlic_roh_coverage_fused with --weighted): every group leaves 16 bits per
+// individual -- score >= cutoff, MISSING and NaN never -- in a bit matrix [chromosome][individual][locus / 32] that
+// cov_counts_from_bits_kernel (coverage_kernel.hpp) turns into inWin[]; bits == NULL: scores as usual
+struct CovBits {
+    uint32_t *bits;
+    const ChrDev *bchrs;       // out_base / out_pitch in dwords, per chromosome
+    double cutoff;
+};
+
 struct WlodArgs {
     const uint8_t *valid;      // [nloci] 1 = window holds a score
     const ChrDev *chrs;
@@ -624,6 +633,7 @@ struct WlodArgs {
     int32_t use_patch;         // transposed write-out through the LDS patch (allocated then)
     int64_t score_rows;        // FROM_SCORES: SNP rows per 64-individual block of the term matrix
     int32_t gl_ring;           // FROM_SCORES: hand-scheduled loop with per-wave LDS rings of term rows (allocated then)
+    CovBits cov;
 };
 // dynamic LDS of the term-matrix variant: patch lock (16 B) + patch [64][WT_PITCH] doubles, then, 1-KB
 // aligned, one ring of GARLIC_WLOD_GL_RING_ROWS x 512 B per wave
@@ -803,7 +813,7 @@ __device__ __forceinline__ void wlod_group_small(ScoreFn score, const double *Ds
 template <int R, bool ALIGNED16, class Args>
 __device__ __forceinline__ void wlod_write_group(double (&acc)[R], uint32_t gm, const ChrDev &c, const Args &p,
                                                  double *__restrict__ out, double *patch, int *patch_lock,
-                                                 int ind0, int s0, int grp, int lane_hint)
+                                                 int ind0, int s0, int grp, int lane_hint, int chr)
 {
     // the lane index afresh (opaque to the compiler): everything per-lane below is then computed here instead of being
     // kept alive across the hand-scheduled loop, whose register budget leaves no room -- hipcc spilled those values and
@@ -812,6 +822,17 @@ __device__ __forceinline__ void wlod_write_group(double (&acc)[R], uint32_t gm, 
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
     (void)lane_hint;
     const bool row_ok = ind0 + lane < p.ind_count;
+    if (p.cov.bits) {          // 2 bytes per lane and group instead of 128
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) m |= (((gm >> r) & 1u) && acc[r] >= p.cov.cutoff) ? (1u << r) : 0u;     // NaN >= x is false
+        if (row_ok) {
+            const ChrDev bc = p.cov.bchrs[chr];
+            uint16_t *brow = reinterpret_cast<uint16_t *>(p.cov.bits + bc.out_base + (int64_t)(ind0 + lane) * bc.out_pitch);
+            brow[(s0 + grp * R) >> 4] = (uint16_t)m;
+        }
+        return;
+    }
 #ifdef GARLIC_WLOD_ABL_NO_WRITE        // timing experiment: only one value per lane leaves (results wrong)
     if (acc[0] == 1.2345e-300 && row_ok) out[ind0 + lane] = acc[0];
     return;
@@ -944,7 +965,7 @@ wlod_tile_body(const uint32_t *__restrict__ packed,
                 wlod_group<R>(rows + grp * R * 4, gcol, G0 + grp * R,
                               D + (c.loc_base + s0 + grp * R) * (int64_t)W, W, acc);
         }
-        wlod_write_group<R, ALIGNED16>(acc, gm, c, p, out, patch, patch_lock, ind0, s0, grp, lane);
+        wlod_write_group<R, ALIGNED16>(acc, gm, c, p, out, patch, patch_lock, ind0, s0, grp, lane, td.x);
     }
 }
 
@@ -1056,8 +1077,8 @@ wlod_tile2_kernel(const uint32_t *__restrict__ packed, const double *__restrict_
         if (gm != 0)
             wlod_group2<R>(rows + grp * R * 4, packed, colA, colB, p.nwordrows, G0 + grp * R,
                            D + (c.loc_base + s0 + grp * R) * (int64_t)W, W, acc, bcc, (p.use_patch & 2) == 0);
-        wlod_write_group<R, ALIGNED16>(acc, gm, c, p, out, patch, patch_lock, ind0A, s0, grp, lane);
-        if (activeB) wlod_write_group<R, ALIGNED16>(bcc, gm, c, p, out, patch, patch_lock, ind0B, s0, grp, lane);
+        wlod_write_group<R, ALIGNED16>(acc, gm, c, p, out, patch, patch_lock, ind0A, s0, grp, lane, td.x);
+        if (activeB) wlod_write_group<R, ALIGNED16>(bcc, gm, c, p, out, patch, patch_lock, ind0B, s0, grp, lane, td.x);
     }
 }
 

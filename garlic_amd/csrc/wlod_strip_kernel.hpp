@@ -65,6 +65,7 @@ struct WlodStripArgs {
     int32_t *stalled;          // set to 1 when a wave gives up waiting (its results are then wrong): the host reruns the
                                // call with the tile form.  A poll budget measures time, not progress -- under a
                                // counter-serialising profiler a correct run may exhaust it -- so nothing traps.
+    CovBits cov;               // coverage bits instead of scores (variant_kernels.hpp); bits == NULL: scores
 };
 
 // flag rows: lane i's copy at row + 8 i
@@ -251,8 +252,8 @@ wlod_strip_gl_kernel(WlodStripArgs p)
             }
         }
         ws_row_write(lane8b, needoff, next_row);
-        wlod_write_group<WLOD_R, ALIGNED16>(acc, gm, c, p, p.out, patch, patch_lock, ind0A, s, 0, lane);
-        if (activeB) wlod_write_group<WLOD_R, ALIGNED16>(bcc, gm, c, p, p.out, patch, patch_lock, ind0B, s, 0, lane);
+        wlod_write_group<WLOD_R, ALIGNED16>(acc, gm, c, p, p.out, patch, patch_lock, ind0A, s, 0, lane, st.chr);
+        if (activeB) wlod_write_group<WLOD_R, ALIGNED16>(bcc, gm, c, p, p.out, patch, patch_lock, ind0B, s, 0, lane, st.chr);
     }
 }
 

@@ -297,10 +297,13 @@ int garlic_roh_coverage(garlic_panel *panel, const double *scores, int32_t pitch
  * itself only ever in a register -- and the inWin[] loop (:446-454) becomes a count over the last winsize bits.  What
  * GARLIC's final pass needs when --raw-lod is not asked for: 2 bytes per window leave the device and no score matrix
  * is resident.  inwin as for garlic_roh_coverage (inwin_pitch_align a multiple of 8 lets the kernel store 16 bytes
- * at a time).  Falls back to scores + garlic_roh_coverage where the fused kernel does not apply (cutoff <= -9999,
- * winsize > 1024, non-finite terms, window sums that can be -9999.0). */
-int garlic_roh_coverage_fused(garlic_panel *panel, int32_t winsize, double error, int32_t max_gap, double cutoff,
-                              int16_t *inwin, int32_t inwin_pitch_align, int32_t where);
+ * at a time).  use_gl / weighted / M / mu as for garlic_lod_windows / garlic_wlod_windows: with `weighted` the tuned
+ * wLOD kernels leave the bits themselves (16 per individual and group instead of 16 scores); unweighted scores with
+ * per-genotype likelihoods take the two-step path.  Falls back to scores + garlic_roh_coverage where the bit form
+ * does not apply (cutoff <= -9999; unweighted: winsize > 1024, non-finite terms, window sums that can be -9999.0). */
+int garlic_roh_coverage_fused(garlic_panel *panel, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
+                              int32_t weighted, int32_t M, double mu, double cutoff, int16_t *inwin,
+                              int32_t inwin_pitch_align, int32_t where);
 
 /* Introspection used by tests and the bench (device work of the last garlic_*_windows call). */
 typedef struct garlic_call_stats {

@@ -251,6 +251,40 @@ def test_roh_coverage_fused_equals_oracle_scores_then_counts(gpu_ctx, W):
                     assert np.array_equal(got[c][:, :n], want), (W, nind, cutoff, align, c)
 
 
+@pytest.mark.parametrize("W", [5, 16, 40, 100])
+def test_roh_coverage_fused_weighted(gpu_ctx, W):
+    """garlic_roh_coverage_fused with --weighted (plain and with per-genotype likelihoods): the tuned wLOD kernels leave
+    16 bits per individual and group instead of 16 scores -- against the oracle's wLOD scores through the oracle's
+    inWin[] loop; also unweighted scores with likelihoods (the two-step path)"""
+    rng = np.random.default_rng(270 + W)
+    mg = 200000
+    sizes = [3000, max(1, W - 1), W + 3, 33, 700]
+    for nind in (37, 130):
+        chroms = [ol.random_panel(rng, n, nind, max_gap=mg, gaps=2 if n > 1000 else 0) for n in sizes]
+        gpos = [c[2] * 1e-6 for c in chroms]
+        lds = [rng.uniform(1.0, max(2.0, W / 4.0), size=(n, W)) for n in sizes]
+        gl = [rng.choice([1e-16, 1e-3, 0.01, 0.2, 1.0], size=c[0].shape) for c in chroms]
+        with abi.Panel(gpu_ctx, sizes, nind) as panel:
+            panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms],
+                          gpos=np.concatenate(gpos))
+            panel.set_freq(np.concatenate([c[1] for c in chroms]))
+            panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+            panel.set_ld(W, np.concatenate(lds, axis=0))
+            panel.set_gl(np.concatenate(gl, axis=0))
+            for use_gl in (False, True):
+                want = [ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, 0.001, mg, 1e-9, 7, gl=gl[c] if use_gl else None)
+                        for c, (g, f, p, cs, ce) in enumerate(chroms)]
+                for cutoff, align in ((0.0, 1), (-1.5, 8), (-10000.0, 8)):
+                    got = panel.roh_coverage_fused(W, 0.001, mg, cutoff, pitch_align=align, use_gl=use_gl, weighted=True)
+                    for c, n in enumerate(sizes):
+                        assert np.array_equal(got[c][:, :n], ol.oracle_roh_coverage(np.ascontiguousarray(want[c]), W, cutoff)), \
+                            (W, nind, use_gl, cutoff, align, c)
+            want = [ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg, gl=gl[c]) for c, (g, f, p, cs, ce) in enumerate(chroms)]
+            got = panel.roh_coverage_fused(W, 0.001, mg, 0.5, pitch_align=8, use_gl=True)
+            for c, n in enumerate(sizes):
+                assert np.array_equal(got[c][:, :n], ol.oracle_roh_coverage(np.ascontiguousarray(want[c]), W, 0.5)), (W, nind, c)
+
+
 def test_lod_feed_one_call(gpu_ctx):
     """garlic_lod_feed = scores + convertWinData2DoubleData on the device, unweighted / TGLS / wLOD"""
     rng = np.random.default_rng(21)

@@ -117,6 +117,15 @@ def soak(ctx, trials, seed, verbose=True):
                 if not ol.bits_equal(np.ascontiguousarray(out[c]), ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, err, mg, 1e-9, 7)):
                     fails += 1
                     print("FAIL wlod", c, tag)
+            # ... and the weighted coverage counts without the score matrix
+            cutw = float(rng.choice([-2.0, 0.0, 1.0]))
+            covw = panel.roh_coverage_fused(W, err, mg, cutw, pitch_align=int(rng.choice([1, 8])), weighted=True)
+            for c, (g, f, p, cs, ce) in enumerate(chroms):
+                checks += 1
+                wantw = ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, err, mg, 1e-9, 7)
+                if not np.array_equal(covw[c][:, :sizes[c]], ol.oracle_roh_coverage(np.ascontiguousarray(wantw), W, cutw)):
+                    fails += 1
+                    print("FAIL weighted fused coverage", cutw, c, tag)
             if rng.integers(0, 2):       # a dictionary of likelihood values ...
                 gl = [rng.choice([1e-16, 1e-3, 0.01, 0.2, 1.0], size=c[0].shape) for c in chroms]
             else:                        # ... or any doubles (continuous mode: lod() on the device)
