@@ -408,6 +408,19 @@ def leg_ns(ctx, dev, steps):
                                                           note="term matrix built once per panel (gl_terms_kernel), not in the pass"))
     dt, k = timed_passes(ctx, lambda: panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU, use_gl=True),
                          steps, 1, torch.cuda.synchronize)
+    # TGLS final pass without its score matrix: the ring chain leaves a dword of coverage bits per lane and tile
+    # (the counts go into the score buffer's memory: with the term matrix resident there is no room for another 25 GB)
+    torch.cuda.synchronize()
+    panel.roh_coverage_fused_device(W, ERROR, MAX_GAP, 2.5, out.data_ptr(), pitch_align=8, use_gl=True)
+    tg = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        panel.roh_coverage_fused_device(W, ERROR, MAX_GAP, 2.5, out.data_ptr(), pitch_align=8, use_gl=True)
+        tg.append(time.perf_counter() - t0)
+    res["tgls_coverage_fused"] = {"call_ms": float(np.min(tg)) * 1e3, "scores_then_counts_ms": res["tgls"]["kernel_ms"] + tcv * 1e3,
+                                  "note": "lod_chain_ring_kernel writing coverage bits (4 B per individual and 32 windows) + "
+                                          "cov_counts_from_bits_kernel, against the score pass + roh_coverage_kernel"}
     clk = clock_under_load(lambda: panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU, use_gl=True),
                            torch.cuda.synchronize)
     res["wlod_gl"] = dict(rate(k, dt), roofline=fp64_roofline("wlod_strip_gl_kernel", win, W, k, clock=clk))

@@ -211,7 +211,8 @@ struct garlic_panel {
     DevBuf<double> d_rld, d_decay, d_stage64;
     DevBuf<uint64_t> d_phase;                      // HapData::firstCopy as bit planes [blk][nloci] (--phased LD)
     uint64_t geno_epoch = 0;                       // bumped by every genotype upload (LD plane cache)
-    CovBits cov_pending{nullptr, nullptr, 0.0};    // set by garlic_roh_coverage_fused around a weighted score call: bits, not scores
+    CovBits cov_pending{nullptr, nullptr, 0.0};    // set by garlic_roh_coverage_fused around a score call: bits, not scores
+    bool cov_written = false;                      // ... and a kernel that writes bits took the call
     bool have_phase = false;
     // scratch of the LD-weight kernels, kept between calls (window-size sweeps): at 10M SNPs the six
     // 8-GB allocations and frees of a call cost 9x its kernels.  garlic_panel_release_scratch drops it.
@@ -1096,6 +1097,14 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     const bool exact_possible = mode != MODE_WLOD && lod_exact_needed(p, mode, W);
     bool exact = exact_possible && getenv("GARLIC_EXACT_CHAIN_ONLY") != nullptr;
     if (exact_possible && thin_step > 0) return fail(GARLIC_ERR_INVALID, "internal: thinned output with the exact chain");
+    // coverage bits instead of scores (garlic_roh_coverage_fused): only the kernels that know how; nothing else may touch
+    // `out` (it is not a score buffer then)
+    const bool cov_bits = p->cov_pending.bits != nullptr;
+    if (cov_bits && mode == MODE_LOD)
+        return fail(GARLIC_ERR_STATE, "internal: coverage bits of the unweighted --error scores come from lod_bits_kernel");
+    if (cov_bits && mode == MODE_LOD_GL &&
+        (exact_possible || where != GARLIC_DEVICE || (ind_begin & (WAVE - 1)) != 0 || getenv("GARLIC_TGLS_NO_RING")))
+        return fail(GARLIC_ERR_STATE, "internal: coverage bits need the tuned wLOD kernels or the TGLS ring chain");
     const bool wlod_shape_ok = mode == MODE_WLOD && W + 64 <= GPAD_BACK && !getenv("GARLIC_WLOD_GENERIC") &&
                                (W >= WLOD_R || !getenv("GARLIC_WLOD_SMALL_GENERIC"));
     const bool wlod_small = W < WLOD_R;      // narrower than a window group: wlod_group_small (compiler-scheduled)
@@ -1108,7 +1117,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // narrow windows, plain scores: the streaming kernel (wlod_small_kernel.hpp) reads the plain reciprocals, a window's
     // W weights contiguous
     const bool wlod_stream = wlod_fast && wlod_small && !wlod_gl && !p->cov_pending.bits && !getenv("GARLIC_WLOD_SMALL_TILES");
-    if (p->cov_pending.bits && !wlod_fast) return fail(GARLIC_ERR_STATE, "internal: coverage bits need the tuned wLOD kernels");
+    if (p->cov_pending.bits && mode == MODE_WLOD && !wlod_fast) return fail(GARLIC_ERR_STATE, "internal: coverage bits need the tuned wLOD kernels");
     if (wlod_stream && (rc = ensure_rld(p))) return rc;
     // continuous likelihoods have no code table: the generic kernel takes its terms from the raw matrix
     if (mode == MODE_WLOD && use_gl && p->gl_cont && !wlod_fast && (rc = ensure_gl_terms(p))) return rc;
@@ -1290,7 +1299,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     }
     if (thin_step > 0) {          // small matrix: MISSING everywhere, the chain kernel overwrites the scored samples
         hipLaunchKernelGGL(fill_value_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_out, L.total, MISSING_D);
-    } else if (n_fill && !wlod_fast) {   // the tuned wLOD kernel writes MISSING itself
+    } else if (n_fill && !wlod_fast && !cov_bits) {   // the tuned wLOD kernel writes MISSING itself
         dim3 grid((unsigned)n_fill, (unsigned)((ind_count + FILL_ROWS - 1) / FILL_ROWS));
         hipLaunchKernelGGL(fill_missing_kernel, grid, dim3(256), 0, ctx->stream, p->d_fill.p,
                            p->d_chrs.p, ind_count, d_out);
@@ -1456,8 +1465,11 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
             !getenv("GARLIC_TGLS_NO_RING")) {
             // persistent workgroups, every term row through an LDS ring once (tgls_ring_kernel.hpp)
             TglsArgs t{p->d_glterms.p, (int64_t)(GOFF + p->nloci + GPAD_BACK), p->d_items.p, p->d_chrs.p, d_out,
-                       ind_begin, ind_count, W, (int32_t)n_items, p->d_counter.p};
+                       ind_begin, ind_count, W, (int32_t)n_items, p->d_counter.p, p->cov_pending};
+            if (p->cov_pending.bits) p->cov_written = true;
             hipLaunchKernelGGL(lod_chain_ring_kernel, dim3((unsigned)workers), dim3(TG_THREADS), 0, ctx->stream, t);
+        } else if (cov_bits) {
+            return fail(GARLIC_ERR_STATE, "internal: coverage bits need the tuned wLOD kernels or the TGLS ring chain");
         } else if (mode == MODE_LOD_GL && p->glterms_valid && !p->glterms_scaled) {
             hipLaunchKernelGGL(lod_chain_terms_kernel, dim3((unsigned)n_items), dim3(2 * WAVE), 0, ctx->stream, a,
                                (int)n_items, (int64_t)(GOFF + p->nloci + GPAD_BACK), p->d_glterms.p);
@@ -2909,7 +2921,7 @@ int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, in
         return garlic_roh_coverage(p, p->d_out.p, 32, p->nind, W, cutoff, inwin, inwin_pitch_align, where);
     };
     hipStream_t s = ctx->stream;
-    if (weighted && cutoff > MISSING_D && !getenv("GARLIC_COVERAGE_UNFUSED")) {
+    if ((weighted || use_gl) && cutoff > MISSING_D && !getenv("GARLIC_COVERAGE_UNFUSED")) {
         // --weighted (with or without likelihoods): the tuned wLOD kernels leave 16 bits per individual and group instead
         // of 16 scores (wlod_write_group), the counts come from the bits as for the unweighted scores
         std::vector<ChrDev> bchrs;
@@ -2939,10 +2951,16 @@ int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, in
         if (e == hipSuccess) e = hipStreamSynchronize(s);      // (the host vectors above)
         if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
         p->cov_pending = CovBits{d_bits.p, d_bchrs.p, cutoff};
-        rc = garlic_wlod_windows(p, W, error, max_gap, use_gl, M, mu, 0, p->nind, 32, reinterpret_cast<double *>(d_bits.p), GARLIC_DEVICE);
+        p->cov_written = false;
+        if (weighted)
+            rc = garlic_wlod_windows(p, W, error, max_gap, use_gl, M, mu, 0, p->nind, 32, reinterpret_cast<double *>(d_bits.p), GARLIC_DEVICE);
+        else      // unweighted scores with likelihoods: the TGLS ring chain leaves a dword of bits per lane and tile
+            rc = garlic_lod_windows(p, W, error, max_gap, 1, 0, p->nind, 32, reinterpret_cast<double *>(d_bits.p), GARLIC_DEVICE);
+        const bool written = weighted || p->cov_written;
         p->cov_pending = CovBits{nullptr, nullptr, 0.0};
         if (rc == GARLIC_ERR_STATE && strstr(garlic_hip_last_error(), "coverage bits need")) return done(unfused());
         if (rc) return done(rc);
+        if (!written) return done(unfused());       // (no scored window at all: nothing was launched)
         bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
         for (int c = 0; c < p->nchr; c++) vec_ok = vec_ok && Lo.base[c] % 8 == 0 && Lo.pitch[c] % 8 == 0;
         hipLaunchKernelGGL(cov_counts_from_bits_kernel, dim3((unsigned)((word_base[(size_t)p->nchr] + 255) / 256), (unsigned)p->nind),

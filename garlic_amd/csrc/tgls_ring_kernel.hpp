@@ -42,6 +42,7 @@ struct TglsArgs {
     double *out;
     int32_t ind_begin, ind_count, winsize, n_items;
     int32_t *next_item;       // [0] queue head, [1] workgroups that have left (both zero at launch; reset by the last one)
+    CovBits cov;              // coverage bits instead of scores (variant_kernels.hpp): one dword per lane and tile; NULL: scores
 };
 
 // flags in LDS: [0] tiles written by CHAIN, [1] tiles stored by POST, [2] / [3] requests landed (LOAD0 / LOAD1)
@@ -167,6 +168,8 @@ lod_chain_ring_kernel(TglsArgs p)
                 tg_loader(wave == 0 ? lead : trail, n_pieces, 1, 0, ring_rows,
                           ring_lds + (wave == 0 ? 0u : (uint32_t)ring_rows * 512u), &flags[0], &flags[2 + wave], lane);
             }
+        } else if (wave == 3 && p.cov.bits) {
+            // coverage bits: the chain wave stores its own dword per tile, there are no tiles to write out
         } else if (wave == 3) {   // ---- write-out
             const int rows_valid = min(WAVE, p.ind_count - it.ind0);
             double *out_row0 = p.out + c.out_base + (int64_t)it.ind0 * c.out_pitch;
@@ -193,6 +196,13 @@ lod_chain_ring_kernel(TglsArgs p)
             //   single: (i) % R and (i + W) % R of one ring;  double: (i) % R2 in the upper / lower half
             int so = 0, si = single ? W % ring_rows : 0;
             const int base_out = single ? 0 : ring_rows * WAVE;
+            // coverage bits: the lane's row of the bit matrix (looked up once per item: inside the tile loop the load
+            // sat on the chain's critical path, a trip to memory per tile)
+            uint32_t *bits_row = nullptr;
+            if (p.cov.bits) {
+                const ChrDev bc = p.cov.bchrs[it.chr];
+                bits_row = p.cov.bits + bc.out_base + (int64_t)(it.ind0 + lane) * bc.out_pitch;
+            }
             for (int k = 0; k < ntiles; k++) {
                 // inputs: every row this tile reads has landed
                 if (single) {
@@ -203,7 +213,9 @@ lod_chain_ring_kernel(TglsArgs p)
                     const int need = TILE * (k + 1) / 2;
                     while (LDS_FLAG_GET(flags[2]) < need || LDS_FLAG_GET(flags[3]) < need) __builtin_amdgcn_s_sleep(1);
                 }
-                while (LDS_FLAG_GET(flags[1]) + 2 <= k) __builtin_amdgcn_s_sleep(1);   // tile buffer k & 1 written out
+                const bool bits_mode = p.cov.bits != nullptr;
+                if (!bits_mode)
+                    while (LDS_FLAG_GET(flags[1]) + 2 <= k) __builtin_amdgcn_s_sleep(1);   // tile buffer k & 1 written out
                 lds_acquire();
                 double *tile = tiles[k & 1];
                 const int s0 = first + k * TILE;
@@ -216,7 +228,34 @@ lod_chain_ring_kernel(TglsArgs p)
                     si = (si + 1 == ring_rows) ? 0 : si + 1;
                     so = (so + 1 == ring_rows) ? 0 : so + 1;
                 }
-                if (edge) {
+                if (bits_mode) {
+                    // one bit per window -- score >= cutoff, NaN never -- 32 per lane and tile; a tile at a run's edge may
+                    // hold another run's windows too when W < 32: those OR their bits into the zeroed matrix
+                    uint32_t m = 0;
+                    const double cutoff = p.cov.cutoff;
+                    if (edge) {
+#pragma unroll
+                        for (int j = 0; j < TILE; j++) {
+                            const int s = s0 + j;
+                            const bool in = (s >= a && s <= b);
+                            const double ti = in ? t_in[j] : 0.0;
+                            const double to = (in && s > a) ? t_out[j] : 0.0;
+                            acc = (acc - to) + ti;
+                            m |= (in && acc >= cutoff) ? (1u << j) : 0u;
+                        }
+                    } else {        // (a loop of its own: with the edge tests in it every window carried a dozen more instructions)
+#pragma unroll
+                        for (int j = 0; j < TILE; j++) {
+                            acc = (acc - t_out[j]) + t_in[j];
+                            m |= (acc >= cutoff) ? (1u << j) : 0u;
+                        }
+                    }
+                    if (it.ind0 + lane < p.ind_count) {
+                        uint32_t *w = bits_row + (s0 >> 5);
+                        if (edge) { if (m) atomicOr(w, m); }
+                        else *w = m;
+                    }
+                } else if (edge) {
 #pragma unroll
                     for (int j = 0; j < TILE; j++) {
                         const int s = s0 + j;

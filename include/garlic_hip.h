@@ -298,8 +298,8 @@ int garlic_roh_coverage(garlic_panel *panel, const double *scores, int32_t pitch
  * GARLIC's final pass needs when --raw-lod is not asked for: 2 bytes per window leave the device and no score matrix
  * is resident.  inwin as for garlic_roh_coverage (inwin_pitch_align a multiple of 8 lets the kernel store 16 bytes
  * at a time).  use_gl / weighted / M / mu as for garlic_lod_windows / garlic_wlod_windows: with `weighted` the tuned
- * wLOD kernels leave the bits themselves (16 per individual and group instead of 16 scores); unweighted scores with
- * per-genotype likelihoods take the two-step path.  Falls back to scores + garlic_roh_coverage where the bit form
+ * wLOD kernels leave the bits themselves (16 per individual and group instead of 16 scores), with unweighted
+ * per-genotype likelihoods the TGLS chain does (32 per individual and tile).  Falls back to scores + garlic_roh_coverage where the bit form
  * does not apply (cutoff <= -9999; unweighted: winsize > 1024, non-finite terms, window sums that can be -9999.0). */
 int garlic_roh_coverage_fused(garlic_panel *panel, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
                               int32_t weighted, int32_t M, double mu, double cutoff, int16_t *inwin,

@@ -143,6 +143,15 @@ def soak(ctx, trials, seed, verbose=True):
                 if not ol.bits_equal(np.ascontiguousarray(out[c]), ol.oracle_calc_lod(g, f, p, cs, ce, W, err, mg, gl=gl[c])):
                     fails += 1
                     print("FAIL tgls", c, tag)
+            # coverage counts from the TGLS chain's bits (dictionary mode: the ring kernel; continuous: whichever path)
+            cutg = float(rng.choice([-2.0, 0.5]))
+            covg = panel.roh_coverage_fused(W, err, mg, cutg, pitch_align=8, use_gl=True)
+            for c, (g, f, p, cs, ce) in enumerate(chroms):
+                checks += 1
+                wantg = ol.oracle_calc_lod(g, f, p, cs, ce, W, err, mg, gl=gl[c])
+                if not np.array_equal(covg[c][:, :sizes[c]], ol.oracle_roh_coverage(np.ascontiguousarray(wantg), W, cutg)):
+                    fails += 1
+                    print("FAIL tgls fused coverage", cutg, c, tag)
             out = panel.wlod_windows(W, err, mg, 7, 1e-9, pitch_align=32, use_gl=True)
             for c, (g, f, p, cs, ce) in enumerate(chroms):
                 checks += 1
