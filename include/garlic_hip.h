@@ -332,8 +332,11 @@ int garlic_panel_chain_kind(garlic_panel *panel, int32_t *kind);
  * Where a score buffer sits in VRAM decides between two speeds of the unweighted kernel (1.36 / 1.62 ms at 1M SNPs x
  * 1000 individuals).  garlic_panel_alloc_scores allocates `candidates` (0 = 4) buffers for the
  * layout garlic_lod_out_layout(pitch_align, nind_out), times the real kernel for `winsize` into each and keeps the
- * fastest; candidate_ms (may be NULL): the kernel time into each candidate.  Free with garlic_device_free.  The
- * library's own full-score scratch (host-output calls) is chosen the same way at first use. */
+ * fastest; candidate_ms (may be NULL): the kernel time into each candidate.  When all candidates of a round time
+ * within 6 % of each other (buffers allocated together can all sit on one side) a further round is taken from fresh
+ * memory while the first is held, three at most (GARLIC_ALLOC_ROUNDS), memory permitting; candidate_ms then holds the
+ * times of the round the kept buffer came from.  Free with garlic_device_free.  The library's own full-score scratch
+ * (host-output calls) is chosen the same way at first use. */
 int garlic_device_alloc(garlic_ctx *ctx, int64_t bytes, void **out);
 int garlic_device_free(garlic_ctx *ctx, void *ptr);
 int garlic_device_alloc_stats(garlic_ctx *ctx, int64_t *live_bytes, int64_t *pooled_bytes, int64_t *reserved_bytes);

@@ -105,3 +105,35 @@ def test_library_owned_scratch_lands_in_the_fast_placement(gpu_ctx):
             ms.append(panel.stats()["chain_kernel_ms"])
         buf.free()
         assert min(ms) <= 1.08 * min(cand_ms), (ms, cand_ms)
+
+
+def test_alloc_scores_takes_further_rounds_when_the_candidates_look_alike(gpu_ctx, monkeypatch):
+    """A round of candidates that all time alike is followed by another from fresh memory (at most three); one buffer
+    is kept, the others wait in the pool, and the scores written into the kept one are the oracle's."""
+    rng = np.random.default_rng(11)
+    W, mg, sizes, nind = 20, 200000, [1500, 700], 70
+    chroms = [ol.random_panel(rng, n, nind, max_gap=mg) for n in sizes]
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms])
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        base, pitch, total = panel.out_layout(32, nind)
+        gpu_ctx.trim()
+        live0, pooled0, _ = gpu_ctx.alloc_stats()
+        monkeypatch.setenv("GARLIC_ALLOC_SPREAD", "100")           # never "mixed": all three rounds are taken
+        buf, ms3 = panel.alloc_scores(W, 0.001, mg, candidates=3)
+        live1, pooled1, _ = gpu_ctx.alloc_stats()
+        assert len(ms3) == 3 and min(ms3) > 0
+        assert live1 - live0 >= total * 8 and live1 - live0 < 2 * total * 8 + (4 << 20)      # one buffer kept ...
+        assert pooled1 - pooled0 >= 8 * total * 8                  # ... eight candidates of three rounds in the pool
+        monkeypatch.setenv("GARLIC_ALLOC_ROUNDS", "1")
+        buf1, ms1 = panel.alloc_scores(W, 0.001, mg, candidates=2)
+        assert len(ms1) == 2 and min(ms1) > 0
+        for b in (buf, buf1):
+            panel.lod_windows_device(b.ptr, W, 0.001, mg, pitch_align=32)
+            gpu_ctx.synchronize()
+            host = b.tensor().cpu().numpy()
+            for c, (g, f, p, cs, ce) in enumerate(chroms):
+                got = host[base[c]: base[c] + nind * pitch[c]].reshape(nind, pitch[c])[:, :sizes[c]]
+                assert ol.bits_equal(np.ascontiguousarray(got), ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg)), c
+            b.free()
