@@ -25,6 +25,7 @@
 #pragma once
 #include <type_traits>
 #include "feed_kernel.hpp"
+#include "cov_counts.hpp"
 
 namespace garlic {
 
@@ -315,10 +316,7 @@ lod_coverage_kernel(CovArgs p)
 // individual (10.1 instructions per window on the run's critical path against 18 for the compiler-scheduled
 // one-kernel form above); the counts are then a pass with no chain in it at all:
 //   inWin[l] = #bits in (l - W, l]
-// per (individual, 32-SNP word) thread: the count of the W bits in front of the word (popcounts over W / 32 + 1
-// words), then bit in, bit out, 32 times.  The 32 counts of a thread are 64 contiguous bytes of the individual's row;
-// a wave whose 64 words are whole words of one chromosome passes them through 4 KB of LDS of its own so that every
-// store instruction writes 1 KB contiguously (four 16-byte pieces 64 B apart per lane otherwise).
+// a launch of its own over every (individual, 32-SNP word): cov_counts_word of cov_counts.hpp per thread
 __global__ void __launch_bounds__(256)
 cov_counts_from_bits_kernel(const uint32_t *__restrict__ bits, const ChrDev *__restrict__ bchrs,
                             const ChrDev *__restrict__ ochrs, const int32_t *__restrict__ word_base, int nchr, int W,
@@ -334,46 +332,12 @@ cov_counts_from_bits_kernel(const uint32_t *__restrict__ bits, const ChrDev *__r
     const int t = live ? g - word_base[chr] : 0, nwords = (bc.nloci + 31) >> 5;
     const int row = blockIdx.y;
     const uint32_t *brow = bits + bc.out_base + (int64_t)row * bc.out_pitch;
-    auto word = [&](int x) -> uint32_t { return (live && x >= 0 && x < nwords) ? brow[x] : 0u; };
-    const uint32_t cur = word(t);
-    const int rel = 32 * t - W, dA = rel >> 5, r = rel & 31;          // bit 32 t - W sits in word dA at bit r (floor)
-    const uint32_t wA = word(dA);
-    const uint32_t F = __builtin_amdgcn_alignbit(word(dA + 1), wA, (uint32_t)r);      // bit j = window 32 t - W + j
-    int cnt = __popc(wA >> r);                                        // windows 32 t - W .. 32 t - 1
-    for (int x = dA + 1; x < t; x++) cnt += __popc(word(x));
-    uint32_t pk[16];
-#pragma unroll
-    for (int j = 0; j < 32; j++) {
-        cnt += (int)((cur >> j) & 1u) - (int)((F >> j) & 1u);
-        const uint32_t v = (uint32_t)cnt & 0xFFFFu;
-        if (j & 1) pk[j >> 1] |= v << 16;
-        else pk[j >> 1] = v;
-    }
-    int16_t *orow = out + oc.out_base + (int64_t)row * oc.out_pitch + 32 * t;
+    int16_t *orow = out + oc.out_base + (int64_t)row * oc.out_pitch;
     const bool whole = live && vec_ok && 32 * t + 32 <= oc.nloci;
     // all 64 threads of the wave on whole words of one chromosome: their 4 KB are contiguous in the row
     const int chr0 = __builtin_amdgcn_readfirstlane(chr);
-    if (__ballot(whole && chr == chr0) == ~(uint64_t)0) {
-        uint4 *x = xpose[wave];
-#pragma unroll
-        for (int u = 0; u < 4; u++) x[4 * lane + u] = make_uint4(pk[4 * u], pk[4 * u + 1], pk[4 * u + 2], pk[4 * u + 3]);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        uint4 *o = reinterpret_cast<uint4 *>(orow - 32 * lane);      // the wave's first word
-#pragma unroll
-        for (int u = 0; u < 4; u++) o[u * WAVE + lane] = x[u * WAVE + lane];
-        return;
-    }
-    if (!live) return;
-    if (whole) {
-        uint4 *o = reinterpret_cast<uint4 *>(orow);
-#pragma unroll
-        for (int u = 0; u < 4; u++) o[u] = make_uint4(pk[4 * u], pk[4 * u + 1], pk[4 * u + 2], pk[4 * u + 3]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 32; j++)
-            if (32 * t + j < oc.nloci) orow[j] = (int16_t)((pk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu);
-    }
+    const bool wave_whole = __ballot(whole && chr == chr0) == ~(uint64_t)0;
+    cov_counts_word(brow, nwords, t, live, W, orow, oc.nloci, whole, wave_whole, xpose[wave], lane);
 }
 
 } // namespace garlic

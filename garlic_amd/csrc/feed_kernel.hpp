@@ -33,6 +33,7 @@
 // the same protocol.
 #pragma once
 #include "lod_kernels.hpp"
+#include "cov_counts.hpp"
 #include "feed_loop_gfx950.inc"
 
 namespace garlic {
@@ -64,7 +65,24 @@ struct FeedArgs {
     // (a tile) per dword: `out` is then a uint32 matrix, chrs[].out_base / out_pitch in dwords, row = individual,
     // column = chromosome-local tile index (locus / 32); zeroed by the caller (edge tiles OR their bits in)
     double cutoff;
+    // lod_bits_kernel, optional (cnt_order != NULL): the sliding counts from the bits in the same launch.  The queue
+    // continues behind the chain items with n_cnt_items count items (cov_counts.hpp), chromosomes in the order their
+    // chains finish; every chain item adds one to chr_done[its chromosome] when its bits are in memory, a count item
+    // waits for chr_done[c] == chr_need[c].  Queue order makes that safe: whoever holds a count item knows every chain
+    // item has been taken by a workgroup that is running and waits for nobody.  The longest runs' chains are the kernel's
+    // critical path (one wave's pace x the run length) and leave most of the chip idle: the counts of every chromosome
+    // that is complete fill it.
+    const int32_t *cnt_order; // [nchr] chromosomes in queue order (NULL: no count items); chromosome cnt_order[k] owns the
+    const int32_t *cnt_base;  // [nchr + 1] count items cnt_base[k] .. cnt_base[k + 1] - 1: word chunk major, row group minor
+    const ChrDev *cnt_chrs;   // out_base / out_pitch / nloci of the int16 count rows
+    int16_t *cnt_out;
+    int32_t *chr_done;        // [nchr], zero at launch
+    const int32_t *chr_need;  // [nchr]: chain items per chromosome
+    int32_t n_cnt_items, n_cnt_chr, cnt_vec_ok;
+    int32_t *cnt_timeout;     // set to 1 if a count item's wait ran out of its poll budget (the counts are then not to be used)
 };
+
+constexpr int FEED_BITS_LDS = 1024 + 4 * 4 * WAVE * 16;   // lod_bits_kernel: the count items' 4 KB per wave behind the misc words
 
 __device__ __forceinline__ void feed_barrier()
 {   // s_barrier alone: __syncthreads() would also wait for every outstanding memory request
@@ -110,7 +128,7 @@ template <bool BITS>
 __device__ __forceinline__ void lod_feed_body(const FeedArgs &p)
 {
     // one LDS object at offset 0: the hand-scheduled loop addresses the rings with absolute offsets
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[GARLIC_FEED_LDS_TOTAL];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[BITS && FEED_BITS_LDS > GARLIC_FEED_LDS_TOTAL ? FEED_BITS_LDS : GARLIC_FEED_LDS_TOTAL];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t dma_off = (uint32_t)lane * 4u + (uint32_t)wave * 256u;
@@ -118,11 +136,63 @@ __device__ __forceinline__ void lod_feed_body(const FeedArgs &p)
     // it is only ever touched through the integer addresses below and the loop's immediates)
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem);
     const int W = p.winsize, step = p.thin_step;
+    int fenced_chr = -1;      // count items: the chromosome this workgroup last waited for (its bits are visible here)
     for (;;) {
         if (threadIdx.x == 0) *reinterpret_cast<int *>(smem) = atomicAdd(p.next_item, 1);
         __syncthreads();
         const int item_idx = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(smem));
         __syncthreads();   // (also: every wave is done with the previous item's rings)
+        if (BITS && item_idx >= p.n_items && p.cnt_order && item_idx < p.n_items + p.n_cnt_items) {
+            // ---- a count item: COV_ITEM_WORDS words x COV_ITEM_ROWS individuals of a chromosome whose chains are done
+            const int q = item_idx - p.n_items;
+            int lo = 0, hi = p.n_cnt_chr - 1;          // the last k with cnt_base[k] <= q
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (p.cnt_base[mid] <= q) lo = mid;
+                else hi = mid - 1;
+            }
+            const int chr = __builtin_amdgcn_readfirstlane(p.cnt_order[lo]);
+            const int ql = q - p.cnt_base[lo], nrg = (p.ind_count + COV_ITEM_ROWS - 1) / COV_ITEM_ROWS;
+            const int word0 = ql / nrg * COV_ITEM_WORDS, row0 = ql % nrg * COV_ITEM_ROWS;
+            const int nrows = min(COV_ITEM_ROWS, p.ind_count - row0);
+            if (chr != fenced_chr) {
+                if (threadIdx.x == 0) {
+                    const int need = p.chr_need[chr];
+                    int polls = 0;
+                    while (__hip_atomic_load(p.chr_done + chr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                        __builtin_amdgcn_s_sleep(127);
+                        // (seconds: a chain that never finishes must not hang the device; once one wait has given up
+                        // nobody waits any more and the host reports the call as failed)
+                        if (++polls > (1 << 21) || __hip_atomic_load(p.cnt_timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            __hip_atomic_store(p.cnt_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+#ifndef GARLIC_COVOV_ABL_NOACQ
+                    __threadfence();     // acquire: the other XCDs' bits (their L2s were written back before chr_done moved)
+#endif
+                }
+                __syncthreads();
+                fenced_chr = chr;
+            }
+            const ChrDev bc = p.chrs[chr], oc = p.cnt_chrs[chr];
+            const int nwords = (bc.nloci + 31) >> 5;
+            const int t = word0 + (int)threadIdx.x;
+            const bool live = t < nwords;
+            const bool whole = live && p.cnt_vec_ok && 32 * t + 32 <= oc.nloci;
+            const bool wave_whole = __ballot(whole) == ~(uint64_t)0;
+            uint4 *xw = reinterpret_cast<uint4 *>(smem + 1024) + wave * (4 * WAVE);
+            const uint32_t *bits = reinterpret_cast<const uint32_t *>(p.out);
+#ifdef GARLIC_COVOV_ABL_NOWORK      // (timing experiment: the count items wait and do nothing)
+            if (p.cnt_out) continue;
+#endif
+            for (int r = 0; r < nrows; r++) {
+                const int row = row0 + r;
+                cov_counts_word(bits + bc.out_base + (int64_t)row * bc.out_pitch, nwords, live ? t : 0, live, W,
+                                p.cnt_out + oc.out_base + (int64_t)row * oc.out_pitch, oc.nloci, whole, wave_whole, xw, lane);
+            }
+            continue;
+        }
         if (item_idx >= p.n_items) {
             if (threadIdx.x == 0) {
                 __threadfence();
@@ -303,6 +373,16 @@ __device__ __forceinline__ void lod_feed_body(const FeedArgs &p)
             p.trace[8 * item_idx + 7] = ntiles;
         }
         __builtin_amdgcn_s_setprio(0);
+        if (BITS && p.cnt_order) {
+            // the item's bits are in memory (every wave has waited for its stores) before its chromosome's count moves:
+            // release at device scope, the count items may run on another XCD
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                atomicAdd(p.chr_done + p.items[item_idx].chr, 1);
+            }
+        }
     }
 }
 

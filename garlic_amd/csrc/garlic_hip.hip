@@ -3055,28 +3055,98 @@ int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, in
         (void)hipEventRecord(ctx->hist0[slot], s);
         if (e == hipSuccess) e = hipMemsetAsync(d_bits.p, 0, sizeof(uint32_t) * (size_t)boff, s);
         if (e != hipSuccess) return done2(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+        // GARLIC_COVERAGE_OVERLAP=1: the counts ride in the chain kernel's queue (FeedArgs::cnt_order) instead of a launch of
+        // their own behind it -- the longest runs' chains are that kernel's critical path and leave most of the chip idle,
+        // the counts of every finished chromosome could fill it.  Built and measured ("Coverage
+        // counts without the scores"): the chains are latency-bound and the counts' traffic slows the longest one from
+        // 22.8 to 36.5 ns per window, 19.5 ms against 17.6 ms for the two launches at 10M x 1250.  Off by default.
+        const bool overlap = !items.empty() && getenv("GARLIC_COVERAGE_OVERLAP");
+        DevBuf<int32_t> d_cnt;      // chr_done[nchr] | timeout | chr_need[nchr] | cnt_order[nchr] | cnt_base[nchr + 1]
+        auto done3 = [&](int code) { d_cnt.release(); return done2(code); };
+        const size_t nchr = (size_t)p->nchr;
+        int64_t n_cnt_items = 0;
+        if (overlap) {
+            std::vector<int32_t> h(4 * nchr + 2, 0);
+            int32_t *need = h.data() + nchr + 1, *corder = need + nchr, *cbase = corder + nchr;
+            std::vector<int32_t> longest(nchr, 0);
+            for (const FeedItem &it : items) need[it.chr]++;
+            for (const Run &r : runs) longest[(size_t)r.chr] = std::max(longest[(size_t)r.chr], r.b - r.a + 1);
+            for (size_t c = 0; c < nchr; c++) corder[c] = (int32_t)c;
+            std::stable_sort(corder, corder + nchr, [&](int32_t x, int32_t y) { return longest[(size_t)x] < longest[(size_t)y]; });
+            const int64_t nrg = (p->nind + COV_ITEM_ROWS - 1) / COV_ITEM_ROWS;
+            for (size_t k = 0; k < nchr; k++) {
+                cbase[k] = (int32_t)n_cnt_items;
+                const int64_t words = (p->chr_nloci[corder[k]] + 31) / 32;
+                n_cnt_items += (words + COV_ITEM_WORDS - 1) / COV_ITEM_WORDS * nrg;
+            }
+            cbase[nchr] = (int32_t)n_cnt_items;
+            if (n_cnt_items + (int64_t)items.size() >= ((int64_t)1 << 31))
+                return done3(fail(GARLIC_ERR_INVALID, "coverage: more than 2^31 work items"));
+            if ((rc = d_cnt.reserve(h.size()))) return done3(rc);
+            e = hipMemcpyAsync(d_cnt.p, h.data(), sizeof(int32_t) * h.size(), hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);      // (h leaves scope)
+            if (e != hipSuccess) return done3(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+        }
         if (!items.empty()) {
             FeedArgs f{p->d_packed.p, p->d_tab.p, d_items.p, d_bchrs.p, reinterpret_cast<double *>(d_bits.p), nullptr, p->nwordrows, 0,
                        p->nind, W, (int32_t)items.size(), 1, getenv("GARLIC_FEED_NO_ASM") ? 0 : 1, d_counter.p, nullptr, cutoff};
+            if (overlap) {
+                f.chr_done = d_cnt.p;
+                f.cnt_timeout = d_cnt.p + nchr;
+                f.chr_need = d_cnt.p + nchr + 1;
+                f.cnt_order = d_cnt.p + 2 * nchr + 1;
+                f.cnt_base = d_cnt.p + 3 * nchr + 1;
+                f.cnt_chrs = d_chrs.p;
+                f.cnt_out = dst;
+                f.n_cnt_items = (int32_t)n_cnt_items;
+                f.n_cnt_chr = p->nchr;
+                f.cnt_vec_ok = vec_ok ? 1 : 0;
+            }
+            DevBuf<int64_t> d_ftrace;   // debugging aid: GARLIC_TRACE=<file> dumps the chain items' time stamps
+            const char *ftrace_path = getenv("GARLIC_TRACE");
+            if (ftrace_path && d_ftrace.reserve(8 * items.size()) == GARLIC_OK) {
+                (void)hipMemsetAsync(d_ftrace.p, 0, sizeof(int64_t) * 8 * items.size(), s);
+                f.trace = d_ftrace.p;
+            }
             int per_cu = 0;
             e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)lod_bits_kernel, FEED_G * WAVE, 0);
-            if (e != hipSuccess) return done2(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+            if (e != hipSuccess) return done3(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
             per_cu = std::max(1, std::min(per_cu, 16 / FEED_G));
-            const int grid = (int)std::min<size_t>(items.size(), (size_t)ctx->n_cu * per_cu);
+            // (persistent workgroups, all resident: a count item that waits must not keep a chain item from starting)
+            const int grid = (int)std::min<size_t>(items.size() + (size_t)n_cnt_items, (size_t)ctx->n_cu * per_cu);
             void *kargs[] = {(void *)&f};
             e = hipLaunchKernel((const void *)lod_bits_kernel, dim3((unsigned)grid), dim3(FEED_G * WAVE), kargs, 0, s);
-            if (e != hipSuccess) return done2(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+            if (e != hipSuccess) return done3(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+            if (f.trace) {
+                std::vector<int64_t> tr(8 * items.size());
+                (void)hipMemcpyAsync(tr.data(), d_ftrace.p, sizeof(int64_t) * tr.size(), hipMemcpyDeviceToHost, s);
+                (void)hipStreamSynchronize(s);
+                if (FILE *fo = fopen(ftrace_path, "w")) {
+                    for (size_t i = 0; i < items.size(); i++) {
+                        fprintf(fo, "%zu", i);
+                        for (int q = 0; q < 8; q++) fprintf(fo, " %lld", (long long)tr[8 * i + q]);
+                        fprintf(fo, "\n");
+                    }
+                    fclose(fo);
+                }
+                d_ftrace.release();
+            }
         }
-        hipLaunchKernelGGL(cov_counts_from_bits_kernel, dim3((unsigned)((word_base[(size_t)p->nchr] + 255) / 256), (unsigned)p->nind),
-                           dim3(256), 0, s, d_bits.p, d_bchrs.p, d_chrs.p, d_wbase.p, p->nchr, W, vec_ok ? 1 : 0, dst);
+        if (!overlap)
+            hipLaunchKernelGGL(cov_counts_from_bits_kernel, dim3((unsigned)((word_base[(size_t)p->nchr] + 255) / 256), (unsigned)p->nind),
+                               dim3(256), 0, s, d_bits.p, d_bchrs.p, d_chrs.p, d_wbase.p, p->nchr, W, vec_ok ? 1 : 0, dst);
         (void)hipEventRecord(ctx->hist1[slot], s);
         ctx->n_calls++;
         e = hipGetLastError();
         if (e == hipSuccess && where == GARLIC_HOST)
             e = hipMemcpyAsync(inwin, dst, sizeof(int16_t) * (size_t)Lo.total, hipMemcpyDeviceToHost, s);
+        int32_t timed_out = 0;
+        if (e == hipSuccess && overlap)
+            e = hipMemcpyAsync(&timed_out, d_cnt.p + nchr, sizeof(int32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return done2(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
-        return done2(GARLIC_OK);
+        if (e != hipSuccess) return done3(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+        if (timed_out) return done3(fail(GARLIC_ERR_HIP, "coverage: a count item gave up waiting for its chromosome's chains"));
+        return done3(GARLIC_OK);
     }
     (void)hipEventRecord(ctx->hist0[slot], s);
     if (!ranges.empty())

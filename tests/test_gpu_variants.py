@@ -251,6 +251,29 @@ def test_roh_coverage_fused_equals_oracle_scores_then_counts(gpu_ctx, W):
                     assert np.array_equal(got[c][:, :n], want), (W, nind, cutoff, align, c)
 
 
+def test_roh_coverage_fused_counts_in_the_chain_kernels_queue(gpu_ctx, monkeypatch):
+    """GARLIC_COVERAGE_OVERLAP=1 (off by default: measured slower): the count items wait in the
+    chain kernel's queue for their chromosome's chains -- same counts as the two launches"""
+    rng = np.random.default_rng(99)
+    mg, W = 200000, 40
+    sizes = [40000, 1, W - 1, W + 3, 9000, 33, 20000]
+    for nind in (37, 300):
+        chroms = [ol.random_panel(rng, n, nind, max_gap=mg, gaps=3 if n > 1000 else 0) for n in sizes]
+        with abi.Panel(gpu_ctx, sizes, nind) as panel:
+            panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms])
+            panel.set_freq(np.concatenate([c[1] for c in chroms]))
+            panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+            for cutoff, align in ((0.0, 1), (-2.5, 8)):
+                monkeypatch.delenv("GARLIC_COVERAGE_OVERLAP", raising=False)
+                want = panel.roh_coverage_fused(W, 0.001, mg, cutoff, pitch_align=align)
+                monkeypatch.setenv("GARLIC_COVERAGE_OVERLAP", "1")
+                for _ in range(2):
+                    got = panel.roh_coverage_fused(W, 0.001, mg, cutoff, pitch_align=align)
+                    for c, n in enumerate(sizes):
+                        assert np.array_equal(got[c][:, :n], want[c][:, :n]), (nind, cutoff, align, c)
+            monkeypatch.delenv("GARLIC_COVERAGE_OVERLAP", raising=False)
+
+
 @pytest.mark.parametrize("W", [5, 16, 40, 100])
 def test_roh_coverage_fused_weighted(gpu_ctx, W):
     """garlic_roh_coverage_fused with --weighted (plain and with per-genotype likelihoods): the tuned wLOD kernels leave
