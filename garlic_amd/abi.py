@@ -30,7 +30,7 @@ SYMBOLS = [
     "garlic_lod_feed", "garlic_ctx_set_async",
     "garlic_recent_kernel_ms", "garlic_panel_tgls_mode", "garlic_lod_feed_subset", "garlic_lod_feed_multi",
     "garlic_device_alloc", "garlic_device_free", "garlic_panel_chain_kind", "garlic_device_alloc_stats",
-    "garlic_panel_alloc_scores", "garlic_device_trim", "garlic_roh_coverage_fused",
+    "garlic_panel_alloc_scores", "garlic_device_trim", "garlic_roh_coverage_fused", "garlic_roh_segments",
 ]
 
 
@@ -53,7 +53,7 @@ _i64p = C.POINTER(C.c_int64)
 _f64p = C.POINTER(C.c_double)
 
 
-ABI_VERSION = 6   # GARLIC_HIP_ABI_VERSION of include/garlic_hip.h these bindings were written against
+ABI_VERSION = 7   # GARLIC_HIP_ABI_VERSION of include/garlic_hip.h these bindings were written against
 
 
 def lib():
@@ -109,6 +109,8 @@ def lib():
                                       C.c_int32]
     L.garlic_roh_coverage_fused.argtypes = [_vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double,
                                             C.c_double, _vp, C.c_int32, C.c_int32]
+    L.garlic_roh_segments.argtypes = [_vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                      C.c_double, C.c_double, _vp, C.c_int64, _i64p]
     L.garlic_lod_feed_subset.argtypes = [_vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_double, C.c_int32, _i32p, C.c_int32, _vp, C.c_int64, _i64p, _i64p]
     L.garlic_lod_feed_multi.argtypes = [_vp, _i32p, _i32p, C.c_int32, C.c_double, C.c_int32, _i32p, C.c_int32,
@@ -527,6 +529,20 @@ class Panel:
         check(lib().garlic_roh_coverage_fused(self.handle, winsize, error, max_gap, int(use_gl), int(weighted), M, mu, cutoff,
                                               _vp(out.ctypes.data), pitch_align, HOST))
         return [out[base[c]: base[c] + self.nind * pitch[c]].reshape(self.nind, pitch[c]) for c in range(self.nchr)]
+
+    def roh_segments(self, winsize, error, max_gap, cutoff, overlap_frac, use_gl=False, weighted=False, M=7, mu=1e-9, capacity=None):
+        """garlic_roh_segments: the ROH segments of assembleROHWindows without scores or counts in memory -> int32 array
+        [n][4] of (individual, chromosome, first SNP, last SNP), in the reference's order.  capacity None: asked for first."""
+        n = C.c_int64()
+        args = (self.handle, winsize, error, max_gap, int(use_gl), int(weighted), M, mu, cutoff, overlap_frac)
+        if capacity is None:
+            check(lib().garlic_roh_segments(*args, _vp(), 0, C.byref(n)))
+            capacity = n.value
+        out = np.empty((max(int(capacity), 1), 4), dtype=np.int32)
+        check(lib().garlic_roh_segments(*args, _vp(out.ctypes.data), int(capacity), C.byref(n)))
+        if n.value > capacity:
+            raise GarlicError(1, f"garlic_roh_segments: {n.value} segments, room for {capacity}")
+        return out[:n.value].copy()
 
     def roh_coverage_fused_device(self, winsize, error, max_gap, cutoff, out_ptr, pitch_align=8, use_gl=False, weighted=False,
                                   M=7, mu=1e-9):

@@ -13,6 +13,7 @@
 #include "wlod_strip_kernel.hpp"
 #include "wlod_small_kernel.hpp"
 #include "coverage_kernel.hpp"
+#include "roh_segments_kernel.hpp"
 #include "feed_kernel.hpp"
 
 #include <algorithm>
@@ -2895,14 +2896,77 @@ static int coverage_bits_layout(garlic_panel *p, std::vector<ChrDev> &bchrs, std
     return GARLIC_OK;
 }
 
-int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
-                              int32_t weighted, int32_t M, double mu, double cutoff, int16_t *inwin,
-                              int32_t inwin_pitch_align, int32_t where)
+// What becomes of the window bits: the sliding counts (garlic_roh_coverage_fused) or the ROH segments (garlic_roh_segments)
+struct CovSink {
+    int16_t *inwin = nullptr;            // counts
+    int32_t inwin_pitch_align = 8, where = GARLIC_DEVICE;
+    bool segments = false;               // segments
+    double overlap_frac = 0.0;
+    garlic_roh_segment *segs = nullptr;
+    int64_t cap = 0, *n_out = nullptr;
+};
+
+// ROH segments from the window bits (roh_segments_kernel.hpp): r bits, break bits, the list; sorted on the host into
+// the reference's order.  The bit matrix is [chromosome][individual][word], bchrs / word_base as coverage_bits_layout.
+static int segments_from_bits(garlic_panel *p, const uint32_t *d_bits, const ChrDev *d_bchrs, const std::vector<ChrDev> &bchrs,
+                              const std::vector<int32_t> &word_base, int32_t W, const CovSink &sink)
 {
-    if (!p || !inwin) return fail(GARLIC_ERR_INVALID, "panel and inwin are required");
-    if (winsize <= 1 || inwin_pitch_align < 1) return fail(GARLIC_ERR_INVALID, "winsize must be > 1, inwin_pitch_align >= 1");
-    if (winsize > 32767) return fail(GARLIC_ERR_INVALID, "coverage counts are 16-bit: winsize <= 32767");
-    if (p->nind > 65535) return fail(GARLIC_ERR_INVALID, "coverage: at most 65535 individuals per call");
+    garlic_ctx *ctx = p->ctx;
+    hipStream_t s = ctx->stream;
+    double T = sink.overlap_frac * W;              // src/garlic-roh.cpp:421-423
+    T = (T >= 1) ? T : 1;
+    T = (T <= W) ? T : W;
+    const int thr = (int)std::ceil(T);             // counts are integers: cnt >= T  <=>  cnt >= ceil(T)
+    const size_t nchr = (size_t)p->nchr;
+    const int64_t total_words = word_base[nchr];
+    int64_t bit_words = 0;
+    for (size_t c = 0; c < nchr; c++) bit_words = std::max<int64_t>(bit_words, bchrs[c].out_base + bchrs[c].out_pitch * p->nind);
+    DevBuf<uint32_t> d_mask, d_brk;
+    DevBuf<int32_t> d_wbase;
+    DevBuf<garlic_roh_segment> d_segs;
+    DevBuf<unsigned long long> d_count;
+    auto done = [&](int code) { d_mask.release(); d_brk.release(); d_wbase.release(); d_segs.release(); d_count.release(); return code; };
+    int rc;
+    const int64_t cap = std::max<int64_t>(sink.cap, 0);
+    if ((rc = d_mask.reserve((size_t)std::max<int64_t>(bit_words, 1))) || (rc = d_brk.reserve((size_t)std::max<int64_t>(total_words, 1))) ||
+        (rc = d_wbase.reserve(word_base.size())) || (rc = d_segs.reserve((size_t)std::max<int64_t>(cap, 1))) || (rc = d_count.reserve(1)))
+        return done(rc);
+    hipError_t e = hipMemcpyAsync(d_wbase.p, word_base.data(), sizeof(int32_t) * word_base.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_brk.p, 0, sizeof(uint32_t) * (size_t)std::max<int64_t>(total_words, 1), s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_count.p, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "roh segments: %s", hipGetErrorString(e)));
+    unsigned long long found = 0;
+    if (total_words > 0) {
+        const int nb = (int)p->boundaries.size();
+        if (nb > 0)
+            hipLaunchKernelGGL(roh_break_bits_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, p->d_boundaries.p, nb,
+                               p->d_chr_off.p, d_wbase.p, p->nchr, d_brk.p);
+        const dim3 grid((unsigned)((total_words + 255) / 256), (unsigned)p->nind);
+        hipLaunchKernelGGL(roh_mask_from_bits_kernel, grid, dim3(256), 0, s, d_bits, d_bchrs, d_wbase.p, p->nchr, W, thr, d_mask.p);
+        hipLaunchKernelGGL(roh_segments_from_mask_kernel, grid, dim3(256), 0, s, d_mask.p, d_bchrs, d_brk.p, d_wbase.p, p->nchr, T,
+                           d_segs.p, (long long)cap, d_count.p);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&found, d_count.p, sizeof found, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "roh segments: %s", hipGetErrorString(e)));
+    }
+    if (sink.n_out) *sink.n_out = (int64_t)found;
+    if ((int64_t)found <= cap && found > 0) {
+        e = hipMemcpyAsync(sink.segs, d_segs.p, sizeof(garlic_roh_segment) * found, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "roh segments: %s", hipGetErrorString(e)));
+        std::sort(sink.segs, sink.segs + found, [](const garlic_roh_segment &x, const garlic_roh_segment &y) {
+            return x.ind != y.ind ? x.ind < y.ind : x.chr != y.chr ? x.chr < y.chr : x.start < y.start;
+        });
+    }
+    return done(GARLIC_OK);
+}
+
+static int coverage_impl(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
+                         int32_t weighted, int32_t M, double mu, double cutoff, const CovSink &sink)
+{
+    int16_t *const inwin = sink.inwin;
+    const int32_t inwin_pitch_align = sink.inwin_pitch_align, where = sink.where;
     garlic_ctx *ctx = p->ctx;
     int rc;
     if ((rc = set_device(ctx))) return rc;
@@ -2918,7 +2982,31 @@ int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, in
         if (weighted) rc2 = garlic_wlod_windows(p, W, error, max_gap, use_gl, M, mu, 0, p->nind, 32, p->d_out.p, GARLIC_DEVICE);
         else rc2 = garlic_lod_windows(p, W, error, max_gap, use_gl, 0, p->nind, 32, p->d_out.p, GARLIC_DEVICE);
         if (rc2) return rc2;
-        return garlic_roh_coverage(p, p->d_out.p, 32, p->nind, W, cutoff, inwin, inwin_pitch_align, where);
+        if (!sink.segments) return garlic_roh_coverage(p, p->d_out.p, 32, p->nind, W, cutoff, inwin, inwin_pitch_align, where);
+        // segments: the scores' bits (score >= cutoff, MISSING compared like any score), then as from the chains' bits
+        std::vector<ChrDev> bchrs, schrs((size_t)p->nchr);
+        std::vector<int32_t> word_base;
+        int64_t boff = 0;
+        if ((rc2 = coverage_bits_layout(p, bchrs, word_base, boff))) return rc2;
+        for (int c = 0; c < p->nchr; c++) schrs[(size_t)c] = ChrDev{p->chr_off[c], L.base[c], L.pitch[c], p->chr_nloci[c], 0};
+        DevBuf<uint32_t> d_bits;
+        DevBuf<ChrDev> d_bchrs, d_schrs;
+        DevBuf<int32_t> d_wbase;
+        auto done = [&](int code) { d_bits.release(); d_bchrs.release(); d_schrs.release(); d_wbase.release(); return code; };
+        if ((rc2 = d_bits.reserve((size_t)std::max<int64_t>(boff, 1))) || (rc2 = d_bchrs.reserve(bchrs.size())) ||
+            (rc2 = d_schrs.reserve(schrs.size())) || (rc2 = d_wbase.reserve(word_base.size())))
+            return done(rc2);
+        hipStream_t s2 = ctx->stream;
+        hipError_t e2 = hipMemcpyAsync(d_bchrs.p, bchrs.data(), sizeof(ChrDev) * bchrs.size(), hipMemcpyHostToDevice, s2);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(d_schrs.p, schrs.data(), sizeof(ChrDev) * schrs.size(), hipMemcpyHostToDevice, s2);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(d_wbase.p, word_base.data(), sizeof(int32_t) * word_base.size(), hipMemcpyHostToDevice, s2);
+        if (e2 != hipSuccess) return done(fail(GARLIC_ERR_HIP, "roh segments: %s", hipGetErrorString(e2)));
+        if (word_base[(size_t)p->nchr] > 0)
+            hipLaunchKernelGGL(roh_bits_from_scores_kernel, dim3((unsigned)((word_base[(size_t)p->nchr] + 255) / 256), (unsigned)p->nind),
+                               dim3(256), 0, s2, p->d_out.p, d_schrs.p, d_bchrs.p, d_wbase.p, p->nchr, W, cutoff, d_bits.p);
+        e2 = hipStreamSynchronize(s2);      // (the host vectors above)
+        if (e2 != hipSuccess) return done(fail(GARLIC_ERR_HIP, "roh segments: %s", hipGetErrorString(e2)));
+        return done(segments_from_bits(p, d_bits.p, d_bchrs.p, bchrs, word_base, W, sink));
     };
     hipStream_t s = ctx->stream;
     if ((weighted || use_gl) && cutoff > MISSING_D && !getenv("GARLIC_COVERAGE_UNFUSED")) {
@@ -2961,6 +3049,7 @@ int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, in
         if (rc == GARLIC_ERR_STATE && strstr(garlic_hip_last_error(), "coverage bits need")) return done(unfused());
         if (rc) return done(rc);
         if (!written) return done(unfused());       // (no scored window at all: nothing was launched)
+        if (sink.segments) return done(segments_from_bits(p, d_bits.p, d_bchrs.p, bchrs, word_base, W, sink));
         bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
         for (int c = 0; c < p->nchr; c++) vec_ok = vec_ok && Lo.base[c] % 8 == 0 && Lo.pitch[c] % 8 == 0;
         hipLaunchKernelGGL(cov_counts_from_bits_kernel, dim3((unsigned)((word_base[(size_t)p->nchr] + 255) / 256), (unsigned)p->nind),
@@ -3029,7 +3118,7 @@ int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, in
     bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
     for (int c = 0; c < p->nchr; c++) vec_ok = vec_ok && Lo.base[c] % 8 == 0 && Lo.pitch[c] % 8 == 0;
     const int slot = (int)(ctx->n_calls % garlic_ctx::HIST);
-    if (!getenv("GARLIC_COVERAGE_ONE_KERNEL")) {
+    if (sink.segments || !getenv("GARLIC_COVERAGE_ONE_KERNEL")) {
         // two kernels: one bit per window and individual from the hand-scheduled chain (lod_bits_kernel), then the
         // sliding counts from the bits (cov_counts_from_bits_kernel): a 64th of the score bytes in between
         std::vector<ChrDev> bchrs((size_t)p->nchr);
@@ -3060,7 +3149,7 @@ int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, in
         // the counts of every finished chromosome could fill it.  Built and measured ("Coverage
         // counts without the scores"): the chains are latency-bound and the counts' traffic slows the longest one from
         // 22.8 to 36.5 ns per window, 19.5 ms against 17.6 ms for the two launches at 10M x 1250.  Off by default.
-        const bool overlap = !items.empty() && getenv("GARLIC_COVERAGE_OVERLAP");
+        const bool overlap = !items.empty() && !sink.segments && getenv("GARLIC_COVERAGE_OVERLAP");
         DevBuf<int32_t> d_cnt;      // chr_done[nchr] | timeout | chr_need[nchr] | cnt_order[nchr] | cnt_base[nchr + 1]
         auto done3 = [&](int code) { d_cnt.release(); return done2(code); };
         const size_t nchr = (size_t)p->nchr;
@@ -3132,6 +3221,11 @@ int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, in
                 d_ftrace.release();
             }
         }
+        if (sink.segments) {
+            (void)hipEventRecord(ctx->hist1[slot], s);
+            ctx->n_calls++;
+            return done3(segments_from_bits(p, d_bits.p, d_bchrs.p, bchrs, word_base, W, sink));
+        }
         if (!overlap)
             hipLaunchKernelGGL(cov_counts_from_bits_kernel, dim3((unsigned)((word_base[(size_t)p->nchr] + 255) / 256), (unsigned)p->nind),
                                dim3(256), 0, s, d_bits.p, d_bchrs.p, d_chrs.p, d_wbase.p, p->nchr, W, vec_ok ? 1 : 0, dst);
@@ -3179,6 +3273,47 @@ int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, in
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
     return done(GARLIC_OK);
+}
+
+int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
+                              int32_t weighted, int32_t M, double mu, double cutoff, int16_t *inwin,
+                              int32_t inwin_pitch_align, int32_t where)
+{
+    if (!p || !inwin) return fail(GARLIC_ERR_INVALID, "panel and inwin are required");
+    if (winsize <= 1 || inwin_pitch_align < 1) return fail(GARLIC_ERR_INVALID, "winsize must be > 1, inwin_pitch_align >= 1");
+    if (winsize > 32767) return fail(GARLIC_ERR_INVALID, "coverage counts are 16-bit: winsize <= 32767");
+    if (p->nind > 65535) return fail(GARLIC_ERR_INVALID, "coverage: at most 65535 individuals per call");
+    CovSink sink;
+    sink.inwin = inwin;
+    sink.inwin_pitch_align = inwin_pitch_align;
+    sink.where = where;
+    return coverage_impl(p, winsize, error, max_gap, use_gl, weighted, M, mu, cutoff, sink);
+}
+
+int garlic_roh_segments(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl, int32_t weighted,
+                        int32_t M, double mu, double cutoff, double overlap_frac, garlic_roh_segment *segments,
+                        int64_t capacity, int64_t *n_segments)
+{
+    if (!p || !n_segments) return fail(GARLIC_ERR_INVALID, "panel and n_segments are required");
+    if (capacity < 0 || (capacity > 0 && !segments)) return fail(GARLIC_ERR_INVALID, "segments: capacity without a buffer");
+    if (winsize <= 1) return fail(GARLIC_ERR_INVALID, "winsize must be > 1");
+    if (winsize > 32767) return fail(GARLIC_ERR_INVALID, "coverage counts are 16-bit: winsize <= 32767");
+    if (p->nind > 65535) return fail(GARLIC_ERR_INVALID, "coverage: at most 65535 individuals per call");
+    if (!(overlap_frac == overlap_frac)) return fail(GARLIC_ERR_INVALID, "overlap_frac is not a number");
+    *n_segments = 0;
+    // (the reference tells "a segment is open" by its first position being > 0: src/garlic-roh.cpp:493, 514)
+    if (p->have_map)
+        for (int c = 0; c < p->nchr; c++)
+            if (p->chr_nloci[c] > 0 && p->pos[(size_t)p->chr_off[c]] <= 0)
+                return fail(GARLIC_ERR_INVALID, "chromosome %d starts at position %d: ROH segments need positions >= 1", c,
+                            (int)p->pos[(size_t)p->chr_off[c]]);
+    CovSink sink;
+    sink.segments = true;
+    sink.overlap_frac = overlap_frac;
+    sink.segs = segments;
+    sink.cap = capacity;
+    sink.n_out = n_segments;
+    return coverage_impl(p, winsize, error, max_gap, use_gl, weighted, M, mu, cutoff, sink);
 }
 
 int garlic_panel_tgls_mode(garlic_panel *p, int32_t *mode, int32_t *terms_by)

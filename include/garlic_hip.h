@@ -43,8 +43,9 @@ extern "C" {
  * 4: garlic_device_alloc / garlic_device_free (score matrices), garlic_panel_chain_kind
  * 5: garlic_lod_feed_multi (the feeds of several window sizes in one call); garlic_panel_alloc_scores,
  *    garlic_device_alloc_stats, garlic_device_trim
- * 6: garlic_roh_coverage_fused (coverage counts without the score matrix) */
-#define GARLIC_HIP_ABI_VERSION 6
+ * 6: garlic_roh_coverage_fused (coverage counts without the score matrix)
+ * 7: garlic_roh_segments (the ROH segments of assembleROHWindows without scores or counts) */
+#define GARLIC_HIP_ABI_VERSION 7
 
 #define GARLIC_OK 0
 #define GARLIC_ERR_INVALID 1  /* bad argument (e.g. winsize <= 1: src/garlic-cli.cpp:433-442) */
@@ -304,6 +305,26 @@ int garlic_roh_coverage(garlic_panel *panel, const double *scores, int32_t pitch
 int garlic_roh_coverage_fused(garlic_panel *panel, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
                               int32_t weighted, int32_t M, double mu, double cutoff, int16_t *inwin,
                               int32_t inwin_pitch_align, int32_t where);
+
+/* The ROH segments themselves: assembleROHWindows (src/garlic-roh.cpp:409-545) from the panel to its
+ * rohData->start / stop lists, with neither the scores nor the coverage counts ever in memory.  The window bits come as
+ * for garlic_roh_coverage_fused (same arguments, same fallbacks); on the device they become "SNP is covered by at least
+ * OVERLAP_FRAC * winsize qualifying windows" bits (threshold clamped to [1, winsize], :421-423), and the four-branch
+ * walk over every individual's SNPs (:456-533) becomes: maximal stretches of such SNPs, cut where two neighbours are
+ * more than max_gap apart or straddle the centromere, kept when they hold at least the threshold's number of SNPs
+ * (and not begun at the chromosome's last SNP: the reference never closes such a segment).
+ *   segments[k] = {individual (panel-relative), chromosome (index in the panel), first SNP, last SNP}, SNP indices
+ *   chromosome-local and inclusive; the caller maps them to positions (physicalPos / geneticPos of :470-520).
+ *   Ordered by individual, chromosome, first SNP -- the order the reference appends them in.
+ * *n_segments is the number found; when it exceeds `capacity` nothing usable is in `segments` (call again with room;
+ * capacity 0 / segments NULL just counts).  A few MB for a 10M-SNP x 1250-individual shard, against 25 GB of counts.
+ * Positions must be >= 1 (the reference's "winStart > 0" means "a segment is open"). */
+typedef struct garlic_roh_segment {
+    int32_t ind, chr, start, stop;
+} garlic_roh_segment;
+int garlic_roh_segments(garlic_panel *panel, int32_t winsize, double error, int32_t max_gap, int32_t use_gl, int32_t weighted,
+                        int32_t M, double mu, double cutoff, double overlap_frac, garlic_roh_segment *segments,
+                        int64_t capacity, int64_t *n_segments);
 
 /* Introspection used by tests and the bench (device work of the last garlic_*_windows call). */
 typedef struct garlic_call_stats {

@@ -390,3 +390,45 @@ void oracle_roh_coverage(int nloci, int nind, const double *win, int winsize, do
     }
 }
 
+/* garlic-roh.cpp:456-533: the second half of assembleROHWindows for one individual row of coverage counts --
+ * SNPs whose count reaches OVERLAP_FRAC * winsize (clamped to [1, winsize], :421-423) are strung into
+ * segments, split where two neighbouring SNPs are more than max_gap apart or straddle the centromere,
+ * closed at the last SNP; a segment is reported when its SNP count reaches the same threshold.  The four
+ * branches in the reference's order, tests on winStart (a position) as written there: "< 0" for "none",
+ * "> 0" for "one is open".  Returns the number of segments; (start, stop) SNP indices, at most cap of them. */
+int oracle_roh_segments(int nloci, const int16_t *inwin, const int32_t *pos, int cStart, int cEnd, int winsize,
+                        int max_gap, double overlap_frac, int cap, int32_t *seg_start, int32_t *seg_stop)
+{
+    double thr = overlap_frac * winsize;
+    thr = (thr >= 1) ? thr : 1;
+    thr = (thr <= winsize) ? thr : winsize;
+    int n = 0;
+    int winStart = -1, winStartIndex = -1;
+    for (int w = 0; w < nloci; w++) {
+        int stopIndex = -2;
+        if (winStart < 0 && inwin[w] >= thr) {
+            winStart = pos[w];
+            winStartIndex = w;
+            continue;
+        } else if (inwin[w] >= thr && pair_breaks(pos, w - 1, w, max_gap, cStart, cEnd)) {
+            stopIndex = w - 1;
+        } else if (winStart > 0 && !(inwin[w] >= thr)) {
+            stopIndex = w - 1;
+        } else if (winStart > 0 && w + 1 >= nloci) {
+            stopIndex = w;
+        }
+        if (stopIndex == -2) continue;
+        if (stopIndex - winStartIndex + 1 >= thr) {
+            if (n < cap) { seg_start[n] = winStartIndex; seg_stop[n] = stopIndex; }
+            n++;
+        }
+        if (inwin[w] >= thr && stopIndex == w - 1) {     /* the second branch: the next segment starts here */
+            winStart = pos[w];
+            winStartIndex = w;
+        } else {
+            winStart = -1;
+            winStartIndex = -1;
+        }
+    }
+    return n;
+}

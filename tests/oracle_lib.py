@@ -71,6 +71,8 @@ def oracle():
         lib.oracle_flatten_subset.argtypes = [C.c_int, C.c_int, _dp, C.c_int, _ip, C.c_int, _dp]
         lib.oracle_roh_coverage.restype = None
         lib.oracle_roh_coverage.argtypes = [C.c_int, C.c_int, _dp, C.c_int, C.c_double, _sp]
+        lib.oracle_roh_segments.restype = C.c_int
+        lib.oracle_roh_segments.argtypes = [C.c_int, _sp, _ip, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _ip, _ip]
         lib.oracle_mask.restype = None
         lib.oracle_mask.argtypes = [C.c_int, _ip, C.c_int, C.c_int, C.c_int, C.c_int, _bp]
         _oracle = lib
@@ -220,6 +222,21 @@ def oracle_roh_coverage(win, W, cutoff):
     nind, nloci = win.shape
     out = np.empty((nind, nloci), dtype=np.int16)
     oracle().oracle_roh_coverage(nloci, nind, _p(win, _dp), W, cutoff, _p(out, _sp))
+    return out
+
+
+def oracle_roh_segments(inwin, pos, cS, cE, W, max_gap, overlap_frac):
+    """second half of assembleROHWindows on coverage counts [nind][nloci] -> [(individual, start index, stop index)]"""
+    inwin = np.ascontiguousarray(inwin, dtype=np.int16)
+    pos = np.ascontiguousarray(pos, dtype=np.int32)
+    nind, nloci = inwin.shape
+    a = np.empty(nloci + 1, dtype=np.int32)
+    b = np.empty(nloci + 1, dtype=np.int32)
+    out = []
+    for i in range(nind):
+        n = oracle().oracle_roh_segments(nloci, _p(inwin[i], _sp), _p(pos, _ip), cS, cE, W, max_gap, overlap_frac,
+                                         nloci + 1, _p(a, _ip), _p(b, _ip))
+        out += [(i, int(a[k]), int(b[k])) for k in range(n)]
     return out
 
 

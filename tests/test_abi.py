@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(abi.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert abi.lib().garlic_hip_abi_version() == abi.ABI_VERSION == 6
+    assert abi.lib().garlic_hip_abi_version() == abi.ABI_VERSION == 7
 
 
 def test_no_cpu_fallback_without_device():

@@ -489,3 +489,87 @@ def test_tgls_from_dictionary_codes(gpu_ctx):
             assert ol.bits_equal(np.ascontiguousarray(out[c]), want), c
         with pytest.raises(abi.GarlicError):      # a caller's table holds at most 256 values (one-byte codes)
             panel.set_gl_codes(codes[0], np.linspace(0.1, 0.9, 257))
+
+
+def _oracle_segments(chroms, scores, W, cutoff, mg, frac):
+    """the oracle's scores through the oracle's inWin[] loop and its restatement of the segment walk (pinned against the
+    real assembleROHWindows in tests/test_oracle_vs_ref.py) -> [(individual, chromosome, first SNP, last SNP)] in the
+    reference's order"""
+    out = []
+    for c, (g, f, p, cs, ce) in enumerate(chroms):
+        cov = ol.oracle_roh_coverage(np.ascontiguousarray(scores[c]), W, cutoff)
+        out += [(i, c, a, b) for i, a, b in ol.oracle_roh_segments(cov, p, cs, ce, W, mg, frac)]
+    return sorted(out)
+
+
+@pytest.mark.parametrize("W", [2, 30, 100, 250])
+def test_roh_segments_equal_the_oracles(gpu_ctx, W):
+    """garlic_roh_segments (unweighted --error scores): the segments of assembleROHWindows straight from the genotypes --
+    gaps and centromeres, chromosomes shorter than the window and around the 32-SNP words, ragged individual counts,
+    thresholds from one SNP to the whole window, a cutoff low enough for long segments and one below MISSING (the
+    scores path), capacity too small"""
+    rng = np.random.default_rng(470 + W)
+    mg = 200000
+    sizes = [5000, 1, max(1, W - 1), W, W + 3, 31, 32, 33, 2048 + W]
+    for nind in (1, 37, 130):
+        chroms = [ol.random_panel(rng, n, nind, max_gap=mg, gaps=3 if n > 1000 else 0) for n in sizes]
+        with abi.Panel(gpu_ctx, sizes, nind) as panel:
+            panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms])
+            panel.set_freq(np.concatenate([c[1] for c in chroms]))
+            panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+            scores = [ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg) for (g, f, p, cs, ce) in chroms]
+            total = 0
+            for cutoff in (0.0, -2.5, 3.0, -10000.0):
+                for frac in (1e-9, 0.25, 0.6, 1.0):
+                    want = _oracle_segments(chroms, scores, W, cutoff, mg, frac)
+                    got = panel.roh_segments(W, 0.001, mg, cutoff, frac)
+                    assert [tuple(int(v) for v in r) for r in got] == want, (W, nind, cutoff, frac, len(got), len(want))
+                    total += len(want)
+            assert total > 0
+            if len(want) > 1:
+                with pytest.raises(abi.GarlicError):
+                    panel.roh_segments(W, 0.001, mg, cutoff, frac, capacity=len(want) - 1)
+
+
+@pytest.mark.parametrize("W", [5, 40, 100])
+def test_roh_segments_weighted_and_with_likelihoods(gpu_ctx, W):
+    """garlic_roh_segments with --weighted (plain and with per-genotype likelihoods) and for unweighted scores with
+    likelihoods: the bits of the wLOD kernels / the TGLS chain into the same segment kernels"""
+    rng = np.random.default_rng(570 + W)
+    mg = 200000
+    sizes = [3000, max(1, W - 1), W + 3, 33, 700]
+    nind = 70
+    chroms = [ol.random_panel(rng, n, nind, max_gap=mg, gaps=2 if n > 1000 else 0) for n in sizes]
+    gpos = [c[2] * 1e-6 for c in chroms]
+    lds = [rng.uniform(1.0, max(2.0, W / 4.0), size=(n, W)) for n in sizes]
+    gl = [rng.choice([1e-16, 1e-3, 0.01, 0.2, 1.0], size=c[0].shape) for c in chroms]
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms],
+                      gpos=np.concatenate(gpos))
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        panel.set_ld(W, np.concatenate(lds, axis=0))
+        panel.set_gl(np.concatenate(gl, axis=0))
+        for weighted, use_gl in ((True, False), (True, True), (False, True)):
+            if weighted:
+                scores = [ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, 0.001, mg, 1e-9, 7, gl=gl[c] if use_gl else None)
+                          for c, (g, f, p, cs, ce) in enumerate(chroms)]
+            else:
+                scores = [ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg, gl=gl[c]) for c, (g, f, p, cs, ce) in enumerate(chroms)]
+            for cutoff in (0.0, -1.5):
+                for frac in (0.25, 1.0):
+                    want = _oracle_segments(chroms, scores, W, cutoff, mg, frac)
+                    got = panel.roh_segments(W, 0.001, mg, cutoff, frac, use_gl=use_gl, weighted=weighted)
+                    assert [tuple(int(v) for v in r) for r in got] == want, (W, weighted, use_gl, cutoff, frac, len(got), len(want))
+
+
+def test_roh_segments_refuses_a_chromosome_that_starts_at_position_zero(gpu_ctx):
+    rng = np.random.default_rng(3)
+    g, f, p, cs, ce = ol.random_panel(rng, 300, 5, max_gap=200000)
+    p = p - p[0]
+    with abi.Panel(gpu_ctx, [300], 5) as panel:
+        panel.set_map(p, [cs], [ce])
+        panel.set_freq(f)
+        panel.set_genotypes(g)
+        with pytest.raises(abi.GarlicError, match="positions >= 1"):
+            panel.roh_segments(20, 0.001, 200000, 0.0, 0.25)

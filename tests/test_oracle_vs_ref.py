@@ -159,8 +159,42 @@ def test_roh_coverage_through_the_reference_segments():
             mine = [(i, a, b) for i in range(nind)
                     for a, b in _segments_from_coverage(cov[i], pos, cS, cE, W, mg, frac)]
             assert mine == ref, (nloci, nind, W, frac)
+            # the C restatement the GPU tests use (SNP indices): the same segments
+            segs = ol.oracle_roh_segments(cov, pos, cS, cE, W, mg, frac)
+            assert [(i, float(pos[a]), float(pos[b])) for i, a, b in segs] == ref, (nloci, nind, W, frac)
             checked += len(ref)
     assert checked > 200
+
+
+def test_roh_segments_at_the_edges_of_the_state_machine():
+    """oracle_roh_segments against the real assembleROHWindows where its four branches meet: a qualifying last SNP
+    (a segment that begins there is never reported), a break right before the last SNP, breaks inside a stretch of
+    qualifying SNPs, a chromosome of one SNP, every SNP qualifying, thresholds of one SNP and of the whole window"""
+    rng = np.random.default_rng(5)
+    checked = 0
+    for trial in range(40):
+        nloci, nind, W = int(rng.integers(1, 70)), int(rng.integers(1, 4)), int(rng.integers(2, 9))
+        pos = np.cumsum(rng.integers(1, 3000, size=nloci)).astype(np.int32) + 1000
+        mg = 5000
+        for k in rng.integers(1, max(2, nloci), size=3):        # a few breaks, one of them often before the last SNP
+            if 0 < k < nloci:
+                pos[k:] += mg + 1
+        if nloci > 1 and trial % 3 == 0:
+            pos[-1:] += mg + 1
+        cS, cE = (int(pos[nloci // 2]) + 1, int(pos[nloci // 2]) + 2) if trial % 2 else (0, 0)
+        win = np.where(rng.random((nind, nloci)) < 0.7, 5.0, -5.0)
+        if trial % 4 == 0:
+            win[:] = 5.0
+        win[:, max(0, nloci - W + 1):] = ol.MISSING                # windows that do not fit hold no score
+        if nloci >= W:
+            win[:, nloci - W] = 5.0                                # the last window qualifies: the last SNP is covered
+        cov = ol.oracle_roh_coverage(win, W, 0.0)
+        for frac in (1e-9, 0.3, 1.0):
+            ref = ol.ref_assemble_roh(win, pos, cS, cE, 0.0, W, mg, frac)
+            segs = ol.oracle_roh_segments(cov, pos, cS, cE, W, mg, frac)
+            assert [(i, float(pos[a]), float(pos[b])) for i, a, b in segs] == ref, (trial, nloci, W, frac)
+            checked += len(ref)
+    assert checked > 100
 
 
 def test_genetic_map_interpolation_of_the_host_adapter(tmp_path):
