@@ -28,6 +28,7 @@ thinned feed; C4 / C5 per-GPU shard, 10M x 1250: unweighted, LD weights, wLOD, T
 and say so, once the run has used its time budget (--also-budget-s).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -353,7 +354,27 @@ def leg_ns(ctx, dev, steps):
                                                                "add-with-carry per window (10.1 instructions per window on the longest run's wave), the "
                                                                "second a plain pass over the bits; no 8 B per window of scores written, read or resident; "
                                                                "timed as the whole call (wall clock incl. its scratch allocations)")}
-    del cov, evs, cov8
+    # ... and past the counts: the ROH segments themselves (garlic_roh_segments: the bits become "SNP is covered by >=
+    # OVERLAP_FRAC x winsize qualifying windows" bits and a list of (individual, chromosome, first, last) -- all of
+    # assembleROHWindows on the device, a few MB to the host instead of 25 GB of counts)
+    seg_cap = 16_000_000
+    seg_buf = np.empty((seg_cap, 4), dtype=np.int32)
+    n_seg = ctypes.c_int64()
+    seg_args = (panel.handle, W, ERROR, MAX_GAP, 0, 0, M_GEN, MU, 2.5, 0.25, ctypes.c_void_p(seg_buf.ctypes.data), seg_cap, ctypes.byref(n_seg))
+    abi.check(abi.lib().garlic_roh_segments(*seg_args))
+    tsg = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        abi.check(abi.lib().garlic_roh_segments(*seg_args))
+        tsg.append(time.perf_counter() - t0)
+    res["roh_segments"] = {"call_ms": float(np.min(tsg)) * 1e3, "sliding_windows_per_s": win / float(np.min(tsg)),
+                           "n_segments": int(n_seg.value), "bytes_to_host": int(n_seg.value) * 16,
+                           "counts_bytes_it_replaces": int(tcov8) * 2, "cutoff": 2.5, "overlap_frac": 0.25,
+                           "note": "lod_bits_kernel + roh_mask_from_bits_kernel + roh_segments_from_mask_kernel + the list to the host, "
+                                   "sorted (wall clock of the whole call, best of 3); against roh_coverage_fused.call_ms, whose counts "
+                                   "would still have to cross PCIe and be walked per individual on the host"}
+    del cov, evs, cov8, seg_buf
     torch.cuda.empty_cache()      # 25 GB of counts: the likelihood legs below need the room
     # LD weights: integer pair counts (AND + popcount on bit planes) + W^2 ordered FP64 adds per window start
     for name, sub in (("ld_all_individuals", None),

@@ -146,6 +146,28 @@ struct garlic_ctx {
 static int score_alloc(garlic_ctx *ctx, size_t bytes, void **out);   // pooled score memory (below)
 static int score_free(garlic_ctx *ctx, void *ptr);
 
+// per-call scratch from the score pool (freed buffers stay mapped there: the next call's request costs no hipMalloc)
+template <class T> struct PoolBuf {
+    T *p = nullptr;
+    garlic_ctx *ctx = nullptr;
+    int reserve(garlic_ctx *c, size_t n)
+    {
+        release();
+        void *q = nullptr;
+        const int rc = score_alloc(c, std::max<size_t>(n, 1) * sizeof(T), &q);
+        if (rc) return rc;
+        p = (T *)q;
+        ctx = c;
+        return GARLIC_OK;
+    }
+    void release()
+    {
+        if (p) (void)score_free(ctx, p);
+        p = nullptr;
+    }
+};
+
+
 struct garlic_panel {
     garlic_ctx *ctx = nullptr;
     int32_t nchr = 0;
@@ -2921,15 +2943,16 @@ static int segments_from_bits(garlic_panel *p, const uint32_t *d_bits, const Chr
     const int64_t total_words = word_base[nchr];
     int64_t bit_words = 0;
     for (size_t c = 0; c < nchr; c++) bit_words = std::max<int64_t>(bit_words, bchrs[c].out_base + bchrs[c].out_pitch * p->nind);
-    DevBuf<uint32_t> d_mask, d_brk;
+    PoolBuf<uint32_t> d_mask;
+    PoolBuf<garlic_roh_segment> d_segs;
+    DevBuf<uint32_t> d_brk;
     DevBuf<int32_t> d_wbase;
-    DevBuf<garlic_roh_segment> d_segs;
     DevBuf<unsigned long long> d_count;
     auto done = [&](int code) { d_mask.release(); d_brk.release(); d_wbase.release(); d_segs.release(); d_count.release(); return code; };
     int rc;
     const int64_t cap = std::max<int64_t>(sink.cap, 0);
-    if ((rc = d_mask.reserve((size_t)std::max<int64_t>(bit_words, 1))) || (rc = d_brk.reserve((size_t)std::max<int64_t>(total_words, 1))) ||
-        (rc = d_wbase.reserve(word_base.size())) || (rc = d_segs.reserve((size_t)std::max<int64_t>(cap, 1))) || (rc = d_count.reserve(1)))
+    if ((rc = d_mask.reserve(ctx, (size_t)std::max<int64_t>(bit_words, 1))) || (rc = d_brk.reserve((size_t)std::max<int64_t>(total_words, 1))) ||
+        (rc = d_wbase.reserve(word_base.size())) || (rc = d_segs.reserve(ctx, (size_t)std::max<int64_t>(cap, 1))) || (rc = d_count.reserve(1)))
         return done(rc);
     hipError_t e = hipMemcpyAsync(d_wbase.p, word_base.data(), sizeof(int32_t) * word_base.size(), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_brk.p, 0, sizeof(uint32_t) * (size_t)std::max<int64_t>(total_words, 1), s);
@@ -2941,9 +2964,9 @@ static int segments_from_bits(garlic_panel *p, const uint32_t *d_bits, const Chr
         if (nb > 0)
             hipLaunchKernelGGL(roh_break_bits_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, p->d_boundaries.p, nb,
                                p->d_chr_off.p, d_wbase.p, p->nchr, d_brk.p);
-        const dim3 grid((unsigned)((total_words + 255) / 256), (unsigned)p->nind);
-        hipLaunchKernelGGL(roh_mask_from_bits_kernel, grid, dim3(256), 0, s, d_bits, d_bchrs, d_wbase.p, p->nchr, W, thr, d_mask.p);
-        hipLaunchKernelGGL(roh_segments_from_mask_kernel, grid, dim3(256), 0, s, d_mask.p, d_bchrs, d_brk.p, d_wbase.p, p->nchr, T,
+        const dim3 grid((unsigned)((total_words + 255) / 256), (unsigned)((p->nind + ROH_ROWS - 1) / ROH_ROWS));
+        hipLaunchKernelGGL(roh_mask_from_bits_kernel, grid, dim3(256), 0, s, d_bits, d_bchrs, d_wbase.p, p->nchr, p->nind, W, thr, d_mask.p);
+        hipLaunchKernelGGL(roh_segments_from_mask_kernel, grid, dim3(256), 0, s, d_mask.p, d_bchrs, d_brk.p, d_wbase.p, p->nchr, p->nind, T,
                            d_segs.p, (long long)cap, d_count.p);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&found, d_count.p, sizeof found, hipMemcpyDeviceToHost, s);
@@ -2989,11 +3012,11 @@ static int coverage_impl(garlic_panel *p, int32_t winsize, double error, int32_t
         int64_t boff = 0;
         if ((rc2 = coverage_bits_layout(p, bchrs, word_base, boff))) return rc2;
         for (int c = 0; c < p->nchr; c++) schrs[(size_t)c] = ChrDev{p->chr_off[c], L.base[c], L.pitch[c], p->chr_nloci[c], 0};
-        DevBuf<uint32_t> d_bits;
+        PoolBuf<uint32_t> d_bits;
         DevBuf<ChrDev> d_bchrs, d_schrs;
         DevBuf<int32_t> d_wbase;
         auto done = [&](int code) { d_bits.release(); d_bchrs.release(); d_schrs.release(); d_wbase.release(); return code; };
-        if ((rc2 = d_bits.reserve((size_t)std::max<int64_t>(boff, 1))) || (rc2 = d_bchrs.reserve(bchrs.size())) ||
+        if ((rc2 = d_bits.reserve(ctx, (size_t)std::max<int64_t>(boff, 1))) || (rc2 = d_bchrs.reserve(bchrs.size())) ||
             (rc2 = d_schrs.reserve(schrs.size())) || (rc2 = d_wbase.reserve(word_base.size())))
             return done(rc2);
         hipStream_t s2 = ctx->stream;
@@ -3019,12 +3042,12 @@ static int coverage_impl(garlic_panel *p, int32_t winsize, double error, int32_t
         const Layout Lo = make_layout(p, inwin_pitch_align, p->nind);
         std::vector<ChrDev> ochrs((size_t)p->nchr);
         for (int c = 0; c < p->nchr; c++) ochrs[(size_t)c] = ChrDev{p->chr_off[c], Lo.base[c], Lo.pitch[c], p->chr_nloci[c], 0};
-        DevBuf<uint32_t> d_bits;
+        PoolBuf<uint32_t> d_bits;
         DevBuf<ChrDev> d_bchrs, d_ochrs;
         DevBuf<int32_t> d_wbase;
         DevBuf<int16_t> d_cov;
         auto done = [&](int code) { d_bits.release(); d_bchrs.release(); d_ochrs.release(); d_wbase.release(); d_cov.release(); return code; };
-        if ((rc = d_bits.reserve((size_t)std::max<int64_t>(boff, 4))) || (rc = d_bchrs.reserve(bchrs.size())) ||
+        if ((rc = d_bits.reserve(ctx, (size_t)std::max<int64_t>(boff, 4))) || (rc = d_bchrs.reserve(bchrs.size())) ||
             (rc = d_ochrs.reserve(ochrs.size())) || (rc = d_wbase.reserve(word_base.size())))
             return done(rc);
         int16_t *dst = inwin;
@@ -3132,11 +3155,11 @@ static int coverage_impl(garlic_panel *p, int32_t winsize, double error, int32_t
             if (words * 4 * (int64_t)p->nind >= (int64_t)1 << 32)
                 return done(fail(GARLIC_ERR_INVALID, "chromosome %d: bit rows beyond 32-bit offsets", c));
         }
-        DevBuf<uint32_t> d_bits;
+        PoolBuf<uint32_t> d_bits;
         DevBuf<ChrDev> d_bchrs;
         DevBuf<int32_t> d_wbase;
         auto done2 = [&](int code) { d_bits.release(); d_bchrs.release(); d_wbase.release(); return done(code); };
-        if ((rc = d_bits.reserve((size_t)std::max<int64_t>(boff, 1))) || (rc = d_bchrs.reserve(bchrs.size())) ||
+        if ((rc = d_bits.reserve(ctx, (size_t)std::max<int64_t>(boff, 1))) || (rc = d_bchrs.reserve(bchrs.size())) ||
             (rc = d_wbase.reserve(word_base.size())))
             return done2(rc);
         e = hipMemcpyAsync(d_bchrs.p, bchrs.data(), sizeof(ChrDev) * bchrs.size(), hipMemcpyHostToDevice, s);

@@ -58,33 +58,44 @@ roh_break_bits_kernel(const int64_t *__restrict__ boundaries, int n, const int64
 }
 
 // r bits: thread per (individual, 32-SNP word); the count in front of the word by popcounts, then bit in / bit out
+constexpr int ROH_ROWS = 8;      // individuals per workgroup: a launch of one workgroup per 256 words and row runs at the dispatcher's pace
+
 __global__ void __launch_bounds__(256)
 roh_mask_from_bits_kernel(const uint32_t *__restrict__ bits, const ChrDev *__restrict__ bchrs,
-                          const int32_t *__restrict__ word_base, int nchr, int W, int thr, uint32_t *__restrict__ mask)
+                          const int32_t *__restrict__ word_base, int nchr, int nind, int W, int thr, uint32_t *__restrict__ mask)
 {
     const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (g >= word_base[nchr]) return;
     int chr = 0;
     while (chr + 1 < nchr && g >= word_base[chr + 1]) chr++;
     const ChrDev bc = bchrs[chr];
-    const int t = g - word_base[chr], nwords = (bc.nloci + 31) >> 5, row = blockIdx.y;
-    const uint32_t *brow = bits + bc.out_base + (int64_t)row * bc.out_pitch;
-    auto word = [&](int x) -> uint32_t { return (x >= 0 && x < nwords) ? brow[x] : 0u; };
-    const uint32_t cur = word(t);
+    const int t = g - word_base[chr], nwords = (bc.nloci + 31) >> 5;
     const int rel = 32 * t - W, dA = rel >> 5, r = rel & 31;          // bit 32 t - W sits in word dA at bit r (floor)
-    const uint32_t wA = word(dA);
-    const uint32_t F = __builtin_amdgcn_alignbit(word(dA + 1), wA, (uint32_t)r);      // bit j = window 32 t - W + j
-    int cnt = __popc(wA >> r);                                        // windows 32 t - W .. 32 t - 1
-    for (int x = dA + 1; x < t; x++) cnt += __popc(word(x));
-    uint32_t m = 0;
-#pragma unroll
-    for (int j = 0; j < 32; j++) {
-        cnt += (int)((cur >> j) & 1u) - (int)((F >> j) & 1u);
-        m |= (cnt >= thr) ? (1u << j) : 0u;
-    }
     const int left = bc.nloci - 32 * t;                                // SNPs of the chromosome in this word
-    if (left < 32) m &= (1u << left) - 1u;
-    mask[bc.out_base + (int64_t)row * bc.out_pitch + t] = m;
+    const int row_end = min(nind, ((int)blockIdx.y + 1) * ROH_ROWS);
+    for (int row = (int)blockIdx.y * ROH_ROWS; row < row_end; row++) {
+        const uint32_t *brow = bits + bc.out_base + (int64_t)row * bc.out_pitch;
+        auto word = [&](int x) -> uint32_t { return (x >= 0 && x < nwords) ? brow[x] : 0u; };
+        const uint32_t cur = word(t);
+        const uint32_t wA = word(dA);
+        const uint32_t F = __builtin_amdgcn_alignbit(word(dA + 1), wA, (uint32_t)r);      // bit j = window 32 t - W + j
+        int cnt = (int)__popc(wA >> r);                               // windows 32 t - W .. 32 t - 1
+        for (int x = dA + 1; x < t; x++) cnt += (int)__popc(word(x));
+        // inside the word the count moves between cnt - popc(F) and cnt + popc(cur): most words are decided by that alone
+        // (SNPs far from any qualifying window, or deep inside a stretch of them); the others walk their 32 steps
+        uint32_t m = 0;
+        if (cnt - (int)__popc(F) >= thr) {      // (__popc returns unsigned)
+            m = ~0u;
+        } else if (cnt + (int)__popc(cur) >= thr) {
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                cnt += (int)((cur >> j) & 1u) - (int)((F >> j) & 1u);
+                m |= (cnt >= thr) ? (1u << j) : 0u;
+            }
+        }
+        if (left < 32) m &= (1u << left) - 1u;
+        mask[bc.out_base + (int64_t)row * bc.out_pitch + t] = m;
+    }
 }
 
 // first / last SNPs of the segments inside word t of a row: start = r & (!r[w-1] | break[w]), end = r & (!r[w+1] | break[w+1])
@@ -96,7 +107,7 @@ __device__ __forceinline__ uint32_t roh_start_bits(const uint32_t *mrow, const u
 
 __global__ void __launch_bounds__(256)
 roh_segments_from_mask_kernel(const uint32_t *__restrict__ mask, const ChrDev *__restrict__ bchrs,
-                              const uint32_t *__restrict__ brk, const int32_t *__restrict__ word_base, int nchr,
+                              const uint32_t *__restrict__ brk, const int32_t *__restrict__ word_base, int nchr, int nind,
                               double T, garlic_roh_segment *__restrict__ segs, long long cap, unsigned long long *__restrict__ count)
 {
     const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -104,29 +115,34 @@ roh_segments_from_mask_kernel(const uint32_t *__restrict__ mask, const ChrDev *_
     int chr = 0;
     while (chr + 1 < nchr && g >= word_base[chr + 1]) chr++;
     const ChrDev bc = bchrs[chr];
-    const int t = g - word_base[chr], nwords = (bc.nloci + 31) >> 5, row = blockIdx.y;
-    const uint32_t *mrow = mask + bc.out_base + (int64_t)row * bc.out_pitch;
+    const int t = g - word_base[chr], nwords = (bc.nloci + 31) >> 5;
     const uint32_t *b = brk + word_base[chr];
-    const uint32_t R = mrow[t];
-    if (!R) return;
-    const uint32_t next = t + 1 < nwords ? (mrow[t + 1] & 1u) : 0u, bnext = t + 1 < nwords ? (b[t + 1] & 1u) : 0u;
-    uint32_t end = R & (~((R >> 1) | (next << 31)) | ((b[t] >> 1) | (bnext << 31)));
-    const uint32_t start_here = roh_start_bits(mrow, b, t);
-    while (end) {
-        const int e = __builtin_ctz(end);
-        end &= end - 1;
-        // the segment's first SNP: the highest start bit at or below e, in this word or in one before it
-        int x = t;
-        uint32_t s_bits = start_here & (e == 31 ? ~0u : ((2u << e) - 1u));
-        while (!s_bits && x > 0) {     // (every word between is all ones: a stretch of r = 1 has a first SNP)
-            x--;
-            s_bits = roh_start_bits(mrow, b, x);
-        }
-        const int s = 32 * x + 31 - __builtin_clz(s_bits), stop = 32 * t + e;
-        const int len = stop - s + 1;
-        if ((double)len >= T && s != bc.nloci - 1) {
-            const unsigned long long slot = atomicAdd(count, 1ull);
-            if ((long long)slot < cap) segs[slot] = garlic_roh_segment{row, chr, s, stop};
+    const uint32_t bt = b[t], bnext = t + 1 < nwords ? (b[t + 1] & 1u) : 0u;
+    const int row_end = min(nind, ((int)blockIdx.y + 1) * ROH_ROWS);
+    for (int row = (int)blockIdx.y * ROH_ROWS; row < row_end; row++) {
+        const uint32_t *mrow = mask + bc.out_base + (int64_t)row * bc.out_pitch;
+        const uint32_t R = mrow[t];
+        if (!R) continue;
+        const uint32_t next = t + 1 < nwords ? (mrow[t + 1] & 1u) : 0u;
+        uint32_t end = R & (~((R >> 1) | (next << 31)) | ((bt >> 1) | (bnext << 31)));
+        if (!end) continue;
+        const uint32_t start_here = roh_start_bits(mrow, b, t);
+        while (end) {
+            const int e = __builtin_ctz(end);
+            end &= end - 1;
+            // the segment's first SNP: the highest start bit at or below e, in this word or in one before it
+            int x = t;
+            uint32_t s_bits = start_here & (e == 31 ? ~0u : ((2u << e) - 1u));
+            while (!s_bits && x > 0) {     // (every word between is all ones: a stretch of r = 1 has a first SNP)
+                x--;
+                s_bits = roh_start_bits(mrow, b, x);
+            }
+            const int s = 32 * x + 31 - __builtin_clz(s_bits), stop = 32 * t + e;
+            const int len = stop - s + 1;
+            if ((double)len >= T && s != bc.nloci - 1) {
+                const unsigned long long slot = atomicAdd(count, 1ull);
+                if ((long long)slot < cap) segs[slot] = garlic_roh_segment{row, chr, s, stop};
+            }
         }
     }
 }

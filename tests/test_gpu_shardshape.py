@@ -137,6 +137,23 @@ def test_10M_by_1250_every_variant(gpu_ctx):
             w0 = ol.oracle_flatten(lod_want[c][:1], W)
             assert ol.bits_equal(feed_all[off:off + w0.shape[0]], w0), c
             off += int(per_all[c])
+
+        # ---- the final pass without scores or counts: ROH segments straight from the genotypes (garlic_roh_segments);
+        #      the sampled individuals' segments against the oracle's walk over the oracle's counts of the oracle's scores
+        cutoff, frac = 2.5, 0.25
+        segs = panel.roh_segments(W, ERR, MG, cutoff, frac)
+        assert segs.shape[0] > nind and (np.diff(segs[:, 0]) >= 0).all()
+        n_checked = 0
+        for c in range(spec.nchr):
+            lo, hi, fp, cen = chrom_args(spec, c)
+            cov = ol.oracle_roh_coverage(lod_want[c], W, cutoff)
+            want_segs = ol.oracle_roh_segments(cov, fp[1], *cen, W, MG, frac)
+            for k, i in enumerate(sample):
+                got = [(int(a), int(b)) for _, _, a, b in segs[(segs[:, 0] == i) & (segs[:, 1] == c)]]
+                assert got == [(a, b) for kk, a, b in want_segs if kk == k], ("roh segments", c, i)
+                n_checked += len(got)
+        assert n_checked > 20
+        del segs
         lod_want.clear()
 
         # ---- LD weights from a 500-individual subsample (--ld-subsample 500), on the device
