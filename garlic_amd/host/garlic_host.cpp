@@ -1153,6 +1153,95 @@ DoubleData *LodEngine::lodFeed(int winsize, double error, int MAX_GAP, int step,
     return d;
 }
 
+// ---- ROH calls
+std::vector<ROHData *> *initROHData(IndData *indData)
+{
+    auto *v = new std::vector<ROHData *>;
+    for (int ind = 0; ind < indData->nind; ind++) v->push_back(new ROHData);
+    return v;
+}
+
+void releaseROHData(std::vector<ROHData *> *rohDataByInd)
+{
+    if (!rohDataByInd) return;
+    for (ROHData *r : *rohDataByInd) delete r;
+    rohDataByInd->clear();
+    delete rohDataByInd;
+}
+
+ROHLength *initROHLength(int size, std::string pop)
+{
+    ROHLength *r = new ROHLength;
+    r->pop = pop;
+    r->length = new double[size > 0 ? size : 1];
+    r->size = size;
+    return r;
+}
+
+void releaseROHLength(ROHLength *rohLength)
+{
+    if (!rohLength) return;
+    delete[] rohLength->length;
+    delete rohLength;
+}
+
+// assembleROHWindows, garlic-roh.cpp:409-545: the device returns every segment as (individual, chromosome, first SNP,
+// last SNP) in the reference's order; positions, sizes and the pooled length list are filled in here as :470-520 do
+// (size in cM from geneticPos with CM, else stop - start + 1 in bp; start / stop are the SNPs' physical positions)
+std::vector<ROHData *> *LodEngine::assembleROHWindows(IndData *indData, double lodScoreCutoff, ROHLength **rohLength,
+                                                      int winSize, double error, int MAX_GAP, double OVERLAP_FRAC, bool CM,
+                                                      bool weighted, int M, double mu)
+{
+    if (!indData || indData->nind != impl->nind) fail("assembleROHWindows: IndData does not match the panel");
+    std::cerr << "Assembling ROH windows on the device (winsize " << winSize << ").\n";
+    const size_t ns = impl->shards.size();
+    std::vector<std::vector<garlic_roh_segment>> segs(ns);
+    std::vector<std::string> errors(ns);
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < ns; k++)
+        th.emplace_back([&, k] {
+            auto &s = impl->shards[k];
+            int64_t n = 0;
+            // a first guess of room for 64 segments per individual; the call says how many there are
+            segs[k].resize((size_t)std::max<int64_t>(1024, 64 * (int64_t)s.nind));
+            for (int attempt = 0; attempt < 2; attempt++) {
+                if (garlic_roh_segments(s.panel, winSize, error, MAX_GAP, impl->use_gl, weighted, M, mu, lodScoreCutoff, OVERLAP_FRAC,
+                                        segs[k].data(), (int64_t)segs[k].size(), &n) != GARLIC_OK) {
+                    errors[k] = garlic_hip_last_error();
+                    return;
+                }
+                if (n <= (int64_t)segs[k].size()) break;
+                segs[k].resize((size_t)n);
+            }
+            segs[k].resize((size_t)n);
+        });
+    for (auto &t : th) t.join();
+    for (auto &e : errors)
+        if (!e.empty()) fail("garlic_roh_segments: " + e);
+    std::vector<ROHData *> *rohDataByInd = initROHData(indData);
+    std::vector<double> lengths;
+    for (size_t k = 0; k < ns; k++) {           // shards hold the individuals in order, each list is sorted by individual
+        const auto &s = impl->shards[k];
+        for (const garlic_roh_segment &g : segs[k]) {
+            const MapData *map = impl->maps->at((size_t)g.chr);
+            ROHData *r = rohDataByInd->at((size_t)(s.ind_begin + g.ind));
+            const int winStart = map->physicalPos[g.start], winStop = map->physicalPos[g.stop];
+            const double size = CM ? map->geneticPos[g.stop] - map->geneticPos[g.start] : winStop - winStart + 1;
+            lengths.push_back(size);
+            r->length.push_back(size);
+            r->chr.push_back(g.chr);
+            r->start.push_back(winStart);
+            r->stop.push_back(winStop);
+        }
+    }
+    for (int ind = 0; ind < indData->nind; ind++) rohDataByInd->at((size_t)ind)->indID = indData->indID[ind];
+    ROHLength *rl = initROHLength((int)lengths.size(), indData->pop);
+    for (size_t i = 0; i < lengths.size(); i++) rl->length[i] = lengths[i];
+    if (rohLength) *rohLength = rl;
+    else releaseROHLength(rl);
+    return rohDataByInd;
+}
+
 // The callers that sweep window sizes on one data set -- exploreWinsizes (garlic-roh.cpp:726-751), selectWinsize
 // (:798-837), selectWinsizeFromList (:881-920) -- through garlic_lod_feed_multi: unweighted --error scores, the thinning
 // step of a size is the size itself (convertWinData2DoubleData(.., winsize), :735,743,817,900) unless `steps` says otherwise.

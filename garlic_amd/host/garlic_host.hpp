@@ -178,6 +178,22 @@ void loadGenotypeCache(const std::string &path, int &numLoci, int &numInd,
                        std::vector<FreqData *> **freqDataByChr,
                        bool keepPacked = false);   // keepPacked: HapData::packed instead of ::data
 
+// ---- ROH calls (src/garlic-roh.h:43-57)
+struct ROHData {
+    std::string indID;
+    std::vector<int> chr;
+    std::vector<double> start, stop, length;
+};
+struct ROHLength {
+    std::string pop;
+    double *length;
+    double size;
+};
+std::vector<ROHData *> *initROHData(IndData *indData);                 // garlic-roh.cpp:387-397
+void releaseROHData(std::vector<ROHData *> *rohDataByInd);             // :399-407
+ROHLength *initROHLength(int size, std::string pop);                   // :547-554
+void releaseROHLength(ROHLength *rohLength);                           // :556-560
+
 // ---- the path (drop-in signatures)
 struct LodOptions {
     std::vector<int> devices;   // HIP device ordinals; empty = {0}.  Individuals shard contiguously.
@@ -247,6 +263,13 @@ public:
     std::vector<DoubleData *> lodFeedMulti(const std::vector<int> &winsizes, double error, int MAX_GAP,
                                            const std::vector<int> *steps = nullptr,
                                            const std::vector<int> *kdeSubsample = nullptr);
+    // assembleROHWindows (garlic-roh.cpp:409-545) for the resident panel, from the genotypes to rohData->start / stop /
+    // length without the window scores or the per-SNP coverage counts in memory (garlic_roh_segments): what main needs of
+    // calcLODWindows + assembleROHWindows when --raw-lod is not asked for (garlic-main.cpp:346-420).  Same arguments as
+    // the reference's function after the data; weighted: wLOD from the resident LD weights (ldWeights).
+    std::vector<ROHData *> *assembleROHWindows(IndData *indData, double lodScoreCutoff, ROHLength **rohLength, int winSize,
+                                               double error, int MAX_GAP, double OVERLAP_FRAC, bool CM, bool weighted = false,
+                                               int M = 0, double mu = 0.0);
     LodEngine(const LodEngine &) = delete;
     LodEngine &operator=(const LodEngine &) = delete;
 

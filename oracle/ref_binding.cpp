@@ -8,8 +8,11 @@
 //     vector<HapData*>* .. centromere* and return a vector<WinData*>* made by the reference's initWinData, which the
 //     reference's releaseWinData (src/garlic-data.cpp:1640-1667) frees.  INTEGRATION.md's code block is generated
 //     from the marked region below (tools/gen_integration.py), so the two cannot drift;
+//   * hip_assembleROHWindows is what main would call for calcLODWindows + assembleROHWindows (:409-545) when the raw
+//     scores are not asked for: the ROH segments straight from the device (garlic_roh_segments);
 //   * refbind_compare_* build the reference's structs from flat arrays, run the reference's calcLODWindows /
-//     calcwLODWindows and the binding on the SAME objects and memcmp the WinData rows.
+//     calcwLODWindows (/ assembleROHWindows on its scores) and the binding on the SAME objects and memcmp the WinData
+//     rows (the ROHData lists).
 #include "garlic-roh.h"
 #include "garlic-data.h"
 #include "garlic-centromeres.h"
@@ -105,6 +108,38 @@ vector< WinData * > *hip_calcwLODWindows(vector< HapData * > *hapDataByChr, vect
             flat.insert(flat.end(), ldDataByChr->at(c)->LD[l], ldDataByChr->at(c)->LD[l] + winsize);
     if (garlic_panel_set_ld(h.panel, winsize, flat.data(), GARLIC_HOST)) throw 0;
     return hip_download(h, mapDataByChr, hapDataByChr->at(0)->nind, true, winsize, error, MAX_GAP, USE_GL, M, mu);
+}
+
+// garlic-main.cpp:346-420 -- when --raw-lod is not asked for, calcLODWindows + assembleROHWindows (garlic-roh.cpp:409-545)
+// become one call: the device goes from the genotypes to the ROH segments, neither the window scores nor the per-SNP
+// coverage counts exist anywhere.  Same results as assembleROHWindows(calcLODWindows(..), ..): rohData per individual,
+// the pooled lengths in the order the reference appends them.
+vector< ROHData * > *hip_assembleROHWindows(vector< HapData * > *hapDataByChr, vector< FreqData * > *freqDataByChr,
+                                            vector< MapData * > *mapDataByChr, vector< GenoLikeData * > *GLDataByChr,
+                                            IndData *indData, centromere *centro, double lodScoreCutoff, ROHLength **rohLength,
+                                            int winSize, double error, int MAX_GAP, double OVERLAP_FRAC, bool CM, bool USE_GL)
+{
+    HipPanel h;
+    hip_upload(h, hapDataByChr, freqDataByChr, mapDataByChr, GLDataByChr, centro, USE_GL, false);
+    int64_t n = 0;
+    if (garlic_roh_segments(h.panel, winSize, error, MAX_GAP, USE_GL, 0, 0, 0.0, lodScoreCutoff, OVERLAP_FRAC, NULL, 0, &n)) throw 0;
+    vector<garlic_roh_segment> seg((size_t)(n > 0 ? n : 1));
+    if (garlic_roh_segments(h.panel, winSize, error, MAX_GAP, USE_GL, 0, 0, 0.0, lodScoreCutoff, OVERLAP_FRAC, seg.data(), n, &n)) throw 0;
+    vector< ROHData * > *rohDataByInd = initROHData(indData);           // garlic-roh.cpp:387
+    for (int ind = 0; ind < indData->nind; ind++) rohDataByInd->at(ind)->indID = indData->indID[ind];
+    (*rohLength) = initROHLength((int)n, indData->pop);                 // :535-541
+    for (int64_t k = 0; k < n; k++) {                                    // ordered by individual, chromosome, position
+        MapData *mapData = mapDataByChr->at(seg[k].chr);
+        ROHData *rohData = rohDataByInd->at(seg[k].ind);
+        const int winStart = mapData->physicalPos[seg[k].start], winStop = mapData->physicalPos[seg[k].stop];
+        const double size = CM ? mapData->geneticPos[seg[k].stop] - mapData->geneticPos[seg[k].start] : winStop - winStart + 1;
+        (*rohLength)->length[k] = size;
+        rohData->length.push_back(size);
+        rohData->chr.push_back(seg[k].chr);
+        rohData->start.push_back(winStart);
+        rohData->stop.push_back(winStop);
+    }
+    return rohDataByInd;
 }
 // INTEGRATION-END
 
@@ -230,6 +265,53 @@ REF_API long refbind_compare_wlod(int nchr, const int *chr_nloci, int nind, cons
                                                         gl != NULL, M, mu, numThreads);
         releaseLDData(ld);
         return (long)compare_and_release(ref, mine);
+    } catch (...) {
+        return -1;
+    }
+}
+
+// calcLODWindows + assembleROHWindows of the reference against hip_assembleROHWindows on the same structs: the number of
+// differences over every individual's chr / start / stop / length lists and the pooled length list (0 = identical;
+// *n_segments: how many segments the reference reported), -1 if either threw
+REF_API long refbind_compare_roh(int nchr, const int *chr_nloci, int nind, const short *geno, const double *freq,
+                                 const int *pos, const double *gpos, const int *cStart, const int *cEnd, const double *gl,
+                                 int winsize, double error, int max_gap, double cutoff, double overlap_frac, int cm,
+                                 long *n_segments)
+{
+    StderrSilencer quiet;
+    try {
+        RefData d;
+        build(d, nchr, chr_nloci, nind, geno, freq, pos, gpos, cStart, cEnd, gl);
+        IndData ind;
+        ind.pop = "POP";
+        ind.nind = nind;
+        ind.indID = new string[nind];
+        for (int i = 0; i < nind; i++) ind.indID[i] = "ind" + std::to_string(i);
+        vector< WinData * > *win = calcLODWindows(d.hap, d.frq, d.map, d.gl, d.centro, winsize, error, max_gap, gl != NULL);
+        ROHLength *lenRef = NULL, *lenMine = NULL;
+        vector< ROHData * > *ref = assembleROHWindows(win, d.map, &ind, d.centro, cutoff, &lenRef, winsize, max_gap, overlap_frac, cm != 0);
+        releaseWinData(win);
+        vector< ROHData * > *mine = hip_assembleROHWindows(d.hap, d.frq, d.map, d.gl, &ind, d.centro, cutoff, &lenMine, winsize,
+                                                          error, max_gap, overlap_frac, cm != 0, gl != NULL);
+        long bad = (lenRef->size == lenMine->size) ? 0 : 1;
+        for (int k = 0; k < (int)lenRef->size && k < (int)lenMine->size; k++) bad += memcmp(&lenRef->length[k], &lenMine->length[k], sizeof(double)) != 0;
+        bad += lenRef->pop != lenMine->pop;
+        for (int i = 0; i < nind; i++) {
+            ROHData *a = ref->at(i), *b = mine->at(i);
+            bad += a->indID != b->indID;
+            bad += a->chr != b->chr;
+            bad += a->start != b->start;
+            bad += a->stop != b->stop;
+            bad += a->length.size() != b->length.size() ||
+                   (a->length.size() && memcmp(a->length.data(), b->length.data(), sizeof(double) * a->length.size()) != 0);
+        }
+        if (n_segments) *n_segments = (long)lenRef->size;
+        releaseROHData(ref);
+        releaseROHData(mine);
+        releaseROHLength(lenRef);
+        releaseROHLength(lenMine);
+        delete [] ind.indID;
+        return bad;
     } catch (...) {
         return -1;
     }

@@ -37,9 +37,10 @@ def test_binding_compiles_against_the_reference_headers_and_links(tmp_path):
     so = out / "libgarlic_ref_hip.so"
     assert so.exists()
     syms = subprocess.run(["nm", "-D", "--defined-only", str(so)], capture_output=True, text=True).stdout
-    assert "refbind_compare_lod" in syms and "refbind_compare_wlod" in syms
+    assert "refbind_compare_lod" in syms and "refbind_compare_wlod" in syms and "refbind_compare_roh" in syms
     undefined = subprocess.run(["nm", "-D", "--undefined-only", str(so)], capture_output=True, text=True).stdout
     assert "garlic_lod_windows" in undefined and "garlic_wlod_windows" in undefined   # from libgarlic_hip.so, nothing stubbed
+    assert "garlic_roh_segments" in undefined
 
 
 def _lib():
@@ -50,6 +51,9 @@ def _lib():
     lib.refbind_compare_wlod.restype = C.c_long
     lib.refbind_compare_wlod.argtypes = [C.c_int, i32p, C.c_int, i16p, f64p, i32p, f64p, i32p, i32p, f64p, C.c_int, C.c_double,
                                          C.c_int, C.c_int, C.c_double, C.c_int]
+    lib.refbind_compare_roh.restype = C.c_long
+    lib.refbind_compare_roh.argtypes = [C.c_int, i32p, C.c_int, i16p, f64p, i32p, f64p, i32p, i32p, f64p, C.c_int, C.c_double,
+                                        C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_long)]
     return lib
 
 
@@ -83,3 +87,35 @@ def test_binding_equals_the_reference_on_the_references_own_structs():
                                            _p(pos, C.c_int32), _p(gpos, C.c_double), _p(cs, C.c_int32), _p(ce, C.c_int32),
                                            _p(use_gl, C.c_double), W, 0.001, mg, 7, 1e-9, 3)
             assert bad == 0, ("calcwLODWindows", sizes, W, use_gl is not None, bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(SO), reason="oracle/_ref/libgarlic_ref_hip.so is built in the build container (make -C oracle ref)")
+def test_roh_binding_equals_the_references_calcLODWindows_plus_assembleROHWindows():
+    """The reference's calcLODWindows -> assembleROHWindows and the binding's one call (garlic_roh_segments) on the same
+    vector<HapData*>* .. IndData*: every individual's chr / start / stop / length lists and the pooled ROHLength, in bp
+    and in cM, with and without likelihoods, thresholds from one SNP to the whole window"""
+    rng = np.random.default_rng(808)
+    lib = _lib()
+    mg = 200000
+    total = 0
+    for sizes, nind, W in (([900, 90, 33], 45, 30), ([500, 260], 70, 12), ([150], 3, 2)):
+        chroms = [ol.random_panel(rng, n, nind, max_gap=mg, gaps=2 if n > 300 else 0) for n in sizes]
+        nl = np.array(sizes, dtype=np.int32)
+        geno = np.ascontiguousarray(np.concatenate([c[0] for c in chroms], axis=0), dtype=np.int16)
+        freq = np.ascontiguousarray(np.concatenate([c[1] for c in chroms]))
+        pos = np.ascontiguousarray(np.concatenate([c[2] for c in chroms]), dtype=np.int32)
+        gpos = np.ascontiguousarray(pos.astype(np.float64) * 1.3e-6)
+        cs = np.array([c[3] for c in chroms], dtype=np.int32)
+        ce = np.array([c[4] for c in chroms], dtype=np.int32)
+        cs[-1] = -1
+        gl = np.ascontiguousarray(rng.choice([1e-3, 0.01, 0.2, 10 ** -3.7], size=geno.shape))
+        for use_gl in (None, gl):
+            for cutoff, frac, cm in ((0.0, 0.25, 0), (-1.0, 1e-9, 1), (0.5, 1.0, 0), (-3.0, 0.6, 1)):
+                n = C.c_long(0)
+                bad = lib.refbind_compare_roh(len(sizes), _p(nl, C.c_int32), nind, _p(geno, C.c_int16), _p(freq, C.c_double),
+                                              _p(pos, C.c_int32), _p(gpos, C.c_double), _p(cs, C.c_int32), _p(ce, C.c_int32),
+                                              _p(use_gl, C.c_double), W, 0.001, mg, cutoff, frac, cm, C.byref(n))
+                assert bad == 0, ("assembleROHWindows", sizes, W, use_gl is not None, cutoff, frac, cm, bad)
+                total += n.value
+    assert total > 300
