@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <iostream>
 #include <sstream>
 #include <random>
@@ -1183,6 +1184,37 @@ void releaseROHLength(ROHLength *rohLength)
     if (!rohLength) return;
     delete[] rohLength->length;
     delete rohLength;
+}
+
+// garlic-roh.cpp:574-648
+void writeROHData(const std::string &outfile, std::vector<ROHData *> *rohDataByInd, std::vector<MapData *> *mapDataByChr,
+                  const std::vector<double> &bounds, const std::string &popName, const std::string &version, bool CM)
+{
+    static const char *colors[9] = {"228,26,28", "77,175,74", "55,126,184", "152,78,163", "255,127,0",
+                                    "255,255,51", "166,86,40", "247,129,191", "153,153,153"};
+    std::ofstream out(outfile.c_str());
+    if (out.fail()) fail("Failed to open " + outfile);
+    for (size_t ind = 0; ind < rohDataByInd->size(); ind++) {
+        const ROHData *rohData = rohDataByInd->at(ind);
+        out << "track name=\"Ind: " + rohData->indID + " Pop:" + popName + " ROH\" description=\"Ind: " + rohData->indID +
+                   " Pop:" + popName + " ROH from GARLIC v" + version + "\" visibility=2 itemRgb=\"On\"\n";
+        for (size_t roh = 0; roh < rohData->chr.size(); roh++) {
+            const double size = rohData->length[roh];
+            // the first boundary the size lies below names the class (A, B, ..); past the last one: the next letter
+            size_t i = 0;
+            while (i < bounds.size() && !(size < bounds[i])) i++;
+            const char sizeClass = (char)('A' + i);
+            const char *color = colors[i <= 8 ? i : 8];
+            std::string chr = mapDataByChr->at((size_t)rohData->chr[roh])->chr;
+            if (chr[0] != 'c' && chr[0] != 'C') chr = "chr" + chr;
+            out << chr << "\t" << int(rohData->start[roh]) << "\t" << int(rohData->stop[roh]) << "\t" << sizeClass << "\t";
+            if (CM) out << size;
+            else out << int(size);
+            out << "\t.\t0\t0\t" << color << std::endl;
+        }
+    }
+    out.close();
+    std::cerr << "ROH calls: " << outfile << "\n";
 }
 
 // assembleROHWindows, garlic-roh.cpp:409-545: the device returns every segment as (individual, chromosome, first SNP,

@@ -193,6 +193,10 @@ std::vector<ROHData *> *initROHData(IndData *indData);                 // garlic
 void releaseROHData(std::vector<ROHData *> *rohDataByInd);             // :399-407
 ROHLength *initROHLength(int size, std::string pop);                   // :547-554
 void releaseROHLength(ROHLength *rohLength);                           // :556-560
+// the .roh.bed file (garlic-roh.cpp:574-648): a track line per individual, then chr / start / stop / size class /
+// size / colour per segment; bounds: the size-class boundaries (--size-bounds, or GARLIC's GMM stage)
+void writeROHData(const std::string &outfile, std::vector<ROHData *> *rohDataByInd, std::vector<MapData *> *mapDataByChr,
+                  const std::vector<double> &bounds, const std::string &popName, const std::string &version, bool CM);
 
 // ---- the path (drop-in signatures)
 struct LodOptions {

@@ -36,6 +36,9 @@ struct Args {
     unsigned long long ld_seed = 0; // extension: 0 = time-seeded like the reference
     unsigned long long kde_seed = 0; // extension: the --kde-subsample draw, 0 = time-seeded like the reference
     double mu = 1e-9, overlap_frac = 0.25;
+    bool have_cutoff = false, cm = false;   // --lod-cutoff (src/garlic-cli.cpp:101), --cm (:167)
+    double lod_cutoff = 0.0;
+    std::vector<double> size_bounds;        // --size-bounds (:107)
 };
 
 [[noreturn]] void usage(const char *msg)
@@ -46,7 +49,8 @@ struct Args {
                  "         [--auto-winsize] [--auto-winsize-step N] [--winsize-stream] [--max-gap N] [--overlap-frac X]\n"
                  "         [--freq-file F] [--tped-missing C] [--raw-lod] [--kde-subsample N] [--kde-seed S] [--no-kde-thinning]\n"
                  "         [--weighted --map F --M N --mu X --ld-subsample N --ld-seed S --threads N]\n"
-                 "         [--resample N --resample-seed S] [--gpus N | --devices 0,1,...] [--genotype-cache F]\n";
+                 "         [--resample N --resample-seed S] [--gpus N | --devices 0,1,...] [--genotype-cache F]\n"
+                 "         [--lod-cutoff X --size-bounds B1 B2 ... [--cm]]   (ROH calls: <out>.roh.bed)\n";
     exit(1);
 }
 
@@ -78,6 +82,11 @@ Args parse(int argc, char **argv)
         else if (f == "--max-gap") a.max_gap = atoi(val().c_str());
         else if (f == "--overlap-frac") a.overlap_frac = atof(val().c_str());
         else if (f == "--weighted") a.weighted = !a.weighted;
+        else if (f == "--lod-cutoff") { a.lod_cutoff = atof(val().c_str()); a.have_cutoff = true; }
+        else if (f == "--cm") a.cm = !a.cm;
+        else if (f == "--size-bounds") {
+            while (i + 1 < argc && (isdigit((unsigned char)argv[i + 1][0]) || argv[i + 1][0] == '.')) a.size_bounds.push_back(atof(argv[++i]));
+        }
         else if (f == "--M") a.M = atoi(val().c_str());
         else if (f == "--mu") a.mu = atof(val().c_str());
         else if (f == "--threads") a.threads = atoi(val().c_str());
@@ -110,6 +119,12 @@ Args parse(int argc, char **argv)
     if (a.max_gap < 0) usage("Max gap must be > 0.");
     if (a.overlap_frac < 0 || a.overlap_frac > 1) usage("Overlap fraction must be >= 0 and <= 1.");
     if (a.weighted && a.map == "none") usage("--weighted needs --map");
+    if (a.cm && a.map == "none") usage("--cm needs --map");
+    if (a.have_cutoff && a.size_bounds.empty())
+        usage("--lod-cutoff writes the ROH calls and needs --size-bounds (the size classes otherwise come from GARLIC's GMM stage, "
+              "Phase II, not part of this tool)");
+    for (size_t k = 1; k < a.size_bounds.size(); k++)
+        if (!(a.size_bounds[k] > a.size_bounds[k - 1])) usage("--size-bounds must increase");
     return a;
 }
 
@@ -216,8 +231,25 @@ int main(int argc, char **argv)
             }
             sizes.clear();
         }
+        // --lod-cutoff: the ROH calls (garlic-main.cpp:346-420 with a user cutoff and user size classes): assembleROHWindows
+        // on the device(s), straight from the genotypes -- no window scores, no per-SNP counts -- then the .roh.bed
+        auto roh_calls = [&](int W, bool single) {
+            if (!a.have_cutoff) return;
+            ROHLength *len = nullptr;
+            std::vector<ROHData *> *roh = engine.assembleROHWindows(ind, a.lod_cutoff, &len, W, a.error, a.max_gap, a.overlap_frac,
+                                                                    a.cm, a.weighted, a.M, a.mu);
+            std::cerr << "ROH segments: " << (long long)len->size << "\n";
+            writeROHData((single ? a.out : a.out + "." + std::to_string(W) + "SNPs") + ".roh.bed", roh, maps, a.size_bounds, ind->pop,
+                         "1.1.6a (garlic-lod, MI355X)", a.cm);
+            releaseROHData(roh);
+            releaseROHLength(len);
+        };
+        const bool single_size = a.winsize_multi.empty();
+        if (a.have_cutoff && !a.weighted)
+            for (int W : a.winsize_multi.empty() ? std::vector<int>{a.winsize} : a.winsize_multi) roh_calls(W, single_size);
         for (int W : sizes) {
             if (a.weighted) engine.ldWeights(W, ldsub, false, a.phased);   // garlic-main.cpp:346-357: LD weights per window size
+            if (a.weighted) roh_calls(W, single_size);
             const std::string feed_path = a.out + "." + std::to_string(W) + "SNPs.lod.f64";
             if (!a.raw_lod) {   // only the KDE feed is wanted: thin on the device, no full-score download
                 DoubleData *feed = engine.lodFeed(W, a.error, a.max_gap, a.kde_thinning ? W : 1, a.weighted, a.M, a.mu, &kdesub);

@@ -273,3 +273,31 @@ def test_genotype_cache_keeps_the_phase(tmp_path):
            *weighted, "--genotype-cache", plain]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode != 0 and "without phase" in r.stderr
+
+
+def _bed(text):
+    """.roh.bed -> {individual: [segment lines]} (the track lines name the individuals)"""
+    out, cur = {}, None
+    for line in text.splitlines():
+        if line.startswith("track"):
+            cur = line.split('"')[1].split()[1]
+            out[cur] = []
+        else:
+            out[cur].append(line)
+    return out
+
+
+@pytest.mark.parametrize("tag,flags", [
+    ("ref", ["--lod-cutoff", "-12", "--size-bounds", "50000", "200000"]),
+    ("refw", ["--weighted", "--map", os.path.join(E2E, "tiny.map"), "--ld-subsample", "0", "--cm", "--lod-cutoff", "-4",
+              "--size-bounds", "0.05", "0.2"])])
+def test_roh_calls_match_reference_binary(tmp_path, tag, flags):
+    """--lod-cutoff / --size-bounds: calcLODWindows + assembleROHWindows + writeROHData of the prebuilt binary (the
+    .roh.bed in tests/golden/e2e) against the tool, whose device goes from the genotypes to the segments without scores
+    or counts: every individual's chromosome / start / stop / size class / size / colour lines, in bp and in cM"""
+    out = run_tool(tmp_path, "--winsize", "30", *flags)
+    ref = _bed(gzip.open(os.path.join(E2E, tag + ".roh.bed.gz"), "rt").read())
+    mine = _bed(open(out + ".roh.bed").read())
+    assert list(mine) == list(ref) and len(ref) == 24
+    assert sum(len(v) for v in ref.values()) > 100
+    assert mine == ref
