@@ -79,6 +79,17 @@ def soak(ctx, trials, seed, verbose=True):
                 if not np.array_equal(cov[c][:, :sizes[c]], ol.oracle_roh_coverage(np.ascontiguousarray(lod[c]), W, cut)):
                     fails += 1
                     print("FAIL fused coverage", cut, pa, c, tag)
+            # ... and past the counts: the ROH segments (garlic_roh_segments) against the oracle's walk over the oracle's counts
+            frac = float(rng.choice([1e-9, 0.25, 0.5, 1.0]))
+            segs = [tuple(int(v) for v in r) for r in panel.roh_segments(W, err, mg, cut, frac)]
+            want_segs = []
+            for c, (g, f, p, cs, ce) in enumerate(chroms):
+                covc = ol.oracle_roh_coverage(np.ascontiguousarray(lod[c]), W, cut)
+                want_segs += [(i, c, a, b) for i, a, b in ol.oracle_roh_segments(covc, p, cs, ce, W, mg, frac)]
+            checks += 1
+            if segs != sorted(want_segs):
+                fails += 1
+                print("FAIL roh segments", cut, frac, len(segs), len(want_segs), tag)
             # the subset feed (--kde-subsample): drawn individuals in drawn order
             if nind > 1:
                 idx = rng.choice(nind, size=int(rng.integers(1, min(nind, 40) + 1)), replace=False).astype(np.int32)
@@ -126,6 +137,17 @@ def soak(ctx, trials, seed, verbose=True):
                 if not np.array_equal(covw[c][:, :sizes[c]], ol.oracle_roh_coverage(np.ascontiguousarray(wantw), W, cutw)):
                     fails += 1
                     print("FAIL weighted fused coverage", cutw, c, tag)
+            fracw = float(rng.choice([0.25, 1.0]))
+            segsw = [tuple(int(v) for v in r) for r in panel.roh_segments(W, err, mg, cutw, fracw, weighted=True)]
+            want_segs = []
+            for c, (g, f, p, cs, ce) in enumerate(chroms):
+                wantw = ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, err, mg, 1e-9, 7)
+                covc = ol.oracle_roh_coverage(np.ascontiguousarray(wantw), W, cutw)
+                want_segs += [(i, c, a, b) for i, a, b in ol.oracle_roh_segments(covc, p, cs, ce, W, mg, fracw)]
+            checks += 1
+            if segsw != sorted(want_segs):
+                fails += 1
+                print("FAIL weighted roh segments", cutw, fracw, len(segsw), len(want_segs), tag)
             if rng.integers(0, 2):       # a dictionary of likelihood values ...
                 gl = [rng.choice([1e-16, 1e-3, 0.01, 0.2, 1.0], size=c[0].shape) for c in chroms]
             else:                        # ... or any doubles (continuous mode: lod() on the device)
