@@ -357,6 +357,7 @@ def leg_ns(ctx, dev, steps):
     # ... and past the counts: the ROH segments themselves (garlic_roh_segments: the bits become "SNP is covered by >=
     # OVERLAP_FRAC x winsize qualifying windows" bits and a list of (individual, chromosome, first, last) -- all of
     # assembleROHWindows on the device, a few MB to the host instead of 25 GB of counts)
+    from garlic_amd import abi
     seg_cap = 16_000_000
     seg_buf = np.empty((seg_cap, 4), dtype=np.int32)
     n_seg = ctypes.c_int64()
