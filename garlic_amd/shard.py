@@ -42,6 +42,36 @@ def gather_rows(local_rows, nind, group=None):
     return out
 
 
+def gather_segments(local_segs, nind, group=None):
+    """local_segs: this rank's garlic_roh_segments result, int32 [n][4] of (shard-local individual, chromosome, first
+    SNP, last SNP), ordered by individual.  Returns on rank 0 the panel-wide list -- individuals offset by the shard's
+    first one, shards in rank order = the order assembleROHWindows appends in (src/garlic-roh.cpp:425, individual by
+    individual) -- and None on the other ranks.  A few KB per rank: no score row or coverage count crosses ranks."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    seg = np.ascontiguousarray(local_segs, dtype=np.int32).reshape(-1, 4)
+    counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)] if rank == 0 else None
+    dist.gather(torch.tensor([seg.shape[0]], dtype=torch.int64), counts, dst=0, group=group)
+    cap = torch.zeros(1, dtype=torch.int64)
+    if rank == 0:
+        cap[0] = max(int(c.item()) for c in counts)
+    dist.broadcast(cap, src=0, group=group)
+    buf = torch.zeros((max(int(cap.item()), 1), 4), dtype=torch.int32)
+    buf[: seg.shape[0]] = torch.from_numpy(seg)
+    parts = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, parts, dst=0, group=group)
+    if rank != 0:
+        return None
+    out = []
+    for r in range(world):
+        part = parts[r][: int(counts[r].item())].numpy().copy()
+        part[:, 0] += shard_range(nind, world, r)[0]
+        out.append(part)
+    return np.concatenate(out, axis=0)
+
+
 def split_subsample(sub_idx, nind, world, rank):
     """The part of a panel-wide LD subsample (sorted individual indices, src/garlic-data.cpp:361)
     that lives in `rank`'s block, as shard-local indices; None (= everyone) stays None."""

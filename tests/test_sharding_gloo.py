@@ -57,6 +57,44 @@ def test_two_rank_shard_and_gather(tmp_path, nind):
     assert out.read_text() == "ok"
 
 
+def _seg_worker(rank, world, port, nind, W, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import oracle_lib as ol
+    from garlic_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(43)
+    chroms = [ol.random_panel(rng, n, nind, max_gap=200000) for n in (900, 350)]
+    cutoff, frac = -8.0, 0.25
+
+    def segments(lo, hi):      # what garlic_roh_segments returns for the individuals [lo, hi): local indices, sorted
+        out = []
+        for c, (g, f, p, cs, ce) in enumerate(chroms):
+            cov = ol.oracle_roh_coverage(ol.oracle_calc_lod(g[:, lo:hi], f, p, cs, ce, W, 0.001, 200000), W, cutoff)
+            out += [(i, c, a, b) for i, a, b in ol.oracle_roh_segments(cov, p, cs, ce, W, 200000, frac)]
+        return np.array(sorted(out), dtype=np.int32).reshape(-1, 4)
+
+    b, e = shard.shard_range(nind, world, rank)
+    full = shard.gather_segments(segments(b, e), nind)
+    if rank == 0:
+        want = segments(0, nind)
+        with open(out_path, "w") as fh:
+            fh.write("ok" if want.shape[0] > 3 and np.array_equal(full, want) else "mismatch")
+    else:
+        assert full is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nind", [10, 7])
+def test_two_rank_roh_segments_gather(tmp_path, nind):
+    out = tmp_path / "result.txt"
+    mp.spawn(_seg_worker, args=(2, _free_port(), nind, 20, str(out)), nprocs=2, join=True)
+    assert out.read_text() == "ok"
+
+
 def _ld_counts_numpy(geno, W, sub):
     """what garlic_ld_counts returns for a shard: integer counts only"""
     nloci = geno.shape[0]
