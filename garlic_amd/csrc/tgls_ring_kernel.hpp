@@ -28,9 +28,18 @@
 
 namespace garlic {
 
-constexpr int TG_RING = 240;            // ring rows (512 B each): 120 KB
+#ifndef GARLIC_TG_RING      // (timing experiments override the three: tools/exp/tgls_ring_abl.sh)
+#define GARLIC_TG_RING 240
+#endif
+#ifndef GARLIC_TG_DEPTH
+#define GARLIC_TG_DEPTH 3
+#endif
+#ifndef GARLIC_TG_TILE_ROWS
+#define GARLIC_TG_TILE_ROWS WAVE
+#endif
+constexpr int TG_RING = GARLIC_TG_RING;   // ring rows (512 B each): 120 KB
 constexpr int TG_GROUP = 8;             // LDS-DMA requests (1 KB = 2 rows) per loader round
-constexpr int TG_DEPTH = 3;             // rounds a loader keeps in flight
+constexpr int TG_DEPTH = GARLIC_TG_DEPTH; // rounds a loader keeps in flight
 constexpr int TG_THREADS = 4 * WAVE;    // LOAD0, LOAD1, CHAIN, POST
 constexpr int TG_SINGLE_MAX_W = TG_RING - 32 - 4 * TG_GROUP * 2;   // one stream: W + the tile + a few rounds must fit
 
@@ -120,7 +129,7 @@ __global__ void __launch_bounds__(TG_THREADS)
 lod_chain_ring_kernel(TglsArgs p)
 {
     __shared__ __attribute__((aligned(1024))) double ring[TG_RING * WAVE];
-    __shared__ __attribute__((aligned(16))) double tiles[2][WAVE * TPITCH];
+    __shared__ __attribute__((aligned(16))) double tiles[2][GARLIC_TG_TILE_ROWS * TPITCH];
     __shared__ int flags[8];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
