@@ -214,6 +214,7 @@ lod_chain_ring_kernel(TglsArgs p)
             }
             for (int k = 0; k < ntiles; k++) {
                 // inputs: every row this tile reads has landed
+#ifndef GARLIC_TG_ABL_NOWAIT     // (timing experiment when defined: the chain never waits for its rows)
                 if (single) {
                     const int pieces = (TILE * (k + 1) + W + 1) / 2;            // stream pieces 0 .. pieces-1
                     const int need0 = (pieces + 1) / 2, need1 = pieces / 2;      // of loader 0 (even) / 1 (odd)
@@ -222,6 +223,7 @@ lod_chain_ring_kernel(TglsArgs p)
                     const int need = TILE * (k + 1) / 2;
                     while (LDS_FLAG_GET(flags[2]) < need || LDS_FLAG_GET(flags[3]) < need) __builtin_amdgcn_s_sleep(1);
                 }
+#endif
                 const bool bits_mode = p.cov.bits != nullptr;
                 if (!bits_mode)
                     while (LDS_FLAG_GET(flags[1]) + 2 <= k) __builtin_amdgcn_s_sleep(1);   // tile buffer k & 1 written out
@@ -230,12 +232,26 @@ lod_chain_ring_kernel(TglsArgs p)
                 const int s0 = first + k * TILE;
                 const bool edge = (s0 <= a) || (s0 + TILE - 1 > b);
                 double t_in[TILE], t_out[TILE];
+                if (si + TILE <= ring_rows && so + TILE <= ring_rows) {
+                    // neither stream wraps inside this tile (six tiles in seven): one address per stream, the rows at
+                    // immediate offsets -- with a wrap test per row the reads cost ten instructions per window, more
+                    // than the chain itself, and the chain wave is what paces the kernel when it leaves bits
+                    const double *pi = ring + si * WAVE + lane, *po = ring + base_out + so * WAVE + lane;
 #pragma unroll
-                for (int j = 0; j < TILE; j++) {
-                    t_in[j] = ring[si * WAVE + lane];
-                    t_out[j] = ring[base_out + so * WAVE + lane];
-                    si = (si + 1 == ring_rows) ? 0 : si + 1;
-                    so = (so + 1 == ring_rows) ? 0 : so + 1;
+                    for (int j = 0; j < TILE; j++) {
+                        t_in[j] = pi[j * WAVE];
+                        t_out[j] = po[j * WAVE];
+                    }
+                    si = (si + TILE == ring_rows) ? 0 : si + TILE;
+                    so = (so + TILE == ring_rows) ? 0 : so + TILE;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TILE; j++) {
+                        t_in[j] = ring[si * WAVE + lane];
+                        t_out[j] = ring[base_out + so * WAVE + lane];
+                        si = (si + 1 == ring_rows) ? 0 : si + 1;
+                        so = (so + 1 == ring_rows) ? 0 : so + 1;
+                    }
                 }
                 if (bits_mode) {
                     // one bit per window -- score >= cutoff, NaN never -- 32 per lane and tile; a tile at a run's edge may
