@@ -239,8 +239,13 @@ lod_chain_ring_kernel(TglsArgs p)
                     const double *pi = ring + si * WAVE + lane, *po = ring + base_out + so * WAVE + lane;
 #pragma unroll
                     for (int j = 0; j < TILE; j++) {
+#ifdef GARLIC_TG_ABL_NOREADS        // (timing experiment: no ring reads)
+                        t_in[j] = (double)(j + k);
+                        t_out[j] = (double)(j - k);
+#else
                         t_in[j] = pi[j * WAVE];
                         t_out[j] = po[j * WAVE];
+#endif
                     }
                     si = (si + TILE == ring_rows) ? 0 : si + TILE;
                     so = (so + TILE == ring_rows) ? 0 : so + TILE;
@@ -269,11 +274,15 @@ lod_chain_ring_kernel(TglsArgs p)
                             m |= (in && acc >= cutoff) ? (1u << j) : 0u;
                         }
                     } else {        // (a loop of its own: with the edge tests in it every window carried a dozen more instructions)
+#ifdef GARLIC_TG_ABL_NOCOMPUTE      // (timing experiment: the reads, no chain)
+                        asm volatile("" :: "v"(t_in[0]), "v"(t_out[0]), "v"(t_in[TILE - 1]), "v"(t_out[TILE - 1]));
+#else
 #pragma unroll
                         for (int j = 0; j < TILE; j++) {
                             acc = (acc - t_out[j]) + t_in[j];
                             m |= (acc >= cutoff) ? (1u << j) : 0u;
                         }
+#endif
                     }
                     if (it.ind0 + lane < p.ind_count) {
                         uint32_t *w = bits_row + (s0 >> 5);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # lod_chain_ring_kernel in bits mode (garlic_roh_coverage_fused with likelihoods): ring rows and loader rounds in flight
-# (variants built into build/abl/ with -DGARLIC_TG_DEPTH=: 4 rounds instead of 3 -> 7.04 against 7.16 ms at 2M x 1280, the
-# loads are not what paces the bits mode.  Do NOT build -DGARLIC_TG_TILE_ROWS=1 variants for this script: its first call is
+# (variants built into build/abl/ with -DGARLIC_TG_DEPTH=4 / -DGARLIC_TG_ABL_NOWAIT / _NOREADS / _NOCOMPUTE: none moves the call
+# by more than 12 %: the bits mode reads 8 B of terms per window and runs at 0.8 of that stream's rate.  Do NOT build -DGARLIC_TG_TILE_ROWS=1 variants for this script: its first call is
 # the score path, which then writes past its tiles and never finishes)
 cp garlic_amd/libgarlic_hip.so /tmp/shipped.so
 for f in build/abl/*.so; do
