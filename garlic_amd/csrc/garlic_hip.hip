@@ -3479,7 +3479,7 @@ int garlic_panel_alloc_scores(garlic_panel *p, int32_t pitch_align, int32_t nind
     candidates = std::min(candidates, 16);
     const Layout L = make_layout(p, pitch_align, nind_out);
     // Candidates come in rounds.  Buffers of one round are cut from neighbouring physical memory and can ALL land on
-    // the slow side (profiles/r03_bench_plain.json: eight candidates at 1.65 ms on a fresh device, 1.35 ms one process
+    // the slow side (profiles/r03_bench_plain_all_candidates_slow.json: eight candidates at 1.65 ms on a fresh device, 1.35 ms one process
     // later; tools/exp/placement_fresh.py: one round in four without a fast buffer).  A round whose fastest and slowest
     // candidate are within 6 % of each other has told nothing: take another one from fresh memory while the first is
     // still held (so that the allocator cannot hand the same pages back), up to three; the best of all rounds is kept.
