@@ -218,7 +218,10 @@ def test_sharded_run_equals_single_device(tmp_path):
     # with --raw-lod the full scores come back; without, only the feed thinned on the devices
     cases = ((["--winsize", "30", "--raw-lod"], []), (["--winsize", "30", "--raw-lod"], weighted),
              (["--winsize-multi", "20", "45"], []), (["--winsize", "30", "--no-kde-thinning"], weighted),
-             (["--winsize", "30", "--raw-lod", "--phased"], weighted))
+             (["--winsize", "30", "--raw-lod", "--phased"], weighted),
+             # the ROH calls: every shard's segments, merged in TFAM order
+             (["--winsize", "30", "--lod-cutoff", "-12", "--size-bounds", "50000", "200000"], []),
+             (["--winsize", "30", "--lod-cutoff", "-4", "--size-bounds", "0.05", "0.2", "--cm"], weighted))
     for case, (common, extra) in enumerate(cases):
         outs = []
         for k, devs in enumerate(("0", "0,0", "0,0,0,0,0")):
@@ -227,6 +230,7 @@ def test_sharded_run_equals_single_device(tmp_path):
             outs.append(run_tool(d, *common, *extra, "--devices", devs))
         names = sorted(os.path.basename(p)[len("mine"):] for p in glob.glob(outs[0] + "*"))
         assert any(n.endswith(".lod.f64") for n in names)
+        assert ("--lod-cutoff" in common) == any(n.endswith(".roh.bed") for n in names)
         for other in outs[1:]:
             for n in names:
                 assert filecmp.cmp(outs[0] + n, other + n, shallow=False), (n, other)
