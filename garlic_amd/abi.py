@@ -532,16 +532,19 @@ class Panel:
 
     def roh_segments(self, winsize, error, max_gap, cutoff, overlap_frac, use_gl=False, weighted=False, M=7, mu=1e-9, capacity=None):
         """garlic_roh_segments: the ROH segments of assembleROHWindows without scores or counts in memory -> int32 array
-        [n][4] of (individual, chromosome, first SNP, last SNP), in the reference's order.  capacity None: asked for first."""
+        [n][4] of (individual, chromosome, first SNP, last SNP), in the reference's order.  capacity None: room for 64 per
+        individual, once more with the number found if that was too little."""
         n = C.c_int64()
         args = (self.handle, winsize, error, max_gap, int(use_gl), int(weighted), M, mu, cutoff, overlap_frac)
-        if capacity is None:
-            check(lib().garlic_roh_segments(*args, _vp(), 0, C.byref(n)))
-            capacity = n.value
-        out = np.empty((max(int(capacity), 1), 4), dtype=np.int32)
-        check(lib().garlic_roh_segments(*args, _vp(out.ctypes.data), int(capacity), C.byref(n)))
-        if n.value > capacity:
-            raise GarlicError(1, f"garlic_roh_segments: {n.value} segments, room for {capacity}")
+        cap = max(1024, 64 * self.nind) if capacity is None else int(capacity)
+        for _ in range(2):
+            out = np.empty((max(cap, 1), 4), dtype=np.int32)
+            check(lib().garlic_roh_segments(*args, _vp(out.ctypes.data), cap, C.byref(n)))
+            if n.value <= cap or capacity is not None:
+                break
+            cap = n.value           # (nothing usable was written: once more, with room)
+        if n.value > cap:
+            raise GarlicError(1, f"garlic_roh_segments: {n.value} segments, room for {cap}")
         return out[:n.value].copy()
 
     def roh_coverage_fused_device(self, winsize, error, max_gap, cutoff, out_ptr, pitch_align=8, use_gl=False, weighted=False,

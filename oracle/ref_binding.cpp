@@ -122,9 +122,13 @@ vector< ROHData * > *hip_assembleROHWindows(vector< HapData * > *hapDataByChr, v
     HipPanel h;
     hip_upload(h, hapDataByChr, freqDataByChr, mapDataByChr, GLDataByChr, centro, USE_GL, false);
     int64_t n = 0;
-    if (garlic_roh_segments(h.panel, winSize, error, MAX_GAP, USE_GL, 0, 0, 0.0, lodScoreCutoff, OVERLAP_FRAC, NULL, 0, &n)) throw 0;
-    vector<garlic_roh_segment> seg((size_t)(n > 0 ? n : 1));
-    if (garlic_roh_segments(h.panel, winSize, error, MAX_GAP, USE_GL, 0, 0, 0.0, lodScoreCutoff, OVERLAP_FRAC, seg.data(), n, &n)) throw 0;
+    vector<garlic_roh_segment> seg((size_t)(64 * indData->nind));      // room for a first guess; the call says how many there are
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (garlic_roh_segments(h.panel, winSize, error, MAX_GAP, USE_GL, 0, 0, 0.0, lodScoreCutoff, OVERLAP_FRAC, seg.data(),
+                                (int64_t)seg.size(), &n)) throw 0;
+        if (n <= (int64_t)seg.size()) break;
+        seg.resize((size_t)n);                                           // (nothing usable was written: once more, with room)
+    }
     vector< ROHData * > *rohDataByInd = initROHData(indData);           // garlic-roh.cpp:387
     for (int ind = 0; ind < indData->nind; ind++) rohDataByInd->at(ind)->indID = indData->indID[ind];
     (*rohLength) = initROHLength((int)n, indData->pop);                 // :535-541
