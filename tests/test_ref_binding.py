@@ -63,7 +63,7 @@ def _p(a, t):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(SO), reason="oracle/_ref/libgarlic_ref_hip.so is built in the build container (make -C oracle ref)")
-def test_binding_equals_the_reference_on_the_references_own_structs():
+def test_binding_equals_the_reference_on_the_references_own_structs(gpu_ctx):      # (the fixture: torch finds the device first, conftest.py)
     rng = np.random.default_rng(404)
     lib = _lib()
     mg = 200000
@@ -91,7 +91,7 @@ def test_binding_equals_the_reference_on_the_references_own_structs():
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(SO), reason="oracle/_ref/libgarlic_ref_hip.so is built in the build container (make -C oracle ref)")
-def test_roh_binding_equals_the_references_calcLODWindows_plus_assembleROHWindows():
+def test_roh_binding_equals_the_references_calcLODWindows_plus_assembleROHWindows(gpu_ctx):
     """The reference's calcLODWindows -> assembleROHWindows and the binding's one call (garlic_roh_segments) on the same
     vector<HapData*>* .. IndData*: every individual's chr / start / stop / length lists and the pooled ROHLength, in bp
     and in cM, with and without likelihoods, thresholds from one SNP to the whole window"""
