@@ -563,6 +563,29 @@ def test_roh_segments_weighted_and_with_likelihoods(gpu_ctx, W):
                     assert [tuple(int(v) for v in r) for r in got] == want, (W, weighted, use_gl, cutoff, frac, len(got), len(want))
 
 
+def test_roh_segments_and_counts_over_many_small_chromosomes(gpu_ctx):
+    """150 chromosomes of 1 .. 90 SNPs (scaffolds): every word of the bit matrices belongs to another chromosome than its
+    neighbours -- the fused counts and the segments against the oracle"""
+    rng = np.random.default_rng(77)
+    mg, W, nind = 200000, 6, 45
+    sizes = [int(x) for x in rng.integers(1, 91, size=150)]
+    chroms = [ol.random_panel(rng, n, nind, max_gap=mg, gaps=0) for n in sizes]
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms])
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        scores = [ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg) for (g, f, p, cs, ce) in chroms]
+        for cutoff in (-1.0, -4.0):
+            got = panel.roh_coverage_fused(W, 0.001, mg, cutoff, pitch_align=8)
+            for c, n in enumerate(sizes):
+                assert np.array_equal(got[c][:, :n], ol.oracle_roh_coverage(np.ascontiguousarray(scores[c]), W, cutoff)), (cutoff, c)
+            for frac in (0.2, 1.0):
+                want = _oracle_segments(chroms, scores, W, cutoff, mg, frac)
+                segs = panel.roh_segments(W, 0.001, mg, cutoff, frac)
+                assert [tuple(int(v) for v in r) for r in segs] == want, (cutoff, frac, len(segs), len(want))
+        assert len(want) > 50
+
+
 def test_roh_segments_refuses_a_chromosome_that_starts_at_position_zero(gpu_ctx):
     rng = np.random.default_rng(3)
     g, f, p, cs, ce = ol.random_panel(rng, 300, 5, max_gap=200000)
