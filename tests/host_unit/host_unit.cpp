@@ -10,6 +10,7 @@
 #include <cstring>
 #include <iostream>
 #include <sstream>
+#include <fstream>
 
 using namespace garlic_host;
 
@@ -146,6 +147,40 @@ int main(int argc, char **argv)
                 releaseWinData(ww[c]);
                 delete wm[c];
             }
+        }
+        // writeROHData (garlic-roh.cpp:574-648): track line per individual, size class by the first boundary the size lies
+        // below (A, B, ..; past the last: the next letter), bp sizes as integers, cM sizes as the stream prints a double,
+        // "chr" put in front of chromosome names that lack it
+        {
+            IndData ind;
+            ind.pop = "POP";
+            ind.nind = 2;
+            ind.indID = new std::string[2]{"a", "b"};
+            std::vector<ROHData *> *roh = initROHData(&ind);
+            roh->at(0)->indID = "a";
+            roh->at(1)->indID = "b";
+            MapData m1, m2;
+            m1.chr = "7";
+            m2.chr = "chrX";
+            std::vector<MapData *> maps{&m1, &m2};
+            auto add = [&](int i, int c, int a, int b, double len) {
+                roh->at(i)->chr.push_back(c); roh->at(i)->start.push_back(a); roh->at(i)->stop.push_back(b); roh->at(i)->length.push_back(len);
+            };
+            add(0, 0, 100, 49999, 49900.0);
+            add(0, 1, 5, 250004, 250000.0);
+            add(1, 0, 7, 100006, 100000.0);
+            const std::string bed = tmp + "/unit.roh.bed", bedcm = tmp + "/unit.cm.roh.bed";
+            writeROHData(bed, roh, &maps, {50000.0, 200000.0}, "POP", "x", false);
+            roh->at(1)->length[0] = 0.125;
+            writeROHData(bedcm, roh, &maps, {0.05, 0.2}, "POP", "x", true);
+            auto slurp = [](const std::string &p) { std::ifstream f(p); std::stringstream s; s << f.rdbuf(); return s.str(); };
+            const std::string t0 = "track name=\"Ind: a Pop:POP ROH\" description=\"Ind: a Pop:POP ROH from GARLIC vx\" visibility=2 itemRgb=\"On\"\n";
+            const std::string t1 = "track name=\"Ind: b Pop:POP ROH\" description=\"Ind: b Pop:POP ROH from GARLIC vx\" visibility=2 itemRgb=\"On\"\n";
+            CHECK(slurp(bed) == t0 + "chr7\t100\t49999\tA\t49900\t.\t0\t0\t228,26,28\n" + "chrX\t5\t250004\tC\t250000\t.\t0\t0\t55,126,184\n" +
+                                t1 + "chr7\t7\t100006\tB\t100000\t.\t0\t0\t77,175,74\n");
+            CHECK(slurp(bedcm).find(t1 + "chr7\t7\t100006\tB\t0.125\t.\t0\t0\t77,175,74\n") != std::string::npos);
+            releaseROHData(roh);
+            delete[] ind.indID;
         }
     } catch (...) {
         std::cerr << "FAILED: exception\n";
