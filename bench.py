@@ -471,6 +471,11 @@ def leg_ns(ctx, dev, steps):
                                  roofline=hbm_roofline("wlod_stream_small_kernel", BYTES_LOD * win, k,
                                                        note="2 * 10 flops per window: the 8 B of score per window bound it"))
     res["wlod_winsize10"]["lod_windows_per_s"] = win / W10 / (dt / steps)
+    # ... and with per-genotype likelihoods (round 2's tile kernel: the scaled term matrix is its second stream)
+    dt, k = timed_passes(ctx, lambda: panel.wlod_windows_device(out.data_ptr(), W10, ERROR, MAX_GAP, M_GEN, MU, use_gl=True), steps, 1,
+                         torch.cuda.synchronize)
+    res["wlod_gl_winsize10"] = dict(rate(k, dt), roofline=hbm_roofline("wlod_tile_small_kernel", BYTES_TGLS * win, k,
+                                                                      note="8 B of scaled terms in, 8 B of score out per window"))
     panel.close()
     out.free()
     torch.cuda.empty_cache()
