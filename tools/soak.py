@@ -174,6 +174,18 @@ def soak(ctx, trials, seed, verbose=True):
                 if not np.array_equal(covg[c][:, :sizes[c]], ol.oracle_roh_coverage(np.ascontiguousarray(wantg), W, cutg)):
                     fails += 1
                     print("FAIL tgls fused coverage", cutg, c, tag)
+            # ... and the ROH segments from the same bits
+            fracg = float(rng.choice([0.25, 0.7]))
+            segsg = [tuple(int(v) for v in r) for r in panel.roh_segments(W, err, mg, cutg, fracg, use_gl=True)]
+            want_segs = []
+            for c, (g, f, p, cs, ce) in enumerate(chroms):
+                wantg = ol.oracle_calc_lod(g, f, p, cs, ce, W, err, mg, gl=gl[c])
+                covc = ol.oracle_roh_coverage(np.ascontiguousarray(wantg), W, cutg)
+                want_segs += [(i, c, a, b) for i, a, b in ol.oracle_roh_segments(covc, p, cs, ce, W, mg, fracg)]
+            checks += 1
+            if segsg != sorted(want_segs):
+                fails += 1
+                print("FAIL tgls roh segments", cutg, fracg, len(segsg), len(want_segs), tag)
             out = panel.wlod_windows(W, err, mg, 7, 1e-9, pitch_align=32, use_gl=True)
             for c, (g, f, p, cs, ce) in enumerate(chroms):
                 checks += 1
