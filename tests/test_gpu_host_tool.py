@@ -34,6 +34,16 @@ def run_tool(tmp_path, *extra, want_stderr=False):
     return (out, r.stderr) if want_stderr else out
 
 
+def run_tool_tgls(tmp_path, *extra):
+    """the same without --error (the likelihoods take its place)"""
+    out = str(tmp_path / "mine")
+    cmd = [TOOL, "--tped", os.path.join(E2E, "tiny.tped.gz"), "--tfam", os.path.join(E2E, "tiny.tfam"),
+           "--centromere", os.path.join(E2E, "tiny.centromeres.txt"), "--out", out, "--kde-subsample", "0"]
+    r = subprocess.run(cmd + list(extra), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out
+
+
 def tiny_panels():
     """independent re-parse of the tped (first non-missing allele is the counted one), monomorphic sites dropped"""
     chroms = {}
@@ -294,12 +304,17 @@ def _bed(text):
 @pytest.mark.parametrize("tag,flags", [
     ("ref", ["--lod-cutoff", "-12", "--size-bounds", "50000", "200000"]),
     ("refw", ["--weighted", "--map", os.path.join(E2E, "tiny.map"), "--ld-subsample", "0", "--cm", "--lod-cutoff", "-4",
-              "--size-bounds", "0.05", "0.2"])])
+              "--size-bounds", "0.05", "0.2"]),
+    ("reft", ["--tgls", os.path.join(E2E, "tiny.tgls.gz"), "--gl-type", "GQ", "--lod-cutoff", "-11", "--size-bounds", "50000", "200000"])])
 def test_roh_calls_match_reference_binary(tmp_path, tag, flags):
     """--lod-cutoff / --size-bounds: calcLODWindows + assembleROHWindows + writeROHData of the prebuilt binary (the
     .roh.bed in tests/golden/e2e) against the tool, whose device goes from the genotypes to the segments without scores
-    or counts: every individual's chromosome / start / stop / size class / size / colour lines, in bp and in cM"""
-    out = run_tool(tmp_path, "--winsize", "30", *flags)
+    or counts: every individual's chromosome / start / stop / size class / size / colour lines, in bp and in cM, and from
+    per-genotype likelihoods"""
+    if tag == "reft":
+        out = run_tool_tgls(tmp_path, "--winsize", "30", *flags)
+    else:
+        out = run_tool(tmp_path, "--winsize", "30", *flags)
     ref = _bed(gzip.open(os.path.join(E2E, tag + ".roh.bed.gz"), "rt").read())
     mine = _bed(open(out + ".roh.bed").read())
     assert list(mine) == list(ref) and len(ref) == 24

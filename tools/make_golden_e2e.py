@@ -100,10 +100,12 @@ def main():
         print(" ", os.path.basename(p), os.path.getsize(p))
         shutil.copy(p, os.path.join(OUT, os.path.basename(p)))
     # the final pass: --lod-cutoff (no KDE) and --size-bounds (no GMM) leave calcLODWindows + assembleROHWindows +
-    # writeROHData -- the ROH calls in bp from the unweighted scores, and in cM (--cm) from the weighted ones
+    # writeROHData -- the ROH calls in bp from the unweighted scores, in cM (--cm) from the weighted ones, in bp from the
+    # scores with per-genotype likelihoods
     cmdr = [x for x in cmd[:-1] if x != "--raw-lod"] + [os.path.join(tmp, "ref"), "--lod-cutoff", "-12", "--size-bounds", "50000", "200000"]
     cmdrw = [x for x in cmdw if x != "--raw-lod"] + ["--cm", "--lod-cutoff", "-4", "--size-bounds", "0.05", "0.2"]
-    for c, tag in ((cmdr, "ref"), (cmdrw, "refw")):
+    cmdrt = [x for x in cmdt if x != "--raw-lod"] + ["--lod-cutoff", "-11", "--size-bounds", "50000", "200000"]
+    for c, tag in ((cmdr, "ref"), (cmdrw, "refw"), (cmdrt, "reft")):
         r = subprocess.run(c, capture_output=True, text=True)
         print(r.stdout[-400:], r.stderr[-800:])
         with open(os.path.join(tmp, tag + ".roh.bed"), "rb") as src, open(os.path.join(OUT, tag + ".roh.bed.gz"), "wb") as raw, \
@@ -111,7 +113,7 @@ def main():
             f.write(src.read())
     with open(os.path.join(OUT, "COMMAND.txt"), "w") as f:
         f.write("garlic v1.1.6a prebuilt binary:\n")
-        for c in (cmd, cmdw, cmdp, cmdt, cmdr, cmdrw):
+        for c in (cmd, cmdw, cmdp, cmdt, cmdr, cmdrw, cmdrt):
             f.write(" ".join(os.path.basename(x) if x.startswith("/") else x for x in c) + "\n")
     shutil.rmtree(tmp)
 
