@@ -10,6 +10,23 @@ namespace garlic {
 // a count item of lod_bits_kernel: COV_ITEM_WORDS 32-SNP words of COV_ITEM_ROWS individuals of one chromosome
 constexpr int COV_ITEM_WORDS = 256, COV_ITEM_ROWS = 8;
 
+// the chromosome of word column g (word_base: prefix sums of the chromosomes' word counts).  The workgroup's first
+// column is looked up once, wave-uniformly (scalar instructions); a thread then moves on by the chromosomes its own
+// column lies beyond -- none, almost always: a search per thread was a dozen dependent loads in front of every thread
+__device__ __forceinline__ int cov_word_chr(const int32_t *__restrict__ word_base, int nchr, int g)
+{
+    const int g0 = (int)(blockIdx.x * blockDim.x);
+    int lo = 0, hi = nchr - 1;                 // the last chromosome with word_base[c] <= g0
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (word_base[mid] <= g0) lo = mid;
+        else hi = mid - 1;
+    }
+    int chr = __builtin_amdgcn_readfirstlane(lo);
+    while (chr + 1 < nchr && g >= word_base[chr + 1]) chr++;
+    return chr;
+}
+
 // One thread, one (individual, 32-SNP word): the count of the W bits in front of the word (popcounts over W / 32 + 1
 // words), then bit in, bit out, 32 times.  The 32 counts of a thread are 64 contiguous bytes of the individual's row;
 // a wave whose 64 words are whole words of one chromosome (`wave_whole`: decided by the caller, the same in every

@@ -326,8 +326,7 @@ cov_counts_from_bits_kernel(const uint32_t *__restrict__ bits, const ChrDev *__r
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);      // word column over all chromosomes
     const bool live = g < word_base[nchr];
-    int chr = 0;
-    while (live && chr + 1 < nchr && g >= word_base[chr + 1]) chr++;
+    const int chr = live ? cov_word_chr(word_base, nchr, g) : 0;
     const ChrDev bc = bchrs[chr], oc = ochrs[chr];
     const int t = live ? g - word_base[chr] : 0, nwords = (bc.nloci + 31) >> 5;
     const int row = blockIdx.y;

@@ -17,6 +17,7 @@
 // the reference's order (individual, chromosome, position).
 #pragma once
 #include "lod_kernels.hpp"
+#include "cov_counts.hpp"
 #include "../../include/garlic_hip.h"
 
 namespace garlic {
@@ -30,8 +31,7 @@ roh_bits_from_scores_kernel(const double *__restrict__ scores, const ChrDev *__r
 {
     const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (g >= word_base[nchr]) return;
-    int chr = 0;
-    while (chr + 1 < nchr && g >= word_base[chr + 1]) chr++;
+    const int chr = cov_word_chr(word_base, nchr, g);
     const ChrDev sc = schrs[chr], bc = bchrs[chr];
     const int t = g - word_base[chr], row = blockIdx.y;
     const double *srow = scores + sc.out_base + (int64_t)row * sc.out_pitch;
@@ -66,8 +66,7 @@ roh_mask_from_bits_kernel(const uint32_t *__restrict__ bits, const ChrDev *__res
 {
     const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (g >= word_base[nchr]) return;
-    int chr = 0;
-    while (chr + 1 < nchr && g >= word_base[chr + 1]) chr++;
+    const int chr = cov_word_chr(word_base, nchr, g);
     const ChrDev bc = bchrs[chr];
     const int t = g - word_base[chr], nwords = (bc.nloci + 31) >> 5;
     const int rel = 32 * t - W, dA = rel >> 5, r = rel & 31;          // bit 32 t - W sits in word dA at bit r (floor)
@@ -112,8 +111,7 @@ roh_segments_from_mask_kernel(const uint32_t *__restrict__ mask, const ChrDev *_
 {
     const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (g >= word_base[nchr]) return;
-    int chr = 0;
-    while (chr + 1 < nchr && g >= word_base[chr + 1]) chr++;
+    const int chr = cov_word_chr(word_base, nchr, g);
     const ChrDev bc = bchrs[chr];
     const int t = g - word_base[chr], nwords = (bc.nloci + 31) >> 5;
     const uint32_t *b = brk + word_base[chr];
