@@ -320,23 +320,25 @@ lod_coverage_kernel(CovArgs p)
 __global__ void __launch_bounds__(256)
 cov_counts_from_bits_kernel(const uint32_t *__restrict__ bits, const ChrDev *__restrict__ bchrs,
                             const ChrDev *__restrict__ ochrs, const int32_t *__restrict__ word_base, int nchr, int W,
-                            int vec_ok, int16_t *__restrict__ out)
+                            int nind, int vec_ok, int16_t *__restrict__ out)
 {
-    __shared__ uint4 xpose[4][4 * WAVE];
+    __shared__ uint4 xpose[4][COV_XPOSE_SLOTS];
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);      // word column over all chromosomes
     const bool live = g < word_base[nchr];
     const int chr = live ? cov_word_chr(word_base, nchr, g) : 0;
     const ChrDev bc = bchrs[chr], oc = ochrs[chr];
     const int t = live ? g - word_base[chr] : 0, nwords = (bc.nloci + 31) >> 5;
-    const int row = blockIdx.y;
-    const uint32_t *brow = bits + bc.out_base + (int64_t)row * bc.out_pitch;
-    int16_t *orow = out + oc.out_base + (int64_t)row * oc.out_pitch;
     const bool whole = live && vec_ok && 32 * t + 32 <= oc.nloci;
     // all 64 threads of the wave on whole words of one chromosome: their 4 KB are contiguous in the row
     const int chr0 = __builtin_amdgcn_readfirstlane(chr);
     const bool wave_whole = __ballot(whole && chr == chr0) == ~(uint64_t)0;
-    cov_counts_word(brow, nwords, t, live, W, orow, oc.nloci, whole, wave_whole, xpose[wave], lane);
+    // COV_ITEM_ROWS individuals per workgroup: one workgroup per 256 words and individual is 1.5 M workgroups at
+    // 10M SNPs x 1250 and ran at the dispatcher's pace (3.8 TB/s)
+    const int row_end = min(nind, ((int)blockIdx.y + 1) * COV_ITEM_ROWS);
+    for (int row = (int)blockIdx.y * COV_ITEM_ROWS; row < row_end; row++)
+        cov_counts_word(bits + bc.out_base + (int64_t)row * bc.out_pitch, nwords, t, live, W,
+                        out + oc.out_base + (int64_t)row * oc.out_pitch, oc.nloci, whole, wave_whole, xpose[wave], lane);
 }
 
 } // namespace garlic

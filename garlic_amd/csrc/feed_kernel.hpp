@@ -82,7 +82,7 @@ struct FeedArgs {
     int32_t *cnt_timeout;     // set to 1 if a count item's wait ran out of its poll budget (the counts are then not to be used)
 };
 
-constexpr int FEED_BITS_LDS = 1024 + 4 * 4 * WAVE * 16;   // lod_bits_kernel: the count items' 4 KB per wave behind the misc words
+constexpr int FEED_BITS_LDS = 1024 + 4 * COV_XPOSE_SLOTS * 16;   // lod_bits_kernel: the count items' transpose buffers (one per wave) behind the misc words
 
 __device__ __forceinline__ void feed_barrier()
 {   // s_barrier alone: __syncthreads() would also wait for every outstanding memory request
@@ -181,7 +181,7 @@ __device__ __forceinline__ void lod_feed_body(const FeedArgs &p)
             const bool live = t < nwords;
             const bool whole = live && p.cnt_vec_ok && 32 * t + 32 <= oc.nloci;
             const bool wave_whole = __ballot(whole) == ~(uint64_t)0;
-            uint4 *xw = reinterpret_cast<uint4 *>(smem + 1024) + wave * (4 * WAVE);
+            uint4 *xw = reinterpret_cast<uint4 *>(smem + 1024) + wave * COV_XPOSE_SLOTS;
             const uint32_t *bits = reinterpret_cast<const uint32_t *>(p.out);
 #ifdef GARLIC_COVOV_ABL_NOWORK      // (timing experiment: the count items wait and do nothing)
             if (p.cnt_out) continue;

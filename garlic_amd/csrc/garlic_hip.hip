@@ -3075,8 +3075,9 @@ static int coverage_impl(garlic_panel *p, int32_t winsize, double error, int32_t
         if (sink.segments) return done(segments_from_bits(p, d_bits.p, d_bchrs.p, bchrs, word_base, W, sink));
         bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
         for (int c = 0; c < p->nchr; c++) vec_ok = vec_ok && Lo.base[c] % 8 == 0 && Lo.pitch[c] % 8 == 0;
-        hipLaunchKernelGGL(cov_counts_from_bits_kernel, dim3((unsigned)((word_base[(size_t)p->nchr] + 255) / 256), (unsigned)p->nind),
-                           dim3(256), 0, s, d_bits.p, d_bchrs.p, d_ochrs.p, d_wbase.p, p->nchr, W, vec_ok ? 1 : 0, dst);
+        hipLaunchKernelGGL(cov_counts_from_bits_kernel, dim3((unsigned)((word_base[(size_t)p->nchr] + 255) / 256),
+                                                             (unsigned)((p->nind + COV_ITEM_ROWS - 1) / COV_ITEM_ROWS)),
+                           dim3(256), 0, s, d_bits.p, d_bchrs.p, d_ochrs.p, d_wbase.p, p->nchr, W, p->nind, vec_ok ? 1 : 0, dst);
         e = hipGetLastError();
         if (e == hipSuccess && where == GARLIC_HOST)
             e = hipMemcpyAsync(inwin, dst, sizeof(int16_t) * (size_t)Lo.total, hipMemcpyDeviceToHost, s);
@@ -3250,8 +3251,9 @@ static int coverage_impl(garlic_panel *p, int32_t winsize, double error, int32_t
             return done3(segments_from_bits(p, d_bits.p, d_bchrs.p, bchrs, word_base, W, sink));
         }
         if (!overlap)
-            hipLaunchKernelGGL(cov_counts_from_bits_kernel, dim3((unsigned)((word_base[(size_t)p->nchr] + 255) / 256), (unsigned)p->nind),
-                               dim3(256), 0, s, d_bits.p, d_bchrs.p, d_chrs.p, d_wbase.p, p->nchr, W, vec_ok ? 1 : 0, dst);
+            hipLaunchKernelGGL(cov_counts_from_bits_kernel, dim3((unsigned)((word_base[(size_t)p->nchr] + 255) / 256),
+                                                                 (unsigned)((p->nind + COV_ITEM_ROWS - 1) / COV_ITEM_ROWS)),
+                               dim3(256), 0, s, d_bits.p, d_bchrs.p, d_chrs.p, d_wbase.p, p->nchr, W, p->nind, vec_ok ? 1 : 0, dst);
         (void)hipEventRecord(ctx->hist1[slot], s);
         ctx->n_calls++;
         e = hipGetLastError();

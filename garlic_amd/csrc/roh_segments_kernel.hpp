@@ -79,7 +79,11 @@ roh_mask_from_bits_kernel(const uint32_t *__restrict__ bits, const ChrDev *__res
         const uint32_t wA = word(dA);
         const uint32_t F = __builtin_amdgcn_alignbit(word(dA + 1), wA, (uint32_t)r);      // bit j = window 32 t - W + j
         int cnt = (int)__popc(wA >> r);                               // windows 32 t - W .. 32 t - 1
-        for (int x = dA + 1; x < t; x++) cnt += (int)__popc(word(x));
+        for (int x = dA + 1; x < t; x += 4) {                         // (four loads in flight)
+            const uint32_t w0 = word(x), w1 = x + 1 < t ? word(x + 1) : 0u, w2 = x + 2 < t ? word(x + 2) : 0u,
+                           w3 = x + 3 < t ? word(x + 3) : 0u;
+            cnt += (int)(__popc(w0) + __popc(w1) + __popc(w2) + __popc(w3));
+        }
         // inside the word the count moves between cnt - popc(F) and cnt + popc(cur): most words are decided by that alone
         // (SNPs far from any qualifying window, or deep inside a stretch of them); the others walk their 32 steps
         uint32_t m = 0;
