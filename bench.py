@@ -133,9 +133,10 @@ def fp64_roofline(kernel, windows, W, kernel_ms, **extra):
     return r
 
 
-def cpu_baseline(spec, geno_sample, W, gpu_rows, seconds_budget=25.0):
+def cpu_baseline(spec, geno_sample, W, gpu_rows, seconds_budget=25.0, all_cores=True):
     """Times the CPU path on `geno_sample` (int16 [nloci][n_s]) one chromosome at a time and checks the GPU
-    rows against it.  Returns the cpu_baseline JSON object."""
+    rows against it.  Returns the cpu_baseline JSON object.  (At N > 1 every rank runs it on a few of its own
+    individuals with a small budget: the bit check per rank; rank 0's timing is the line's cpu_baseline.)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
 
@@ -156,6 +157,17 @@ def cpu_baseline(spec, geno_sample, W, gpu_rows, seconds_budget=25.0):
     # (ii) all host cores, SURVEY 8(d): independent slices of individuals, one per core, through the C port
     # (oracle/) -- the reference itself has no threaded calcLOD.  One chromosome's worth of the same sample.
     # The GPU box gives one GPU's job a share of 16 host cores whatever the affinity mask says.
+    single = {
+        "value": windows / W / t_total, "unit": "LOD-windows/s", "cores": 1,
+        "kind": "reference" if use_ref else "port",
+        "sample": f"{n_s} individuals x {windows // n_s} SNPs ({c + 1} of {spec.nchr} chromosomes) of the same panel, "
+                  f"single thread (calcLOD is single-threaded in the reference), {t_total:.1f} s",
+        "sliding_windows_per_s": windows / t_total,
+        "gpu_bit_mismatches_on_sample": int(mismatches),
+        "values_compared": int(windows),
+    }
+    if not all_cores:
+        return single
     ncores = min(len(os.sched_getaffinity(0)), int(os.environ.get("GARLIC_BENCH_CORES", "16")))
     lo, hi = int(spec.chr_off[0]), int(spec.chr_off[1])
     a0 = (np.ascontiguousarray(geno_sample[lo:hi]), spec.freq[lo:hi], spec.pos[lo:hi], int(spec.centro_start[0]),
@@ -167,17 +179,9 @@ def cpu_baseline(spec, geno_sample, W, gpu_rows, seconds_budget=25.0):
         ol.oracle_calc_lod(*a0, threads=ncores)
         t_all += time.perf_counter() - t0
         reps += 1
-    return {
-        "value": windows / W / t_total, "unit": "LOD-windows/s", "cores": 1,
-        "kind": "reference" if use_ref else "port",
-        "sample": f"{n_s} individuals x {windows // n_s} SNPs ({c + 1} of {spec.nchr} chromosomes) of the same panel, "
-                  f"single thread (calcLOD is single-threaded in the reference), {t_total:.1f} s",
-        "sliding_windows_per_s": windows / t_total,
-        "gpu_bit_mismatches_on_sample": int(mismatches),
-        "all_cores": {"value": (hi - lo) * n_s * reps / W / t_all, "unit": "LOD-windows/s", "cores": ncores, "kind": "port",
+    return dict(single, all_cores={"value": (hi - lo) * n_s * reps / W / t_all, "unit": "LOD-windows/s", "cores": ncores, "kind": "port",
                       "sample": f"{n_s} individuals x {hi - lo} SNPs (chromosome 1), {n_s // max(1, ncores)} "
-                                f"individuals per core, {reps} repetitions, {t_all:.1f} s"},
-    }
+                                f"individuals per core, {reps} repetitions, {t_all:.1f} s"})
 
 
 def load_panel(ctx, spec, nind, dev, ind_offset=0, n_cpu=0, gq=False):
@@ -395,13 +399,13 @@ def leg_ns(ctx, dev, steps):
                                            "up to 32 of them); the pair counts are banded Gram matrices of the subsample's bit "
                                            "planes on the matrix cores (ld_pair_mfma_kernel, i8), hr2 two FP64 divisions per SNP pair",
                                   "kernel": "ld_* (planes -- kept across calls --, pair counts, hr2 table, ordered sums + wLOD weights) -- the whole warm call",
-                                  "achieved": adds / t / 1e12, "peak": FP64_PEAK_TFLOPS / 2, "unit": "TFLOP/s (adds only)",
-                                  "frac": adds / t / 1e12 / (FP64_PEAK_TFLOPS / 2), "traffic": None,
+                                  "achieved": adds / t / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s (adds only; one separately rounded FP64 operation = one op, as in every other FP64 leg)",
+                                  "frac": adds / t / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
                                   "ordered_adds_per_call": adds,
                                   "dominant_kernel": {"kernel": "ld_sum_col_kernel (ordered sums + wLOD weights)", "kernel_ms": k_sum,
-                                                      "achieved": adds / (k_sum * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS / 2,
+                                                      "achieved": adds / (k_sum * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
                                                       "unit": "TFLOP/s (adds only)",
-                                                      "frac": adds / (k_sum * 1e-3) / 1e12 / (FP64_PEAK_TFLOPS / 2)},
+                                                      "frac": adds / (k_sum * 1e-3) / 1e12 / FP64_PEAK_TFLOPS},
                                   "popcounts_per_call": float(nloci) * (W - 1) * 2 * ((nsub + 63) // 64)}}
     dt, k = timed_passes(ctx, lambda: panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU), steps, 1,
                          torch.cuda.synchronize)
@@ -521,6 +525,19 @@ def leg_end_to_end(ctx, dev):
             "feed_only": {"call_s": t_feed, "value": win / W / t_feed, "unit": "LOD-windows/s", "feed_values": int(feed.shape[0])}}
 
 
+def self_launch(n):
+    """python bench.py --gpus N without torch.distributed.run: the same command under the launcher, as a child"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: no launcher (WORLD_SIZE unset), starting: " + " ".join(cmd), file=sys.stderr)
+    return subprocess.run(cmd).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -530,6 +547,8 @@ def main():
     ap.add_argument("--mode", default="lod", choices=["lod", "wlod", "tgls"])
     ap.add_argument("--inds", type=int, default=0, help="individuals per GPU (default: workload's)")
     ap.add_argument("--cpu-inds", type=int, default=512, help="individuals in the CPU-baseline sample")
+    ap.add_argument("--cpu-inds-multi", type=int, default=16,
+                    help="N > 1: individuals of its own shard every rank checks against the CPU path")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--out-candidates", type=int, default=8,
                     help="score buffers to try for the timed passes (placement in VRAM changes the kernel time)")
@@ -538,11 +557,18 @@ def main():
                     help="no further `also` leg is started once the run has taken this long")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # asked for N GPUs without a launcher: start one rank per GPU as a CHILD process (nothing has touched the GPU
+        # yet in this one) and relay its line -- never fall through to a one-GPU run that calls itself N
+        sys.exit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     from garlic_amd import abi, shard, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -560,7 +586,6 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     wl = args.workload or ("c2" if world == 1 else "ns")
     nloci, nind, W, seed_off, desc = WORKLOADS[wl]
@@ -570,8 +595,15 @@ def main():
 
     ctx = abi.Context(local_rank)
     ctx.set_async(True)   # repeated passes with device-resident output are enqueued back to back
-    # CPU baseline: rank 0 of the single-GPU run only (the other ranks of a larger run would wait for it)
-    n_cpu = 0 if (args.no_cpu or rank != 0 or world > 1 or args.mode != "lod") else min(args.cpu_inds, nind)
+    # CPU baseline: N = 1: the bounded sample of SURVEY 8(d) on rank 0.  N > 1: EVERY rank keeps a few of its own
+    # individuals on the host and checks their scores bit for bit against the CPU path after the timed region (a
+    # few seconds: the others wait for nobody longer than that); rank 0's timing of it is the line's cpu_baseline
+    if args.no_cpu or args.mode != "lod":
+        n_cpu = 0
+    elif world > 1:
+        n_cpu = min(args.cpu_inds_multi, nind)
+    else:
+        n_cpu = min(args.cpu_inds, nind)
     panel, geno_sample = load_panel(ctx, spec, nind, dev, ind_offset=rank * nind, n_cpu=n_cpu, gq=(args.mode == "tgls"))
 
     PITCH_ALIGN = 32
@@ -663,7 +695,19 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    solo_elapsed = None
     if world > 1:
+        # rank 0 alone first, the other GPUs idle: the same K steps of the same shard, so that the joint line can be
+        # read against a one-GPU point of the SAME workload (no collective on the data path: expect joint = solo;
+        # what is missing is host, power or PCIe, not the kernels)
+        dist.barrier()
+        if rank == 0:
+            ts = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            solo_elapsed = time.perf_counter() - ts
+            solo_kernel_ms = float(np.mean(ctx.recent_kernel_ms(min(args.steps, 32))))
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -688,6 +732,27 @@ def main():
     if os.environ.get("GARLIC_BENCH_DEBUG"):
         print("debug: kernel ms of the timed steps:", [round(x, 3) for x in kernel_ms], file=sys.stderr)
     st = panel.stats()
+    # the bit check: this rank's first n_cpu individuals against the CPU path (reference build if present, else the port)
+    cpu = None
+    if n_cpu:
+        host = out.cpu().numpy() if total * 8 < (6 << 30) else None
+        rows = []
+        for c in range(spec.nchr):
+            n = int(spec.chr_nloci[c])
+            if host is not None:
+                blk = host[base[c]: base[c] + nind * pitch[c]].reshape(nind, pitch[c])
+            else:
+                blk = out[base[c]: base[c] + nind * pitch[c]].view(nind, pitch[c])[:n_cpu].cpu().numpy()
+            rows.append(blk[:n_cpu, :n])
+        cpu = cpu_baseline(spec, geno_sample, W, rows, seconds_budget=25.0 if world == 1 else 4.0, all_cores=(world == 1))
+        del host, rows
+    mism_by_rank = None
+    if world > 1:
+        m = torch.tensor([cpu["gpu_bit_mismatches_on_sample"] if cpu else -1, cpu["values_compared"] if cpu else 0],
+                         dtype=torch.int64, device="cpu" if rehearse else dev)
+        g = [torch.zeros_like(m) for _ in range(world)]
+        dist.all_gather(g, m)
+        mism_by_rank = [[int(x[0].item()), int(x[1].item())] for x in g]
     if rank == 0:
         windows_per_step = nloci * nind * world            # sliding windows (SNPs x inds)
         lod_windows_per_step = windows_per_step / W        # BASELINE.json unit
@@ -725,6 +790,16 @@ def main():
         }
         if per_rank is not None:
             res["ms_per_step_by_rank"] = per_rank
+            solo_value = nloci * nind / W * args.steps / solo_elapsed
+            res["per_gpu_value"] = res["value"] / world
+            res["solo_value_rank0"] = solo_value
+            res["solo_ms_per_step_rank0"] = solo_elapsed / args.steps * 1e3
+            res["solo_kernel_ms_rank0"] = solo_kernel_ms
+            res["efficiency"] = res["per_gpu_value"] / solo_value
+            res["efficiency_note"] = ("joint per-GPU rate (max over ranks) / rank 0 running the same shard alone just before, the "
+                                      "other GPUs idle; ms_per_step_by_rank shows which rank set the joint time")
+            res["gpu_bit_mismatches_by_rank"] = [x[0] for x in mism_by_rank]
+            res["values_compared_by_rank"] = [x[1] for x in mism_by_rank]
         if setup:
             res["setup"] = setup
         if placement:
@@ -736,21 +811,9 @@ def main():
                     res["roofline"][name] = alg / (placement[key] * 1e-3) / 1e9 / res["roofline"]["peak"]
                 res["roofline"]["placement_note"] = ("frac: the buffer garlic_panel_alloc_scores kept (what a caller of the library "
                                                      "gets); frac_median / frac_worst: the median / worst of its candidates")
-        if n_cpu:
-            host = out.cpu().numpy() if total * 8 < (6 << 30) else None
-            rows = []
-            for c in range(spec.nchr):
-                n = int(spec.chr_nloci[c])
-                if host is not None:
-                    blk = host[base[c]: base[c] + nind * pitch[c]].reshape(nind, pitch[c])
-                else:
-                    blk = out[base[c]: base[c] + nind * pitch[c]].view(nind, pitch[c])[:n_cpu].cpu().numpy()
-                rows.append(blk[:n_cpu, :n])
-            res["cpu_baseline"] = cpu_baseline(spec, geno_sample, W, rows)
-            res["speedup_vs_cpu_baseline"] = res["value"] / res["cpu_baseline"]["value"]
-            del host
-        else:
-            res["cpu_baseline"] = None
+        res["cpu_baseline"] = cpu
+        if cpu:
+            res["speedup_vs_cpu_baseline"] = res["value"] / cpu["value"]
     panel.close()
     del out, geno_sample
     if out_buf is not None:
