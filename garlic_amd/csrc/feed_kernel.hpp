@@ -1,36 +1,38 @@
 // Thinned LOD scores for the KDE feed (the explore / auto-winsize flows, src/garlic-roh.cpp:726-751, 798-837,
 // 881-920 -> convertWinData2DoubleData, src/garlic-data.cpp:2026-2069: only the windows at chromosome-local
-// loci 0, step, 2*step, .. are ever looked at).
+// loci 0, step, 2*step, .. are ever looked at), and the same chains leaving one bit per window (score >= cutoff)
+// for the final pass (coverage_kernel.hpp, roh_segments_kernel.hpp).
 //
 // With no score stream to write, the window recurrence (src/garlic-roh.cpp:92-100) is all there is, and the
 // four-role kernel of lod_kernels.hpp -- three helper waves feeding ONE chain wave per CU, built for the
-// store-bound full output -- leaves the machine idle: 35 cycles per window and CU.  Here every wave is a
-// chain of its own and a CU runs sixteen of them:
+// store-bound full output -- leaves the machine idle.  Here every wave is a chain of its own and a CU runs
+// sixteen of them:
 //
 //   work item   one run of valid windows x FEED_G 64-individual blocks = one workgroup of FEED_G waves (lane =
 //               individual); persistent workgroups (four per CU) pull items longest run first; the waves of the
 //               longest runs raise their issue priority (s_setprio): the run length x the pace of one wave is
 //               the kernel's critical path, everything shorter fills the issue slots they leave;
-//   term rows   {lod(0), lod(1), lod(2), +0.0} of the 32 entering and of the 32 leaving SNPs of a tile of 32
-//               windows: two 1-KB chunks per tile, each in a 4-slot ring in LDS shared by the workgroup's waves
-//               (tile t in slot (t + 3) % 4), fetched by LDS-DMA three tiles ahead, a quarter per wave; whatever
-//               the window size: 9 KB of LDS;
+//   interior    tiles of 32 windows, GARLIC_FEED_UNROLL of them per iteration of the hand-scheduled loop of
+//               tools/gen_feed_asm.py (feed_loop_gfx950.inc; round 4: 5.3 instructions per window and lane, 7.1 with
+//               the coverage bit): per window ONE look-up -- {t_out, t_in} of the lane's genotype pair, a
+//               ds_read_b128 from the window's 16-entry pair table -- whose offset comes out of a word of 4-bit
+//               genotype-pair codes by one SDWA instruction, and the two dependent adds acc = (acc - t_out) + t_in.
+//               The pair tables (8 KB per tile, a ring of four in LDS, 33 KB per workgroup) are built by the
+//               workgroup's waves themselves, a quarter each, from the term table in memory two tiles ahead; one
+//               s_barrier per tile is the ring's protocol;
 //   genotypes   the lane's own packed words straight into registers (one dword per 16 SNPs and stream); the leaving
 //               stream is a second, cache-served read of the same words;
-//   per window  the genotype's term offset for both streams, two ds_read_b64, the two dependent adds
-//               acc = (acc - t_out) + t_in;
-//   samples     a sampled locus is stored straight from the lanes, 8 B each, into a [row][column] matrix per chromosome.
+//   edges       a run's first tile, its last ones, the tiles in front of the loop's first aligned one and everything
+//               of a shard that does not start on a block boundary go through the compiler-generated tile below,
+//               which takes its terms from the term table in memory and needs no ring;
+//   samples     a sampled locus goes straight from the lanes into a [row][column] matrix per chromosome, four
+//               consecutive samples of a lane as one 32-byte piece (edges: 8 B each).
 //               The host chooses rows and columns: row = individual, column = locus / step gives the thinned score
 //               matrix; row = position in the caller's individual list, column = rank of the sample among the
 //               chromosome's scored samples gives the KDE feed itself (convertWinData2DoubleData's order: the mask
-//               is the same for every individual, so the rank of a sample is known before anything is computed).
-//
-// One barrier per tile keeps the FEED_G waves within a tile of each other: the rings' only protocol.  Tile t:
-// barrier | request the chunks of tile t + 3 | the tile | wait for what was requested.
-// Interior tiles (every window a rolling update) go through the hand-scheduled loop of tools/gen_feed_asm.py
-// (feed_loop_gfx950.inc), 4 n tiles at a time from tile 1 on; a run's first tile, its last ones and everything
-// of a shard that does not start on a block boundary through the compiler-generated tile below, which keeps
-// the same protocol.
+//               is the same for every individual, so the rank of a sample is known before anything is computed);
+//   bits        (lod_bits_kernel) a tile's 32 bits are one dword per lane; the loop starts at a tile index that is a
+//               multiple of eight and stores eight tiles' dwords as one aligned 32-byte piece per lane.
 #pragma once
 #include "lod_kernels.hpp"
 #include "cov_counts.hpp"
@@ -38,8 +40,7 @@
 
 namespace garlic {
 
-constexpr int FEED_G = 4;                 // waves (64-individual blocks) per workgroup: each moves a quarter of a chunk
-constexpr int FEED_AHEAD = GARLIC_FEED_AHEAD;
+constexpr int FEED_G = 4;                 // waves (64-individual blocks) per workgroup: each builds a quarter of a tile's pair table
 
 struct FeedItem {
     int32_t chr, a, b;        // run of valid windows [a, b] (chromosome-local)
@@ -91,17 +92,6 @@ __device__ __forceinline__ void feed_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// this wave's quarter (256 B = 8 rows) of a 1-KB chunk of term rows: lane i moves bytes 4 i .. 4 i + 3 of the quarter
-__device__ __forceinline__ void feed_dma_quarter(uint32_t lds_quarter, const double *chunk, uint32_t dma_off)
-{
-    const uint64_t u = reinterpret_cast<uint64_t>(chunk);      // wave-uniform: say so
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-    chunk = reinterpret_cast<const double *>(((uint64_t)hi << 32) | lo);
-    lds_quarter = __builtin_amdgcn_readfirstlane(lds_quarter);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
-                 :: "s"(lds_quarter), "v"(dma_off), "s"(chunk) : "memory");
-}
-
 // wave-uniform values for the "s" operands of the inline assembly (hipcc passes a VGPR where it has not proven uniformity)
 __device__ __forceinline__ uint32_t feed_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 template <class T> __device__ __forceinline__ T *feed_uni(T *ptr)
@@ -110,28 +100,14 @@ template <class T> __device__ __forceinline__ T *feed_uni(T *ptr)
     return reinterpret_cast<T *>(((uint64_t)feed_uni((uint32_t)(u >> 32)) << 32) | feed_uni((uint32_t)u));
 }
 
-// LDS address of the term of step j (0..15) of a funnel-shifted genotype word: (genotype * 8) | rows
-__device__ __forceinline__ uint32_t feed_addr(uint32_t w, int j, uint32_t rows)
-{
-    const uint32_t x = (2 * j >= 3) ? (w >> (2 * j - 3)) : (w << (3 - 2 * j));
-    uint32_t a;
-    asm("v_and_or_b32 %0, %1, 24, %2" : "=v"(a) : "v"(x), "s"(rows));
-    return a;
-}
-
-__device__ __forceinline__ double feed_lds_double(uint32_t addr)
-{
-    return *reinterpret_cast<const __attribute__((address_space(3))) double *>((uintptr_t)addr);
-}
-
 template <bool BITS>
 __device__ __forceinline__ void lod_feed_body(const FeedArgs &p)
 {
     // one LDS object at offset 0: the hand-scheduled loop addresses the rings with absolute offsets
     __shared__ __attribute__((aligned(1024))) unsigned char smem[BITS && FEED_BITS_LDS > GARLIC_FEED_LDS_TOTAL ? FEED_BITS_LDS : GARLIC_FEED_LDS_TOTAL];
+    static_assert((GARLIC_FEED_UNROLL & (GARLIC_FEED_UNROLL - 1)) == 0, "tiles per iteration: a power of two");
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t dma_off = (uint32_t)lane * 4u + (uint32_t)wave * 256u;
     // LDS address of smem: 0, the kernel's only LDS object (taking it here also keeps the whole array allocated: most of
     // it is only ever touched through the integer addresses below and the loop's immediates)
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem);
@@ -226,15 +202,10 @@ __device__ __forceinline__ void lod_feed_body(const FeedArgs &p)
 
         const int first = a & ~(TILE - 1);
         const int ntiles = ((b - first) >> 5) + 1;
-        // term rows: the chunks of tile t are rows first + W - 1 + 32 t .. (entering) and first - 1 + 32 t .. (leaving)
-        const double *lead_chunks = p.tab + (Gbase + first + W - 1) * 4;
-        const double *trail_chunks = p.tab + (Gbase + first - 1) * 4;
-        // (pad rows behind the table and the packed panel make requests past the run's last tile harmless)
-        for (int t = 0; t < FEED_AHEAD; t++) {
-            const uint32_t slot = (uint32_t)((t + 3) & 3) * 1024u + (uint32_t)wave * 256u;
-            feed_dma_quarter(lds0 + GARLIC_FEED_LDS_LEAD + slot, lead_chunks + (int64_t)t * 128, dma_off);
-            feed_dma_quarter(lds0 + GARLIC_FEED_LDS_TRAIL + slot, trail_chunks + (int64_t)t * 128, dma_off);
-        }
+        // term rows {lod(0), lod(1), lod(2), +0.0}: window s takes SNP s + W - 1 in and SNP s - 1 out
+        const double *lead_rows = p.tab + (Gbase + first + W - 1) * 4;
+        const double *trail_rows = p.tab + (Gbase + first - 1) * 4;
+        // (pad rows behind the table and the packed panel make the loop's requests past the run's last tile harmless)
 
         // ---- first window of the run: its first W-1 terms left to right (garlic-roh.cpp:57-71); the W-th
         //      enters in the first tile.  32 SNPs per round, every load of a round before its first add.
@@ -268,25 +239,30 @@ __device__ __forceinline__ void lod_feed_body(const FeedArgs &p)
         int next = (a + step - 1) / step * step;
         double *const out_chr = p.out + c.out_base;
         int col = it->col0;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's quarters of the first chunks
         if (p.trace && threadIdx.x == 0) {
             p.trace[8 * item_idx + 2] = wall_clock64();
             p.trace[8 * item_idx + 5] = clock64();
         }
 
-        // interior tiles 1 .. k_int (all 32 windows inside (a, b]); the hand-scheduled loop takes 4 n of them
+        // interior tiles 1 .. k_int (all 32 windows inside (a, b]); the hand-scheduled loop takes GARLIC_FEED_UNROLL n of
+        // them from tile k0 on -- bits: the first tile whose dword sits at a multiple of eight in the lanes' rows, so that
+        // an iteration's eight dwords are one aligned 32-byte piece
         const int k_int = (b - first - (TILE - 1)) >> 5;
-        const int niter = (p.use_asm && lds0 == 0 && (col0 & 63) == 0 && k_int >= 1) ? k_int / 4 : 0;
+        const int k0 = BITS ? GARLIC_FEED_UNROLL - ((first >> 5) & (GARLIC_FEED_UNROLL - 1)) : 1;
+        const bool asm_ok = p.use_asm && lds0 == 0 && (col0 & 63) == 0 &&
+                            (!BITS || (((c.out_pitch | c.out_base) & 7) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 31) == 0));
+        const int niter = (asm_ok && k_int >= k0) ? (k_int - k0 + 1) / GARLIC_FEED_UNROLL : 0;
         for (int k = 0; k < ntiles; k++) {
-            if (k == 1 && niter > 0) {
-                const int s0 = first + TILE;
+            if (k == k0 && niter > 0) {
+                const int s0 = first + k0 * TILE;
                 const uint32_t *blk = p.packed + packed_index(0, col0, p.nwordrows);     // the block's word rows (lane 0)
-                const uint32_t *plw = blk + ((Glead + TILE) >> 4) * WAVE;                // word row 0 of tile 1
-                const uint32_t *ptw = blk + ((Gtrail + TILE) >> 4) * WAVE;
+                const uint32_t *plw = blk + ((Glead + (int64_t)k0 * TILE) >> 4) * WAVE;    // word row 0 of the loop's first tile
+                const uint32_t *ptw = blk + ((Gtrail + (int64_t)k0 * TILE) >> 4) * WAVE;
+                const double *ptl = lead_rows + (int64_t)k0 * TILE * 4, *ptt = trail_rows + (int64_t)k0 * TILE * 4;
                 const double *out_next = out_chr + col;
                 uint32_t next_rel = (uint32_t)(next - s0);
                 if (BITS) {
-                    // the dword of tile 1 in row 0 of the bit matrix; rows are out_pitch dwords apart
+                    // the dword of the loop's first tile in row 0 of the bit matrix; rows are out_pitch dwords apart
                     const uint32_t *bits_next = reinterpret_cast<const uint32_t *>(p.out) + c.out_base + (s0 >> 5);
                     const uint32_t *bits_out;
                     const uint64_t cutbits = __builtin_bit_cast(uint64_t, p.cutoff);
@@ -294,35 +270,27 @@ __device__ __forceinline__ void lod_feed_body(const FeedArgs &p)
                     asm volatile(GARLIC_FEED_BITS_LOOP_ASM
                                  : [acc] "+v"(acc), [next_out] "=s"(next_rel), [out_out] "=s"(bits_out)
                                  : [wave] "s"(wave), [lane] "v"(lane), [active] "s"(feed_uni(active ? 1u : 0u)), [plw] "s"(feed_uni(plw)),
-                                   [ptw] "s"(feed_uni(ptw)), [ptl] "s"(feed_uni(lead_chunks + 128)), [ptt] "s"(feed_uni(trail_chunks + 128)),
+                                   [ptw] "s"(feed_uni(ptw)), [ptl] "s"(feed_uni(ptl)), [ptt] "s"(feed_uni(ptt)),
                                    [out] "s"(feed_uni(bits_next)), [next] "s"(feed_uni(next_rel)), [step] "s"(feed_uni((uint32_t)step)),
                                    [shl] "s"(feed_uni((uint32_t)sh_lead)), [sht] "s"(feed_uni((uint32_t)sh_trail)),
                                    [row] "v"(row), [pitch8] "s"(feed_uni((uint32_t)(c.out_pitch * 4))),
                                    [niter] "s"(feed_uni((uint32_t)niter)), [cut] "s"(cut)
                                  : GARLIC_FEED_LOOP_CLOBBERS);
-                    k += 4 * niter;
-                    if (k >= ntiles) break;
                 } else {
-                asm volatile(GARLIC_FEED_LOOP_ASM
-                             : [acc] "+v"(acc), [next_out] "=s"(next_rel), [out_out] "=s"(out_next)
-                             : [wave] "s"(wave), [lane] "v"(lane), [active] "s"(feed_uni(active ? 1u : 0u)), [plw] "s"(feed_uni(plw)),
-                               [ptw] "s"(feed_uni(ptw)), [ptl] "s"(feed_uni(lead_chunks + 128)), [ptt] "s"(feed_uni(trail_chunks + 128)),
-                               [out] "s"(feed_uni(out_next)), [next] "s"(feed_uni(next_rel)), [step] "s"(feed_uni((uint32_t)step)),
-                               [shl] "s"(feed_uni((uint32_t)sh_lead)), [sht] "s"(feed_uni((uint32_t)sh_trail)),
-                               [row] "v"(row), [pitch8] "s"(feed_uni((uint32_t)(c.out_pitch * 8))),
-                               [niter] "s"(feed_uni((uint32_t)niter))
-                             : GARLIC_FEED_LOOP_CLOBBERS);
-                k += 4 * niter;
-                next = first + k * TILE + (int)next_rel;
-                col = (int)(out_next - out_chr);
-                if (k >= ntiles) break;
+                    asm volatile(GARLIC_FEED_LOOP_ASM
+                                 : [acc] "+v"(acc), [next_out] "=s"(next_rel), [out_out] "=s"(out_next)
+                                 : [wave] "s"(wave), [lane] "v"(lane), [active] "s"(feed_uni(active ? 1u : 0u)), [plw] "s"(feed_uni(plw)),
+                                   [ptw] "s"(feed_uni(ptw)), [ptl] "s"(feed_uni(ptl)), [ptt] "s"(feed_uni(ptt)),
+                                   [out] "s"(feed_uni(out_next)), [next] "s"(feed_uni(next_rel)), [step] "s"(feed_uni((uint32_t)step)),
+                                   [shl] "s"(feed_uni((uint32_t)sh_lead)), [sht] "s"(feed_uni((uint32_t)sh_trail)),
+                                   [row] "v"(row), [pitch8] "s"(feed_uni((uint32_t)(c.out_pitch * 8))),
+                                   [niter] "s"(feed_uni((uint32_t)niter))
+                                 : GARLIC_FEED_LOOP_CLOBBERS);
+                    next = first + (k + GARLIC_FEED_UNROLL * niter) * TILE + (int)next_rel;
+                    col = (int)(out_next - out_chr);
                 }
-            }
-            feed_barrier();   // every wave is done with tile k-1; the chunks of tiles <= k + 2 have landed
-            {
-                const uint32_t slot = (uint32_t)((k + FEED_AHEAD + 3) & 3) * 1024u + (uint32_t)wave * 256u;
-                feed_dma_quarter(lds0 + GARLIC_FEED_LDS_LEAD + slot, lead_chunks + (int64_t)(k + FEED_AHEAD) * 128, dma_off);
-                feed_dma_quarter(lds0 + GARLIC_FEED_LDS_TRAIL + slot, trail_chunks + (int64_t)(k + FEED_AHEAD) * 128, dma_off);
+                k += GARLIC_FEED_UNROLL * niter;
+                if (k >= ntiles) break;
             }
             if (active) {
                 const int s0 = first + k * TILE;
@@ -332,8 +300,7 @@ __device__ __forceinline__ void lod_feed_body(const FeedArgs &p)
                 const uint32_t t0 = tw[0], t1 = tw[WAVE], t2 = tw[2 * WAVE];
                 const uint32_t lead_w[2] = {__builtin_amdgcn_alignbit(l1, l0, sh_lead), __builtin_amdgcn_alignbit(l2, l1, sh_lead)};
                 const uint32_t trail_w[2] = {__builtin_amdgcn_alignbit(t1, t0, sh_trail), __builtin_amdgcn_alignbit(t2, t1, sh_trail)};
-                const uint32_t lead_rows = lds0 + GARLIC_FEED_LDS_LEAD + (uint32_t)((k + 3) & 3) * 1024u;
-                const uint32_t trail_rows = lds0 + GARLIC_FEED_LDS_TRAIL + (uint32_t)((k + 3) & 3) * 1024u;
+                const double *tl = lead_rows + (int64_t)k * TILE * 4, *tt = trail_rows + (int64_t)k * TILE * 4;
                 uint32_t tile_bits = 0;
 #pragma unroll
                 for (int bq = 0; bq < 4; bq++) {
@@ -341,8 +308,8 @@ __device__ __forceinline__ void lod_feed_body(const FeedArgs &p)
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
                         const int j = 8 * bq + i;
-                        tin[i] = feed_lds_double(feed_addr(lead_w[j >> 4], j & 15, lead_rows) + (uint32_t)j * 32u);
-                        tout[i] = feed_lds_double(feed_addr(trail_w[j >> 4], j & 15, trail_rows) + (uint32_t)j * 32u);
+                        tin[i] = tl[4 * j + ((lead_w[j >> 4] >> (2 * (j & 15))) & 3u)];
+                        tout[i] = tt[4 * j + ((trail_w[j >> 4] >> (2 * (j & 15))) & 3u)];
                     }
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
@@ -365,7 +332,6 @@ __device__ __forceinline__ void lod_feed_body(const FeedArgs &p)
                 if (BITS && row >= 0 && tile_bits)
                     atomicOr(reinterpret_cast<uint32_t *>(p.out) + c.out_base + (int64_t)row * c.out_pitch + (s0 >> 5), tile_bits);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's quarters of the chunks of tile k + 3
         }
         if (p.trace && threadIdx.x == 0) {
             p.trace[8 * item_idx + 3] = wall_clock64();

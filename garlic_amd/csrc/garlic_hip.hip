@@ -3099,31 +3099,16 @@ static int coverage_impl(garlic_panel *p, int32_t winsize, double error, int32_t
     std::vector<int32_t> col0(runs.size(), 0);
     std::vector<FeedItem> items;
     build_feed_items(runs, order, nullptr, nblk, col0, items);
-    // what no run covers: zeroed by a kernel of its own (a run [a, b] covers the SNPs a .. b + W - 1)
-    std::vector<CovRange> ranges;
-    {
-        size_t r = 0;
-        for (int c = 0; c < p->nchr; c++) {
-            int32_t cursor = 0;
-            const int32_t n = (int32_t)p->chr_nloci[c];
-            for (; r < runs.size() && runs[r].chr == c; r++) {
-                if (runs[r].a > cursor) ranges.push_back(CovRange{c, cursor, runs[r].a});
-                cursor = std::max<int32_t>(cursor, std::min<int32_t>(runs[r].b + W, n));
-            }
-            if (cursor < n) ranges.push_back(CovRange{c, cursor, n});
-        }
-    }
     const Layout Lo = make_layout(p, inwin_pitch_align, p->nind);
     std::vector<ChrDev> chrs((size_t)p->nchr);
     for (int c = 0; c < p->nchr; c++) chrs[(size_t)c] = ChrDev{p->chr_off[c], Lo.base[c], Lo.pitch[c], p->chr_nloci[c], 0};
     DevBuf<FeedItem> d_items;
     DevBuf<ChrDev> d_chrs;
-    DevBuf<CovRange> d_ranges;
     DevBuf<int32_t> d_counter;
     DevBuf<int16_t> d_cov;
-    auto done = [&](int code) { d_items.release(); d_chrs.release(); d_ranges.release(); d_counter.release(); d_cov.release(); return code; };
+    auto done = [&](int code) { d_items.release(); d_chrs.release(); d_counter.release(); d_cov.release(); return code; };
     if ((rc = d_items.reserve(std::max<size_t>(items.size(), 1))) || (rc = d_chrs.reserve(chrs.size())) ||
-        (rc = d_ranges.reserve(std::max<size_t>(ranges.size(), 1))) || (rc = d_counter.reserve(4)))
+        (rc = d_counter.reserve(4)))
         return done(rc);
     int16_t *dst = inwin;
     if (where == GARLIC_HOST) {
@@ -3133,16 +3118,12 @@ static int coverage_impl(garlic_panel *p, int32_t winsize, double error, int32_t
     hipError_t e = hipMemcpyAsync(d_chrs.p, chrs.data(), sizeof(ChrDev) * chrs.size(), hipMemcpyHostToDevice, s);
     if (e == hipSuccess && !items.empty())
         e = hipMemcpyAsync(d_items.p, items.data(), sizeof(FeedItem) * items.size(), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && !ranges.empty())
-        e = hipMemcpyAsync(d_ranges.p, ranges.data(), sizeof(CovRange) * ranges.size(), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_counter.p, 0, 4 * sizeof(int32_t), s);
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
-    const int ring = (W + 32 + 31) / 32 * 32;
-    const size_t lds = GARLIC_FEED_LDS_TOTAL + sizeof(uint64_t) * (size_t)ring * FEED_G;
     bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
     for (int c = 0; c < p->nchr; c++) vec_ok = vec_ok && Lo.base[c] % 8 == 0 && Lo.pitch[c] % 8 == 0;
     const int slot = (int)(ctx->n_calls % garlic_ctx::HIST);
-    if (sink.segments || !getenv("GARLIC_COVERAGE_ONE_KERNEL")) {
+    {
         // two kernels: one bit per window and individual from the hand-scheduled chain (lod_bits_kernel), then the
         // sliding counts from the bits (cov_counts_from_bits_kernel): a 64th of the score bytes in between
         std::vector<ChrDev> bchrs((size_t)p->nchr);
@@ -3150,10 +3131,12 @@ static int coverage_impl(garlic_panel *p, int32_t winsize, double error, int32_t
         int64_t boff = 0;
         for (int c = 0; c < p->nchr; c++) {
             const int64_t words = (p->chr_nloci[c] + 31) / 32;
-            bchrs[(size_t)c] = ChrDev{p->chr_off[c], boff, words, p->chr_nloci[c], 0};
-            boff += words * p->nind;
+            // rows a multiple of eight dwords long: the chain kernel stores eight tiles' dwords as one aligned 32-byte piece
+            const int64_t row_words = (words + 7) / 8 * 8;
+            bchrs[(size_t)c] = ChrDev{p->chr_off[c], boff, row_words, p->chr_nloci[c], 0};
+            boff += row_words * p->nind;
             word_base[(size_t)c + 1] = word_base[(size_t)c] + (int32_t)words;
-            if (words * 4 * (int64_t)p->nind >= (int64_t)1 << 32)
+            if (row_words * 4 * (int64_t)p->nind >= (int64_t)1 << 32)
                 return done(fail(GARLIC_ERR_INVALID, "chromosome %d: bit rows beyond 32-bit offsets", c));
         }
         PoolBuf<uint32_t> d_bits;
@@ -3267,37 +3250,6 @@ static int coverage_impl(garlic_panel *p, int32_t winsize, double error, int32_t
         if (timed_out) return done3(fail(GARLIC_ERR_HIP, "coverage: a count item gave up waiting for its chromosome's chains"));
         return done3(GARLIC_OK);
     }
-    (void)hipEventRecord(ctx->hist0[slot], s);
-    if (!ranges.empty())
-        hipLaunchKernelGGL(fill_i16_ranges_kernel, dim3((unsigned)ranges.size(), (unsigned)std::min(p->nind, 1024)), dim3(256), 0, s,
-                           d_ranges.p, d_chrs.p, p->nind, dst);
-    if (!items.empty()) {
-        CovArgs a{p->d_packed.p, p->d_tab.p, d_items.p, d_chrs.p, dst, p->nwordrows, p->nind, W, (int32_t)items.size(), ring,
-                  vec_ok ? 1 : 0, cutoff, d_counter.p};
-        // 32 <= W <= 224: the lanes' qualifying bits in registers; else the waves' ballot masks in LDS rings
-        const bool reghist = W >= 32 && W <= COVF_REG_MAX_W && !getenv("GARLIC_COVERAGE_LDS_RING");
-        const void *fn = reghist ? (const void *)lod_coverage_kernel<true> : (const void *)lod_coverage_kernel<false>;
-        if (lds > 48 * 1024) {
-            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
-        }
-        int per_cu = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FEED_G * WAVE, lds);
-        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
-        per_cu = std::max(1, std::min(per_cu, 16 / FEED_G));
-        const int grid = (int)std::min<size_t>(items.size(), (size_t)ctx->n_cu * per_cu);
-        void *kargs[] = {(void *)&a};
-        e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(FEED_G * WAVE), kargs, lds, s);
-        if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
-    }
-    (void)hipEventRecord(ctx->hist1[slot], s);
-    ctx->n_calls++;
-    e = hipGetLastError();
-    if (e == hipSuccess && where == GARLIC_HOST)
-        e = hipMemcpyAsync(inwin, dst, sizeof(int16_t) * (size_t)Lo.total, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
-    return done(GARLIC_OK);
 }
 
 int garlic_roh_coverage_fused(garlic_panel *p, int32_t winsize, double error, int32_t max_gap, int32_t use_gl,
