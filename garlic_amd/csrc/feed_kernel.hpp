@@ -9,19 +9,19 @@
 // sixteen of them:
 //
 //   work item   one run of valid windows x FEED_G 64-individual blocks = one workgroup of FEED_G waves (lane =
-//               individual); persistent workgroups (four per CU) pull items longest run first; the waves of the
+//               individual); persistent workgroups (three per CU: 42 KB of LDS each) pull items longest run first; the waves of the
 //               longest runs raise their issue priority (s_setprio): the run length x the pace of one wave is
 //               the kernel's critical path, everything shorter fills the issue slots they leave;
 //   interior    tiles of 32 windows, GARLIC_FEED_UNROLL of them per iteration of the hand-scheduled loop of
-//               tools/gen_feed_asm.py (feed_loop_gfx950.inc; round 4: 5.3 instructions per window and lane, 7.1 with
-//               the coverage bit): per window ONE look-up -- {t_out, t_in} of the lane's genotype pair, a
-//               ds_read_b128 from the window's 16-entry pair table -- whose offset comes out of a word of 4-bit
-//               genotype-pair codes by one SDWA instruction, and the two dependent adds acc = (acc - t_out) + t_in.
-//               The pair tables (8 KB per tile, a ring of four in LDS, 33 KB per workgroup) are built by the
-//               workgroup's waves themselves, a quarter each, from the term table in memory two tiles ahead; one
-//               s_barrier per tile is the ring's protocol;
-//   genotypes   the lane's own packed words straight into registers (one dword per 16 SNPs and stream); the leaving
-//               stream is a second, cache-served read of the same words;
+//               tools/gen_feed_asm.py (feed_loop_gfx950.inc; round 4: 5.8 instructions per window and lane, 7.6 with
+//               the coverage bit, 1.5 vector-memory instructions per tile and wave): per window ONE look-up -- {t_out,
+//               t_in} of the lane's genotype pair, a ds_read_b128 from the window's 16-entry pair table -- whose offset
+//               comes out of a word of 4-bit genotype-pair codes by one SDWA instruction, and the two dependent adds
+//               acc = (acc - t_out) + t_in.  The pair tables (8 KB per tile, a ring of four in LDS) are built by the
+//               workgroup's waves themselves, a quarter each, from the tile's raw term rows, which the waves take turns
+//               to bring in as two 1-KB loads; one s_barrier per tile is the rings' protocol;
+//   genotypes   the lanes' packed words, 4 word rows (1 KB) per load and stream, turned lane-wise through 1 KB of LDS
+//               into register rings; the leaving stream is a second, cache-served read of the same words;
 //   edges       a run's first tile, its last ones, the tiles in front of the loop's first aligned one and everything
 //               of a shard that does not start on a block boundary go through the compiler-generated tile below,
 //               which takes its terms from the term table in memory and needs no ring;
@@ -249,7 +249,7 @@ __device__ __forceinline__ void lod_feed_body(const FeedArgs &p)
         // an iteration's eight dwords are one aligned 32-byte piece
         const int k_int = (b - first - (TILE - 1)) >> 5;
         const int k0 = BITS ? GARLIC_FEED_UNROLL - ((first >> 5) & (GARLIC_FEED_UNROLL - 1)) : 1;
-        const bool asm_ok = p.use_asm && lds0 == 0 && (col0 & 63) == 0 &&
+        const bool asm_ok = p.use_asm && lds0 == 0 && (col0 & 63) == 0 && W + GARLIC_FEED_REACH <= GPAD_BACK &&
                             (!BITS || (((c.out_pitch | c.out_base) & 7) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 31) == 0));
         const int niter = (asm_ok && k_int >= k0) ? (k_int - k0 + 1) / GARLIC_FEED_UNROLL : 0;
         for (int k = 0; k < ntiles; k++) {
@@ -352,7 +352,7 @@ __device__ __forceinline__ void lod_feed_body(const FeedArgs &p)
     }
 }
 
-__global__ void __launch_bounds__(FEED_G * WAVE, 4)
+__global__ void __launch_bounds__(FEED_G * WAVE, 3)
 lod_feed_kernel(FeedArgs p)
 {
     lod_feed_body<false>(p);
@@ -360,7 +360,7 @@ lod_feed_kernel(FeedArgs p)
 
 // the same chains leaving one bit per window and individual (score >= cutoff) instead of sampled scores: the first
 // half of the coverage counts without a score matrix (coverage_kernel.hpp)
-__global__ void __launch_bounds__(FEED_G * WAVE, 4)
+__global__ void __launch_bounds__(FEED_G * WAVE, 3)
 lod_bits_kernel(FeedArgs p)
 {
     lod_feed_body<true>(p);
