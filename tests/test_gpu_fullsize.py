@@ -170,8 +170,25 @@ def test_run_to_run_determinism_200k_by_1000(gpu_ctx):
                     first = out.clone()
                 else:
                     assert torch.equal(out.view(torch.int64), first.view(torch.int64)), (name, rep)
-        feeds = [panel.lod_feed(W, 0.001, mg, W)[0] for _ in range(40)]
-        assert all(ol.bits_equal(f, feeds[0]) for f in feeds[1:])
+        # the chains that leave samples / bits instead of scores (feed_kernel.hpp; round 4: the raw term rows, the pair
+        # tables and the genotype words all come through LDS behind counted waits and one barrier per tile)
+        for step in (W, 7):
+            feeds = [panel.lod_feed(W, 0.001, mg, step)[0] for _ in range(40)]
+            assert all(ol.bits_equal(f, feeds[0]) for f in feeds[1:]), step
+        _, _, t8 = panel.out_layout(8, nind)
+        cov = torch.empty(t8, dtype=torch.int16, device=dev)
+        first = None
+        for rep in range(60):
+            cov.fill_(-1)
+            torch.cuda.synchronize()
+            panel.roh_coverage_fused_device(W, 0.001, mg, 2.5, cov.data_ptr(), pitch_align=8)
+            torch.cuda.synchronize()
+            if first is None:
+                first = cov.clone()
+            else:
+                assert torch.equal(cov, first), ("coverage from bits", rep)
+        segs = [panel.roh_segments(W, 0.001, mg, 2.5, 0.25) for _ in range(40)]
+        assert segs[0].shape[0] > 0 and all(np.array_equal(x, segs[0]) for x in segs[1:])
 
 
 @pytest.mark.parametrize("W,step", [(100, 100), (50, 50), (100, 7)])
