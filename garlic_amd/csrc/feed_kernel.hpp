@@ -25,8 +25,8 @@
 //   edges       a run's first tile, its last ones, the tiles in front of the loop's first aligned one and everything
 //               of a shard that does not start on a block boundary go through the compiler-generated tile below,
 //               which takes its terms from the term table in memory and needs no ring;
-//   samples     a sampled locus goes straight from the lanes into a [row][column] matrix per chromosome, four
-//               consecutive samples of a lane as one 32-byte piece (edges: 8 B each).
+//   samples     a sampled locus goes straight from the lanes into a [row][column] matrix per chromosome, eight
+//               consecutive samples of a lane as one 64-byte piece (edges: 8 B each).
 //               The host chooses rows and columns: row = individual, column = locus / step gives the thinned score
 //               matrix; row = position in the caller's individual list, column = rank of the sample among the
 //               chromosome's scored samples gives the KDE feed itself (convertWinData2DoubleData's order: the mask

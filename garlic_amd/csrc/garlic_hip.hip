@@ -17,6 +17,7 @@
 #include "feed_kernel.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <cmath>
 #include <cstdarg>
@@ -308,6 +309,9 @@ struct garlic_panel {
     garlic_call_stats stats{};
     bool stats_pending = false;                    // event times of the last call not read yet
     int stats_slot = 0;                            // the context's event pair that brackets its dominant kernel
+    int64_t n_count_timeouts = 0;                  // garlic_call_stats::n_count_timeouts
+    struct Placement { int32_t drawn = 0, rounds = 0; float best_ms = 0, median_ms = 0, worst_ms = 0, target_ms = 0; int32_t reached = 0; };
+    Placement placement;                           // the last garlic_panel_alloc_scores on this panel
     // work list of the last call, still on the device: repeated calls with the same arguments
     // (bench steps, window-size sweeps coming back to a size) skip planning and uploads
     struct {
@@ -412,6 +416,10 @@ static int score_alloc(garlic_ctx *ctx, size_t bytes, void **out)
                 return GARLIC_OK;
             }
             release_score_alloc(a, mapped, mapped != 0);
+            if (mapped != 0 && a.ptr) {      // (a partly mapped range stays reserved: garlic_device_alloc_stats counts it)
+                std::lock_guard<std::mutex> lock(g_score_mutex);
+                g_score_retired[ctx->device < 16 ? ctx->device : 15] += (int64_t)a.size;
+            }
             (void)hipGetLastError();
             {   // out of device memory with buffers idle in the pool: give those back and try once more
                 bool any = false;
@@ -452,15 +460,21 @@ int score_pool_trim()
 static int score_free(garlic_ctx *ctx, void *ptr)
 {
     {
+        // (this device's work first, OUTSIDE the lock: one shard's release must not queue behind another device's kernels)
+        bool ours = false;
+        {
+            std::lock_guard<std::mutex> lock(g_score_mutex);
+            for (const ScoreAlloc &a : g_score_allocs) ours = ours || (a.ptr == ptr && !a.pooled);
+        }
+        if (ours) HIP_TRY(hipDeviceSynchronize());
+        size_t total_mem = 0, free_mem = 0;
+        if (ours) (void)hipMemGetInfo(&free_mem, &total_mem);
         std::lock_guard<std::mutex> lock(g_score_mutex);
         for (size_t k = 0; k < g_score_allocs.size(); k++)
             if (g_score_allocs[k].ptr == ptr && !g_score_allocs[k].pooled) {
-                HIP_TRY(hipDeviceSynchronize());
                 g_score_allocs[k].pooled = true;
                 g_score_allocs[k].stamp = ++g_score_clock;
                 // cap the pool: the oldest idle buffers give their memory back (their ranges stay reserved, unmapped for good)
-                size_t total_mem = 0, free_mem = 0;
-                (void)hipMemGetInfo(&free_mem, &total_mem);
                 int64_t cap = (int64_t)(total_mem / 4);
                 if (const char *e = getenv("GARLIC_ALLOC_POOL_GB")) cap = (int64_t)(atof(e) * 1073741824.0);
                 for (;;) {
@@ -623,6 +637,10 @@ void plan_runs(const garlic_panel *p, int32_t W, std::vector<Run> &runs, std::ve
 }
 
 enum Mode { MODE_LOD, MODE_LOD_GL, MODE_WLOD };
+
+// internal (never returned through the ABI): launch_lod was asked for coverage bits (garlic_panel::cov_pending) by a shape
+// only the score kernels take; garlic_roh_coverage_fused then computes the scores and counts from them
+constexpr int GARLIC_INTERNAL_NO_BITS = -1001;
 
 // Work list of lod_feed_kernel: (run, FEED_G blocks) items, longest runs first (`order`); the runs within reach of
 // the longest one run at raised issue priority: their length x one wave's pace is the kernel's critical path.
@@ -1127,7 +1145,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         return fail(GARLIC_ERR_STATE, "internal: coverage bits of the unweighted --error scores come from lod_bits_kernel");
     if (cov_bits && mode == MODE_LOD_GL &&
         (exact_possible || where != GARLIC_DEVICE || (ind_begin & (WAVE - 1)) != 0 || getenv("GARLIC_TGLS_NO_RING")))
-        return fail(GARLIC_ERR_STATE, "internal: coverage bits need the tuned wLOD kernels or the TGLS ring chain");
+        return GARLIC_INTERNAL_NO_BITS;      // the TGLS ring chain / the tuned wLOD kernels do not take this shape
     const bool wlod_shape_ok = mode == MODE_WLOD && W + 64 <= GPAD_BACK && !getenv("GARLIC_WLOD_GENERIC") &&
                                (W >= WLOD_R || !getenv("GARLIC_WLOD_SMALL_GENERIC"));
     const bool wlod_small = W < WLOD_R;      // narrower than a window group: wlod_group_small (compiler-scheduled)
@@ -1140,7 +1158,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // narrow windows, plain scores: the streaming kernel (wlod_small_kernel.hpp) reads the plain reciprocals, a window's
     // W weights contiguous
     const bool wlod_stream = wlod_fast && wlod_small && !wlod_gl && !p->cov_pending.bits && !getenv("GARLIC_WLOD_SMALL_TILES");
-    if (p->cov_pending.bits && mode == MODE_WLOD && !wlod_fast) return fail(GARLIC_ERR_STATE, "internal: coverage bits need the tuned wLOD kernels");
+    if (p->cov_pending.bits && mode == MODE_WLOD && !wlod_fast) return GARLIC_INTERNAL_NO_BITS;
     if (wlod_stream && (rc = ensure_rld(p))) return rc;
     // continuous likelihoods have no code table: the generic kernel takes its terms from the raw matrix
     if (mode == MODE_WLOD && use_gl && p->gl_cont && !wlod_fast && (rc = ensure_gl_terms(p))) return rc;
@@ -1156,7 +1174,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     // blocks' term rows enter a CU once per strip (wlod_strip_kernel.hpp)
     const int strip_waves = (W + 15 - 16 * WS_WAVES <= 16 || getenv("GARLIC_WLOD_STRIP_NARROW_ONLY")) ? WS_WAVES : WS_WAVES_WIDE;
     const bool wlod_gl_strip = wlod_gl_ring && W + 15 - 16 * strip_waves <= 16 && !getenv("GARLIC_WLOD_GL_NO_STRIP");
-    bool strip_now = wlod_gl_strip;        // false for the rerun after a strip launch that reported a stalled wave
+    const bool strip_now = wlod_gl_strip;
     const size_t wlod_lds = wlod_gl_ring ? WLOD_GL_RING_OFF + (size_t)WLOD_WAVES * GARLIC_WLOD_GL_RING_ROWS * WAVE * 8
                                    : wlod_rows + 16 + (wlod_use_patch ? wlod_patch : 0);   // 16: the patch lock
 
@@ -1170,9 +1188,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         if (3 * L.pitch[c] * 8 + 512 >= (int64_t)1 << 32)
             return fail(GARLIC_ERR_INVALID, "chromosome %d too long for 32-bit row offsets", c);
 
-    // Thinned feed: every wave a chain of its own (feed_kernel.hpp); GARLIC_FEED_ROLES: the four-role kernel with the
-    // thinned write-out instead
-    const bool feed_kernel = thin_step > 0 && !getenv("GARLIC_FEED_ROLES");
+    // Thinned output: every wave a chain of its own (feed_kernel.hpp)
+    const bool feed_kernel = thin_step > 0;
     uint64_t blocks_hash = 0;
     if (blocks) {
         blocks_hash = 0xCBF29CE484222325ull;
@@ -1229,7 +1246,12 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         if ((rc = p->d_chrs.reserve(chrs.size()))) return rc;
         if ((rc = p->d_items.reserve(std::max<size_t>(n_items, 1)))) return rc;
         if ((rc = p->d_fill.reserve(std::max<size_t>(n_fill, 1)))) return rc;
-        if ((rc = p->d_counter.reserve(4))) return rc;      // [0], [1]: the chain kernel's queue; [2]: sentinel_scan_kernel's flag
+        // [0], [1]: the chain kernel's queue; [2]: sentinel_scan_kernel's flag; [3]: the strip kernel's stall flag;
+        // [4]: strip launches repaired by the tile form since the panel was made (garlic_call_stats::n_stall_reruns)
+        if (!p->d_counter.p) {
+            if ((rc = p->d_counter.reserve(8))) return rc;
+            HIP_TRY(hipMemsetAsync(p->d_counter.p, 0, 8 * sizeof(int32_t), ctx->stream));
+        }
         p->plan.valid = false;
     }
     std::vector<uint8_t> valid;
@@ -1340,7 +1362,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         const int nquad = (nblk + per_wg - 1) / per_wg;
         WlodArgs a{p->d_valid.p, p->d_chrs.p, p->d_tiles.p, p->nwordrows, p->nchr, ind_begin, ind_count, W, nquad,
                    (uint32_t)((int64_t)p->plan.n_tiles * nquad), ((wlod_gl_ring ? ring_patch : wlod_use_patch) ? 1 : 0) | (getenv("GARLIC_WLOD_NO_PF") ? 2 : 0),
-                   (int64_t)(GOFF + p->nloci + GPAD_BACK), wlod_gl_ring ? 1 : 0, p->cov_pending};
+                   (int64_t)(GOFF + p->nloci + GPAD_BACK), wlod_gl_ring ? 1 : 0, p->cov_pending, nullptr, nullptr};
         const uint32_t *a_packed = p->d_packed.p;
         const double *a_wtab = wlod_gl ? p->d_glterms.p : p->d_wtab.p, *a_skew = p->d_skew.p + SKEW_FRONT;
         const unsigned wl_grid = (a.n_work + 7u) / 8u * 8u;
@@ -1391,6 +1413,20 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES));
             void *kargs[] = {(void *)&sa};
             HIP_TRY(hipLaunchKernel(fn, dim3(grid), dim3((strip_waves + 1) * WAVE), kargs, WS_LDS_BYTES, ctx->stream));
+            // A wave of the strip kernel that ran out of its poll budget flags the launch (its scores are wrong).  The tile
+            // form, which computes the same values without waits between waves, is enqueued behind it and runs only if
+            // the flag is set -- on the device: no copy back, no synchronisation, the call stays asynchronous -- and
+            // counts itself (garlic_call_stats::n_stall_reruns: expected 0; a liveness bug shows there, not as a slow call)
+            if (getenv("GARLIC_WLOD_STRIP_FORCE_RERUN")) HIP_TRY(hipMemsetAsync(p->d_counter.p + 3, 1, sizeof(int32_t), ctx->stream));
+            WlodArgs ar = a;
+            ar.run_if = p->d_counter.p + 3;
+            ar.rerun_count = p->d_counter.p + 4;
+            if (aligned16)
+                hipLaunchKernelGGL((wlod_tile_glring_kernel<WLOD_R, true>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
+                                   a_packed, a_wtab, a_skew, d_out, ar);
+            else
+                hipLaunchKernelGGL((wlod_tile_glring_kernel<WLOD_R, false>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
+                                   a_packed, a_wtab, a_skew, d_out, ar);
         } else if (wlod_gl_ring && aligned16)
             hipLaunchKernelGGL((wlod_tile_glring_kernel<WLOD_R, true>), dim3(wl_grid), wl_block, wlod_lds, ctx->stream,
                                a_packed, a_wtab, a_skew, d_out, a);
@@ -1423,7 +1459,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         hipLaunchKernelGGL(lod_chain_exact_kernel, dim3((unsigned)n_items), dim3(WAVE), 0, ctx->stream, a, (int)n_items);
     } else if (n_items && mode == MODE_LOD) {
         ChainArgs a{p->d_packed.p, p->d_tab.p, p->d_items.p,     p->d_chrs.p,     d_out, p->nind_pad, p->nwordrows,
-                    ind_begin,     ind_count,  W,               (int32_t)n_items, thin_step, p->d_counter.p, nullptr};
+                    ind_begin,     ind_count,  W,               (int32_t)n_items, p->d_counter.p, nullptr};
         DevBuf<int64_t> d_trace;   // debugging aid: GARLIC_TRACE=<file> dumps per-item timestamps
         const char *trace_path = getenv("GARLIC_TRACE");
         if (trace_path && !(feed_kernel && n_feed_items) && d_trace.reserve(4 * n_items) == GARLIC_OK) {
@@ -1458,14 +1494,11 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                 }
                 d_ftrace.release();
             }
-        } else if (thin_step > 0)
-            hipLaunchKernelGGL((lod_chain_kernel<true, true>), dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
-                               ctx->stream, a);
-        else if (aligned16)
-            hipLaunchKernelGGL((lod_chain_kernel<true, false>), dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
+        } else if (aligned16)
+            hipLaunchKernelGGL((lod_chain_kernel<true>), dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
                                ctx->stream, a);
         else
-            hipLaunchKernelGGL((lod_chain_kernel<false, false>), dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
+            hipLaunchKernelGGL((lod_chain_kernel<false>), dim3((unsigned)workers), dim3(CHAIN_THREADS), 0,
                                ctx->stream, a);
         if (a.trace) {
             std::vector<int64_t> tr(4 * n_items);
@@ -1492,7 +1525,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
             if (p->cov_pending.bits) p->cov_written = true;
             hipLaunchKernelGGL(lod_chain_ring_kernel, dim3((unsigned)workers), dim3(TG_THREADS), 0, ctx->stream, t);
         } else if (cov_bits) {
-            return fail(GARLIC_ERR_STATE, "internal: coverage bits need the tuned wLOD kernels or the TGLS ring chain");
+            return GARLIC_INTERNAL_NO_BITS;      // the TGLS ring chain / the tuned wLOD kernels do not take this shape
         } else if (mode == MODE_LOD_GL && p->glterms_valid && !p->glterms_scaled) {
             hipLaunchKernelGGL(lod_chain_terms_kernel, dim3((unsigned)n_items), dim3(2 * WAVE), 0, ctx->stream, a,
                                (int)n_items, (int64_t)(GOFF + p->nloci + GPAD_BACK), p->d_glterms.p);
@@ -1527,17 +1560,6 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
         p->last_chain_kind = found ? 2 : 1;
         if (found) {
             exact = true;
-            if ((rc = enqueue())) return rc;
-        }
-    }
-    if (strip_now) {
-        // a wave of the strip kernel that ran out of its poll budget has flagged the launch (its scores are wrong):
-        // the tile form computes the same values without waits between waves
-        int32_t stalled = 0;
-        HIP_TRY(hipMemcpyAsync(&stalled, p->d_counter.p + 3, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (stalled || getenv("GARLIC_WLOD_STRIP_FORCE_RERUN")) {
-            strip_now = false;
             if ((rc = enqueue())) return rc;
         }
     }
@@ -2695,7 +2717,7 @@ static int feed_single(garlic_panel *p, int32_t winsize, double error, int32_t m
     // windows (8/step B per window instead of 8 B, no full-size scratch).  Otherwise the full scores
     // go to the panel's device scratch (the one host-output calls use; it stays allocated, hipMalloc
     // of 8 GB per call would cost more than the kernels) and are sampled from there.
-    int32_t thinned = (!weighted && !use_gl && step >= 4 && !getenv("GARLIC_FEED_FULL")) ? step : 0;
+    int32_t thinned = (!weighted && !use_gl && step >= 4) ? step : 0;
     if (thinned) {   // the exact chain (lod_exact_needed) writes full scores only
         if (!p->have_freq) return done(fail(GARLIC_ERR_STATE, "panel needs map, freq and genotypes before computing LOD"));
         if ((rc = ensure_term_table(p, error))) return done(rc);
@@ -2729,7 +2751,7 @@ int garlic_lod_feed_subset(garlic_panel *p, int32_t winsize, double error, int32
 {
     if (!p || !count) return fail(GARLIC_ERR_INVALID, "panel and count are required");
     // unweighted --error scores with a real thinning step: the chain kernel writes the feed itself (garlic_lod_feed_multi)
-    if (!weighted && !use_gl && step >= 4 && !getenv("GARLIC_FEED_MATRIX"))
+    if (!weighted && !use_gl && step >= 4)
         return garlic_lod_feed_multi(p, &winsize, &step, 1, error, max_gap, ind_idx, n_idx, &feed, &feed_capacity, count, chr_counts);
     return feed_single(p, winsize, error, max_gap, use_gl, weighted, M, mu, step, ind_idx, n_idx, feed, feed_capacity, count,
                        chr_counts);
@@ -2772,7 +2794,7 @@ int garlic_lod_feed_multi(garlic_panel *p, const int32_t *winsizes, const int32_
     if ((rc = set_device(ctx))) return rc;
     if (!p->have_map || !p->have_freq || !p->have_geno)
         return fail(GARLIC_ERR_STATE, "panel needs map, freq and genotypes before computing LOD");
-    bool direct = !getenv("GARLIC_FEED_FULL") && !getenv("GARLIC_FEED_ROLES") && !getenv("GARLIC_FEED_SERIAL");
+    bool direct = !getenv("GARLIC_FEED_SERIAL");
     for (int i = 0; i < n_sizes && direct; i++) direct = steps[i] >= 4;
     if (direct) {
         if ((rc = ensure_segments(p, max_gap))) return rc;
@@ -2793,7 +2815,19 @@ int garlic_lod_feed_multi(garlic_panel *p, const int32_t *winsizes, const int32_
     std::vector<uint8_t> blocks;
     std::vector<int32_t> row_map;
     DevBuf<int32_t> d_rowmap;
-    auto done = [&](int code) { d_rowmap.release(); return code; };
+    // one way out: whatever was enqueued on the sizes' streams has finished (the next call reuses their scratch) and the
+    // row map is released
+    auto done = [&](int code) {
+        if (code != GARLIC_OK)
+            for (auto *sl : p->feed_slots) (void)hipStreamSynchronize(sl->stream);
+        d_rowmap.release();
+        return code;
+    };
+#define FEED_TRY(expr)                                                                              \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return done(fail(GARLIC_ERR_HIP, "feed: %s: %s", #expr, hipGetErrorString(e_))); \
+    } while (0)
     if (ind_idx) {
         blocks.assign((size_t)nblk, 0);
         row_map.assign((size_t)p->nind, -1);
@@ -2809,13 +2843,19 @@ int garlic_lod_feed_multi(garlic_panel *p, const int32_t *winsizes, const int32_
         if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "feed: %s", hipGetErrorString(e)));
     }
     while ((int)p->feed_slots.size() < n_sizes) {
-        auto *sl = new garlic_panel::FeedSlot;
-        p->feed_slots.push_back(sl);
-        if (hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&sl->ev0) != hipSuccess ||
-            hipEventCreate(&sl->ev1) != hipSuccess)
+        auto *sl = new garlic_panel::FeedSlot;            // (joins the panel's slots only once it is complete)
+        bool ok = hipStreamCreateWithFlags(&sl->stream, hipStreamNonBlocking) == hipSuccess;
+        const bool ok0 = ok && hipEventCreate(&sl->ev0) == hipSuccess;
+        const bool ok1 = ok0 && hipEventCreate(&sl->ev1) == hipSuccess;
+        if (!ok1) {
+            if (ok0) (void)hipEventDestroy(sl->ev0);
+            if (ok) (void)hipStreamDestroy(sl->stream);
+            delete sl;
             return done(fail(GARLIC_ERR_HIP, "feed: stream / event creation failed"));
+        }
+        p->feed_slots.push_back(sl);
     }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));          // uploads and earlier calls on the context's stream
+    FEED_TRY(hipStreamSynchronize(ctx->stream));          // uploads and earlier calls on the context's stream
     // ---- plans and their uploads, all sizes, before any kernel is enqueued (an upload from pageable memory waits
     //      for the device to take it: behind a running chain kernel it would hold back the sizes that follow)
     std::vector<size_t> n_items((size_t)n_sizes, 0);
@@ -2859,15 +2899,15 @@ int garlic_lod_feed_multi(garlic_panel *p, const int32_t *winsizes, const int32_
         if ((rc = sl.chrs.reserve((size_t)p->nchr))) return done(rc);
         if ((rc = sl.counter.reserve(4))) return done(rc);
         if ((rc = sl.feed.reserve((size_t)off))) return done(rc);
-        HIP_TRY(hipMemcpy(sl.chrs.p, chrs.data(), sizeof(ChrDev) * (size_t)p->nchr, hipMemcpyHostToDevice));
-        if (!items.empty()) HIP_TRY(hipMemcpy(sl.items.p, items.data(), sizeof(FeedItem) * items.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemset(sl.counter.p, 0, 2 * sizeof(int32_t)));
+        FEED_TRY(hipMemcpy(sl.chrs.p, chrs.data(), sizeof(ChrDev) * (size_t)p->nchr, hipMemcpyHostToDevice));
+        if (!items.empty()) FEED_TRY(hipMemcpy(sl.items.p, items.data(), sizeof(FeedItem) * items.size(), hipMemcpyHostToDevice));
+        FEED_TRY(hipMemset(sl.counter.p, 0, 2 * sizeof(int32_t)));
     }
     p->plan.valid = false;
     // ---- every size's chain kernel, each on its own stream; every element of a feed is written by its kernel
     for (int i = 0; i < n_sizes; i++) {
         garlic_panel::FeedSlot &sl = *p->feed_slots[(size_t)i];
-        HIP_TRY(hipEventRecord(sl.ev0, sl.stream));
+        FEED_TRY(hipEventRecord(sl.ev0, sl.stream));
         if (n_items[(size_t)i]) {
             FeedArgs f{p->d_packed.p, p->d_tab.p, sl.items.p, sl.chrs.p, sl.feed.p, ind_idx ? d_rowmap.p : nullptr, p->nwordrows, 0,
                        p->nind, winsizes[i], (int32_t)n_items[(size_t)i], steps[i], getenv("GARLIC_FEED_NO_ASM") ? 0 : 1,
@@ -2875,21 +2915,21 @@ int garlic_lod_feed_multi(garlic_panel *p, const int32_t *winsizes, const int32_
             int grid = 1;
             if ((rc = feed_grid(ctx, n_items[(size_t)i], &grid))) return done(rc);
             void *kargs[] = {(void *)&f};
-            HIP_TRY(hipLaunchKernel((const void *)lod_feed_kernel, dim3((unsigned)grid), dim3(FEED_G * WAVE), kargs, 0, sl.stream));
+            FEED_TRY(hipLaunchKernel((const void *)lod_feed_kernel, dim3((unsigned)grid), dim3(FEED_G * WAVE), kargs, 0, sl.stream));
         }
-        HIP_TRY(hipEventRecord(sl.ev1, sl.stream));
-        HIP_TRY(hipGetLastError());
+        FEED_TRY(hipEventRecord(sl.ev1, sl.stream));
+        FEED_TRY(hipGetLastError());
     }
     // ---- the feeds, in order
     for (int i = 0; i < n_sizes; i++) {
         garlic_panel::FeedSlot &sl = *p->feed_slots[(size_t)i];
         if (n_items[(size_t)i])
-            HIP_TRY(hipMemcpyAsync(feeds[i], sl.feed.p, sizeof(double) * (size_t)total[(size_t)i], hipMemcpyDeviceToHost, sl.stream));
+            FEED_TRY(hipMemcpyAsync(feeds[i], sl.feed.p, sizeof(double) * (size_t)total[(size_t)i], hipMemcpyDeviceToHost, sl.stream));
     }
     float ms_sum = 0.f;
     for (int i = 0; i < n_sizes; i++) {
         garlic_panel::FeedSlot &sl = *p->feed_slots[(size_t)i];
-        HIP_TRY(hipStreamSynchronize(sl.stream));
+        FEED_TRY(hipStreamSynchronize(sl.stream));
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, sl.ev0, sl.ev1) == hipSuccess) ms_sum += ms;
     }
@@ -2897,6 +2937,7 @@ int garlic_lod_feed_multi(garlic_panel *p, const int32_t *winsizes, const int32_
     p->stats.chain_kernel_ms = ms_sum;    // (the sizes overlap: the sum of their spans, not wall time)
     p->stats_pending = false;
     return done(GARLIC_OK);
+#undef FEED_TRY
 }
 
 // Coverage counts of the unweighted --error scores without the scores: chain + compare + sliding count in one kernel
@@ -3069,7 +3110,7 @@ static int coverage_impl(garlic_panel *p, int32_t winsize, double error, int32_t
             rc = garlic_lod_windows(p, W, error, max_gap, 1, 0, p->nind, 32, reinterpret_cast<double *>(d_bits.p), GARLIC_DEVICE);
         const bool written = weighted || p->cov_written;
         p->cov_pending = CovBits{nullptr, nullptr, 0.0};
-        if (rc == GARLIC_ERR_STATE && strstr(garlic_hip_last_error(), "coverage bits need")) return done(unfused());
+        if (rc == GARLIC_INTERNAL_NO_BITS) return done(unfused());
         if (rc) return done(rc);
         if (!written) return done(unfused());       // (no scored window at all: nothing was launched)
         if (sink.segments) return done(segments_from_bits(p, d_bits.p, d_bchrs.p, bchrs, word_base, W, sink));
@@ -3247,7 +3288,10 @@ static int coverage_impl(garlic_panel *p, int32_t winsize, double error, int32_t
             e = hipMemcpyAsync(&timed_out, d_cnt.p + nchr, sizeof(int32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return done3(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
-        if (timed_out) return done3(fail(GARLIC_ERR_HIP, "coverage: a count item gave up waiting for its chromosome's chains"));
+        if (timed_out) {
+            p->n_count_timeouts++;
+            return done3(fail(GARLIC_ERR_HIP, "coverage: a count item gave up waiting for its chromosome's chains"));
+        }
         return done3(GARLIC_OK);
     }
 }
@@ -3361,6 +3405,15 @@ int garlic_last_call_stats(garlic_panel *p, garlic_call_stats *stats)
         (void)hipEventElapsedTime(&p->stats.total_ms, p->ctx->ev_begin, p->ctx->ev_end);
         p->stats_pending = false;
     }
+    if (p->d_counter.p) {      // strip launches the tile form had to repair (counted on the device; waits for the stream)
+        int32_t n = 0;
+        int rc;
+        if ((rc = set_device(p->ctx))) return rc;
+        HIP_TRY(hipMemcpyAsync(&n, p->d_counter.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, p->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+        p->stats.n_stall_reruns = n;
+    }
+    p->stats.n_count_timeouts = p->n_count_timeouts;
     *stats = p->stats;
     return GARLIC_OK;
 }
@@ -3433,48 +3486,53 @@ int garlic_panel_alloc_scores(garlic_panel *p, int32_t pitch_align, int32_t nind
     candidates = std::min(candidates, 16);
     const Layout L = make_layout(p, pitch_align, nind_out);
     // Candidates come in rounds.  Buffers of one round are cut from neighbouring physical memory and can ALL land on
-    // the slow side (profiles/r03_bench_plain_all_candidates_slow.json: eight candidates at 1.65 ms on a fresh device, 1.35 ms one process
-    // later; tools/exp/placement_fresh.py: one round in four without a fast buffer).  A round whose fastest and slowest
-    // candidate are within 6 % of each other has told nothing: take another one from fresh memory while the first is
-    // still held (so that the allocator cannot hand the same pages back), up to three; the best of all rounds is kept.
+    // the slow side (profiles/r03_bench_plain_all_candidates_slow.json: eight candidates at 1.65 ms on a fresh device, 1.35 ms
+    // one process later), and the times are not two clean classes either (BENCH_r03: 1.44 kept / 1.50 median / 1.54 worst
+    // in one round, 1.34-1.40 on other leases), so a relative spread inside a round says little.  The criterion is the
+    // kernel's own bound: a round whose best candidate takes its score bytes at >= 0.74 of the HBM peak (1.39 ms at 1M SNPs
+    // x 1000 individuals) has found the fast placement; otherwise another round is taken from fresh memory while the
+    // earlier ones are still held (so that the allocator cannot hand the same pages back) -- three rounds at most
+    // (GARLIC_ALLOC_ROUNDS), 2 s at most, memory permitting.  The best of all rounds is kept; how many were drawn and what
+    // they timed: garlic_panel_alloc_scores_info.
     int max_rounds = 3;
-    float spread = 1.06f;
     if (const char *e = getenv("GARLIC_ALLOC_ROUNDS")) max_rounds = std::max(1, std::min(atoi(e), 4));
-    if (const char *e = getenv("GARLIC_ALLOC_SPREAD")) spread = std::max(1.f, (float)atof(e));   // tests: 100 = always all rounds
     const size_t bytes = sizeof(double) * (size_t)L.total;
+    const float target_ms = (float)((double)bytes / (0.74 * 8.0e12) * 1e3);
     std::vector<void *> cand;
     std::vector<float> ms;
+    std::vector<size_t> round_start;
     auto cleanup = [&](int keep) {
         for (int k = 0; k < (int)cand.size(); k++)
             if (k != keep && cand[(size_t)k]) (void)score_free(p->ctx, cand[(size_t)k]);
     };
     garlic_ctx *ctx = p->ctx;
     const bool was_async = ctx->async_device;
+    const auto t_begin = std::chrono::steady_clock::now();
     int best = -1, best_round = 0;
     for (int round = 0; round < max_rounds; round++) {
-        const int base = (int)cand.size();
+        const size_t base = cand.size();
+        round_start.push_back(base);
         for (int k = 0; k < candidates; k++) {
             void *q = nullptr;
             if ((rc = score_alloc(ctx, bytes, &q))) break;
             cand.push_back(q);
             ms.push_back(0.f);
         }
-        if (rc && (round == 0 || (int)cand.size() == base)) {
-            if (round == 0) { cleanup(-1); return rc; }
-            g_last_error.clear();   // no room for another round: the first one stands
+        const bool short_round = rc != 0;
+        if (short_round) {
+            if (round == 0 && cand.empty()) return rc;
+            g_last_error.clear();   // no room for (all of) another round: what there is stands
             rc = 0;
-            break;
         }
         // passes enqueued back to back, as a caller that keeps the scores on the device issues them (a pass that is waited
         // for runs ~5 % faster than one in a queue: DESIGN.md section 4): one pass to build the plan, then four in a row,
         // the last three timed by their HIP events
-        rc = 0;   // a short round is still a round
-        for (int k = base; k < (int)cand.size(); k++) {
+        for (size_t k = base; k < cand.size(); k++) {
             ctx->async_device = false;
-            rc = launch_lod(p, MODE_LOD, winsize, error, max_gap, 0, 0.0, 0, nind_out, pitch_align, (double *)cand[(size_t)k], GARLIC_DEVICE);
+            rc = launch_lod(p, MODE_LOD, winsize, error, max_gap, 0, 0.0, 0, nind_out, pitch_align, (double *)cand[k], GARLIC_DEVICE);
             ctx->async_device = true;
             for (int pass = 0; pass < 4 && !rc; pass++)
-                rc = launch_lod(p, MODE_LOD, winsize, error, max_gap, 0, 0.0, 0, nind_out, pitch_align, (double *)cand[(size_t)k], GARLIC_DEVICE);
+                rc = launch_lod(p, MODE_LOD, winsize, error, max_gap, 0, 0.0, 0, nind_out, pitch_align, (double *)cand[k], GARLIC_DEVICE);
             ctx->async_device = was_async;
             if (rc) { cleanup(-1); return rc; }
             hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -3486,18 +3544,42 @@ int garlic_panel_alloc_scores(garlic_panel *p, int32_t pitch_align, int32_t nind
                 (void)hipEventElapsedTime(&t, ctx->hist0[slot], ctx->hist1[slot]);
                 acc += t;
             }
-            ms[(size_t)k] = acc / 3;
-            if (best < 0 || ms[(size_t)k] < ms[(size_t)best]) { best = k; best_round = round; }
+            ms[k] = acc / 3;
+            if (best < 0 || ms[k] < ms[(size_t)best]) { best = (int)k; best_round = round; }
         }
-        // enough once the candidates seen so far differ: the fast kind is among them
-        const float hi = *std::max_element(ms.begin(), ms.end());
-        if (cand.size() < 2 || hi > spread * ms[(size_t)best]) break;
+        const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        if (short_round || ms[(size_t)best] <= target_ms || elapsed > 2.0) break;
     }
-    if (candidate_ms) memset(candidate_ms, 0, sizeof(float) * (size_t)candidates);
-    if (candidate_ms) memcpy(candidate_ms, ms.data() + (size_t)best_round * (size_t)candidates,
-                             sizeof(float) * std::min((size_t)candidates, ms.size() - (size_t)best_round * (size_t)candidates));
+    if (candidate_ms) {
+        memset(candidate_ms, 0, sizeof(float) * (size_t)candidates);
+        const size_t r0 = round_start[(size_t)best_round];
+        const size_t r1 = (size_t)best_round + 1 < round_start.size() ? round_start[(size_t)best_round + 1] : ms.size();
+        memcpy(candidate_ms, ms.data() + r0, sizeof(float) * std::min((size_t)candidates, r1 - r0));
+    }
+    {
+        std::vector<float> sorted(ms);
+        std::sort(sorted.begin(), sorted.end());
+        p->placement = garlic_panel::Placement{(int32_t)ms.size(), (int32_t)round_start.size(), sorted.front(),
+                                               sorted[sorted.size() / 2], sorted.back(), target_ms,
+                                               sorted.front() <= target_ms ? 1 : 0};
+    }
     cleanup(best);
     *out = cand[(size_t)best];
+    return GARLIC_OK;
+}
+
+int garlic_panel_alloc_scores_info(garlic_panel *p, int32_t *drawn, int32_t *rounds, float *best_ms, float *median_ms,
+                                   float *worst_ms, float *target_ms, int32_t *reached_target)
+{
+    if (!p) return fail(GARLIC_ERR_INVALID, "panel is NULL");
+    if (p->placement.drawn == 0) return fail(GARLIC_ERR_STATE, "garlic_panel_alloc_scores has not run on this panel");
+    if (drawn) *drawn = p->placement.drawn;
+    if (rounds) *rounds = p->placement.rounds;
+    if (best_ms) *best_ms = p->placement.best_ms;
+    if (median_ms) *median_ms = p->placement.median_ms;
+    if (worst_ms) *worst_ms = p->placement.worst_ms;
+    if (target_ms) *target_ms = p->placement.target_ms;
+    if (reached_target) *reached_target = p->placement.reached;
     return GARLIC_OK;
 }
 

@@ -278,8 +278,6 @@ struct ChainArgs {
     int32_t ind_count;        // rows in the output
     int32_t winsize;
     int32_t n_items;          // work-list length
-    int32_t thin_step;        // THIN kernels: only windows at chromosome-local loci 0, step, 2*step, .. are
-                              // stored, as out[chr.out_base + ind * chr.out_pitch + locus / step]
     int32_t *next_item;       // [0] the persistent workgroups' queue head, [1] workgroups that have left; both zero
                               // at launch (the last workgroup to leave resets them)
     int64_t *trace;           // optional (GARLIC_TRACE): per item {worker, t_begin, t_asm, t_end} in 100 MHz ticks
@@ -424,19 +422,7 @@ __global__ void __launch_bounds__(256) fill_value_kernel(double *dst, int64_t n,
         dst[i] = value;
 }
 
-// Thinned write-out of one tile (KDE feed, garlic-data.cpp:2036: loci 0, step, 2*step, ..): lane =
-// individual, the tile's sampled columns inside [a, b] go to out_row[lane * pitch + locus / step].
-__device__ __forceinline__ void tile_store_thin(const unsigned char *tile, int s0, int a, int b, int lane,
-                                                int rows_valid, double *out_row, int64_t pitch, int step)
-{
-    const int lo = max(s0, a), hi = min(s0 + TILE - 1, b);
-    for (int s = (lo + step - 1) / step * step; s <= hi; s += step)
-        if (lane < rows_valid)
-            out_row[(int64_t)lane * pitch + s / step] =
-                *reinterpret_cast<const double *>(tile + (uint32_t)lane * (TPITCH * 8) + (uint32_t)(s - s0) * 8u);
-}
-
-template <bool ALIGNED16, bool THIN>
+template <bool ALIGNED16>
 __global__ void __launch_bounds__(CHAIN_THREADS)
 lod_chain_kernel(ChainArgs p)
 {
@@ -546,8 +532,7 @@ lod_chain_kernel(ChainArgs p)
                 fill_regs(smem, st, gcol, lane);
                 const TileBits tb = tile_consume<0>(smem, lc, tc, st, lane);
                 tile_steps<true, 0>(smem, tile, acc, tb, s0, a, b, lane);
-                if (THIN) tile_store_thin(tile, s0, a, b, lane, rows_valid, out_row, pitch, p.thin_step);
-                else tile_store<true, ALIGNED16>(tile, s0, a, b, lane, rows_valid, out_tile, pitch);
+                tile_store<true, ALIGNED16>(tile, s0, a, b, lane, rows_valid, out_tile, pitch);
             }
             advance(st);
             s0 += TILE;
@@ -595,21 +580,7 @@ lod_chain_kernel(ChainArgs p)
                 *reinterpret_cast<uint4 *>(smem + GARLIC_CHAIN_SPREAD_IN + lane * 16) = make_uint4(tin[0], tin[1], tin[2], tin[3]);
                 *reinterpret_cast<uint4 *>(smem + GARLIC_CHAIN_SPREAD_OUT + lane * 16) = make_uint4(tout[0], tout[1], tout[2], tout[3]);
             }
-            if (THIN) {
-                // first sampled locus at or after s0; POST stores one column per sample
-                // (the division runs on the vector ALU: make the wave-uniform result scalar again)
-                const int col = __builtin_amdgcn_readfirstlane((s0 + p.thin_step - 1) / p.thin_step);
-                asm volatile(GARLIC_CHAIN_LOOP_ASM_THIN
-                             : [acc] "+v"(acc)
-                             : [wave] "s"(wave), [lane] "v"(lane), [lc] "v"(lc), [tc] "v"(tc),
-                               [pchunk] "s"(pchunk), [nchunk0] "s"(a_nchunk0), [roff0] "s"(a_roff0),
-                               [laddr0] "s"(a_laddr0), [taddr0] "s"(a_taddr0),
-                               [pltab] "s"(st.lead_tab), [pttab] "s"(st.trail_tab), [out] "s"(out_row + col),
-                               [ntiles] "s"(ntiles), [shl] "s"(st.sh_lead), [sht] "s"(st.sh_trail),
-                               [pitch8] "s"((uint32_t)(pitch * 8)), [rows] "s"(rows_valid),
-                               [next] "s"((uint32_t)(col * p.thin_step - s0)), [step] "s"((uint32_t)p.thin_step)
-                             : GARLIC_CHAIN_LOOP_CLOBBERS);
-            } else {
+            {
                 asm volatile(GARLIC_CHAIN_LOOP_ASM
                              : [acc] "+v"(acc)
                              : [wave] "s"(wave), [lane] "v"(lane), [lc] "v"(lc), [tc] "v"(tc),

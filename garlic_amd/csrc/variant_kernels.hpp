@@ -634,6 +634,11 @@ struct WlodArgs {
     int64_t score_rows;        // FROM_SCORES: SNP rows per 64-individual block of the term matrix
     int32_t gl_ring;           // FROM_SCORES: hand-scheduled loop with per-wave LDS rings of term rows (allocated then)
     CovBits cov;
+    // a launch that repairs another one: runs only if *run_if != 0 (the strip kernel's "a wave ran out of its poll budget"
+    // flag, wlod_strip_kernel.hpp) and then counts itself in *rerun_count -- enqueued behind every strip launch, so that
+    // no call has to come back to the host to look at the flag; NULL: an ordinary launch
+    const int32_t *run_if;
+    int32_t *rerun_count;
 };
 // dynamic LDS of the term-matrix variant: patch lock (16 B) + patch [64][WT_PITCH] doubles, then, 1-KB
 // aligned, one ring of GARLIC_WLOD_GL_RING_ROWS x 512 B per wave
@@ -912,6 +917,10 @@ wlod_tile_body(const uint32_t *__restrict__ packed,
     // Workgroups go round-robin over the 8 XCDs (one L2 each): give every XCD one contiguous
     // range of the work, so that the 64-individual blocks of a tile -- same weights, same score
     // rows -- meet in one L2.
+    if (p.run_if) {
+        if (__hip_atomic_load(p.run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(p.rerun_count, 1);
+    }
     const unsigned per_xcd = gridDim.x >> 3;
     const unsigned v = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (v >= p.n_work) return;

@@ -238,9 +238,9 @@ int main(int argc, char **argv)
             ROHLength *len = nullptr;
             std::vector<ROHData *> *roh = engine.assembleROHWindows(ind, a.lod_cutoff, &len, W, a.error, a.max_gap, a.overlap_frac,
                                                                     a.cm, a.weighted, a.M, a.mu);
-            std::cerr << "ROH segments: " << (long long)len->size << "\n";
+            std::cerr << "ROH segments: " << (long long)len->size << " (garlic-lod, MI355X; .roh.bed in the format of garlic 1.1.6a)\n";
             writeROHData((single ? a.out : a.out + "." + std::to_string(W) + "SNPs") + ".roh.bed", roh, maps, a.size_bounds, ind->pop,
-                         "1.1.6a (garlic-lod, MI355X)", a.cm);
+                         "1.1.6a", a.cm);      // the track lines name the format's version (garlic VERSION); this tool says who it is on stderr
             releaseROHData(roh);
             releaseROHLength(len);
         };

@@ -45,7 +45,7 @@ extern "C" {
  *    garlic_device_alloc_stats, garlic_device_trim
  * 6: garlic_roh_coverage_fused (coverage counts without the score matrix)
  * 7: garlic_roh_segments (the ROH segments of assembleROHWindows without scores or counts) */
-#define GARLIC_HIP_ABI_VERSION 7
+#define GARLIC_HIP_ABI_VERSION 8
 
 #define GARLIC_OK 0
 #define GARLIC_ERR_INVALID 1  /* bad argument (e.g. winsize <= 1: src/garlic-cli.cpp:433-442) */
@@ -335,6 +335,13 @@ typedef struct garlic_call_stats {
     int64_t n_missing;       /* MISSING windows per individual */
     float chain_kernel_ms;   /* HIP-event time of the dominant kernel on the context stream */
     float total_ms;          /* HIP-event time of the whole call's device work */
+    /* ABI 8: liveness book-keeping, cumulative since the panel was created; both are expected to stay 0.
+     * n_stall_reruns: launches of the strip kernel (--weighted with per-genotype likelihoods) in which a wave ran out of
+     * its poll budget and that the tile form, enqueued behind every strip launch, therefore recomputed (on the device:
+     * no call synchronises for it).  n_count_timeouts: garlic_roh_coverage_fused calls that failed because a count item
+     * gave up waiting for its chromosome's chains (GARLIC_COVERAGE_OVERLAP=1 only). */
+    int64_t n_stall_reruns;
+    int64_t n_count_timeouts;
 } garlic_call_stats;
 int garlic_last_call_stats(garlic_panel *panel, garlic_call_stats *stats);
 
@@ -353,11 +360,15 @@ int garlic_panel_chain_kind(garlic_panel *panel, int32_t *kind);
  * Where a score buffer sits in VRAM decides between two speeds of the unweighted kernel (1.36 / 1.62 ms at 1M SNPs x
  * 1000 individuals).  garlic_panel_alloc_scores allocates `candidates` (0 = 4) buffers for the
  * layout garlic_lod_out_layout(pitch_align, nind_out), times the real kernel for `winsize` into each and keeps the
- * fastest; candidate_ms (may be NULL): the kernel time into each candidate.  When all candidates of a round time
- * within 6 % of each other (buffers allocated together can all sit on one side) a further round is taken from fresh
- * memory while the first is held, three at most (GARLIC_ALLOC_ROUNDS), memory permitting; candidate_ms then holds the
- * times of the round the kept buffer came from.  Free with garlic_device_free.  The library's own full-score scratch
- * (host-output calls) is chosen the same way at first use. */
+ * fastest; candidate_ms (may be NULL): the kernel time into each candidate.  Buffers allocated together can all sit on
+ * the slow side, so unless the best candidate of a round takes its score bytes at >= 0.74 of the HBM peak (the fast
+ * placement; out of reach for small panels, which then simply use the budget) a further round is taken from fresh memory
+ * while the earlier ones are held: three rounds at most (GARLIC_ALLOC_ROUNDS), 2 s at most, memory permitting;
+ * candidate_ms then holds the times of the round the kept buffer came from.  garlic_panel_alloc_scores_info (ABI 8):
+ * how many candidates the last call on this panel drew in how many rounds, the best / median / worst kernel time over
+ * all of them, the time the 0.74 target corresponds to and whether the kept buffer reached it (any pointer may be NULL).
+ * Free with garlic_device_free.  The library's own full-score scratch (host-output calls) is chosen the same way at first
+ * use. */
 int garlic_device_alloc(garlic_ctx *ctx, int64_t bytes, void **out);
 int garlic_device_free(garlic_ctx *ctx, void *ptr);
 int garlic_device_alloc_stats(garlic_ctx *ctx, int64_t *live_bytes, int64_t *pooled_bytes, int64_t *reserved_bytes);
@@ -365,6 +376,8 @@ int garlic_device_trim(garlic_ctx *ctx);   /* idle pooled buffers give their mem
                                               when one of its own allocations runs out of memory) */
 int garlic_panel_alloc_scores(garlic_panel *panel, int32_t pitch_align, int32_t nind_out, int32_t winsize, double error,
                               int32_t max_gap, int32_t candidates, void **out, float *candidate_ms);
+int garlic_panel_alloc_scores_info(garlic_panel *panel, int32_t *drawn, int32_t *rounds, float *best_ms, float *median_ms,
+                                   float *worst_ms, float *target_ms, int32_t *reached_target);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(abi.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert abi.lib().garlic_hip_abi_version() == abi.ABI_VERSION == 7
+    assert abi.lib().garlic_hip_abi_version() == abi.ABI_VERSION == 8
 
 
 def test_no_cpu_fallback_without_device():
@@ -49,3 +49,19 @@ def test_product_never_touches_the_oracle():
                 if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".c", ".inc")) or f == "Makefile":
                     text = open(os.path.join(dirpath, f), errors="ignore").read()
                     assert "oracle" not in text.lower() or f == "__init__.py", os.path.join(dirpath, f)
+
+
+def test_every_switch_has_a_test():
+    """every getenv("GARLIC_...") of the library and the host tool is exercised by a test (tests/test_gpu_switches.py runs a
+    soak slice under each kernel-selecting switch) or is one of the documented debugging aids"""
+    import glob
+    import re
+    src = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "garlic_amd", "csrc", "*.h*")) +
+                  glob.glob(os.path.join(ROOT, "garlic_amd", "host", "*.cpp")))
+    switches = set(re.findall(r'getenv\("(GARLIC_[A-Z0-9_]+)"\)', src))
+    tests = "".join(open(f).read() for f in glob.glob(os.path.join(ROOT, "tests", "*.py")))
+    debugging_aids = {"GARLIC_TRACE",            # per-item time stamps of the chain kernels into a file
+                      "GARLIC_WORKERS",          # host tool: parser threads
+                      "GARLIC_ALLOC_POOL_GB"}    # cap of the score-buffer pool (include/garlic_hip.h)
+    missing = sorted(s for s in switches - debugging_aids if s not in tests)
+    assert not missing, missing

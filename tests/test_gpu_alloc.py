@@ -107,9 +107,10 @@ def test_library_owned_scratch_lands_in_the_fast_placement(gpu_ctx):
         assert min(ms) <= 1.08 * min(cand_ms), (ms, cand_ms)
 
 
-def test_alloc_scores_takes_further_rounds_when_the_candidates_look_alike(gpu_ctx, monkeypatch):
-    """A round of candidates that all time alike is followed by another from fresh memory (at most three); one buffer
-    is kept, the others wait in the pool, and the scores written into the kept one are the oracle's."""
+def test_alloc_scores_takes_further_rounds_until_the_fast_placement_or_the_budget(gpu_ctx, monkeypatch):
+    """A round whose best candidate does not take its score bytes at 0.74 of the HBM peak (a panel this small never
+    does) is followed by another from fresh memory, three at most; one buffer is kept, the others wait in the pool, the
+    scores written into the kept one are the oracle's, and garlic_panel_alloc_scores_info says what was drawn."""
     rng = np.random.default_rng(11)
     W, mg, sizes, nind = 20, 200000, [1500, 700], 70
     chroms = [ol.random_panel(rng, n, nind, max_gap=mg) for n in sizes]
@@ -120,15 +121,18 @@ def test_alloc_scores_takes_further_rounds_when_the_candidates_look_alike(gpu_ct
         base, pitch, total = panel.out_layout(32, nind)
         gpu_ctx.trim()
         live0, pooled0, _ = gpu_ctx.alloc_stats()
-        monkeypatch.setenv("GARLIC_ALLOC_SPREAD", "100")           # never "mixed": all three rounds are taken
         buf, ms3 = panel.alloc_scores(W, 0.001, mg, candidates=3)
         live1, pooled1, _ = gpu_ctx.alloc_stats()
         assert len(ms3) == 3 and min(ms3) > 0
+        info = panel.alloc_scores_info()
+        assert info["candidates_drawn"] == 9 and info["rounds"] == 3 and not info["reached_target"]
+        assert info["best_ms"] <= min(ms3) <= info["worst_ms"] and info["best_ms"] <= info["median_ms"] <= info["worst_ms"]
         assert live1 - live0 >= total * 8 and live1 - live0 < 2 * total * 8 + (4 << 20)      # one buffer kept ...
         assert pooled1 - pooled0 >= 8 * total * 8                  # ... eight candidates of three rounds in the pool
         monkeypatch.setenv("GARLIC_ALLOC_ROUNDS", "1")
         buf1, ms1 = panel.alloc_scores(W, 0.001, mg, candidates=2)
         assert len(ms1) == 2 and min(ms1) > 0
+        assert panel.alloc_scores_info()["candidates_drawn"] == 2
         for b in (buf, buf1):
             panel.lod_windows_device(b.ptr, W, 0.001, mg, pitch_align=32)
             gpu_ctx.synchronize()

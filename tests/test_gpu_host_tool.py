@@ -315,8 +315,11 @@ def test_roh_calls_match_reference_binary(tmp_path, tag, flags):
         out = run_tool_tgls(tmp_path, "--winsize", "30", *flags)
     else:
         out = run_tool(tmp_path, "--winsize", "30", *flags)
-    ref = _bed(gzip.open(os.path.join(E2E, tag + ".roh.bed.gz"), "rt").read())
-    mine = _bed(open(out + ".roh.bed").read())
+    ref_text = gzip.open(os.path.join(E2E, tag + ".roh.bed.gz"), "rt").read()
+    mine_text = open(out + ".roh.bed").read()
+    ref = _bed(ref_text)
+    mine = _bed(mine_text)
     assert list(mine) == list(ref) and len(ref) == 24
     assert sum(len(v) for v in ref.values()) > 100
     assert mine == ref
+    assert mine_text == ref_text          # track lines (Ind / Pop / version text, order) included: the whole file

@@ -185,6 +185,8 @@ def test_10M_by_1250_every_variant(gpu_ctx):
         run(lambda: panel.lod_windows_device(out.data_ptr(), W, ERR, MG, use_gl=True), "tgls", want_tgls)
         assert panel.tgls_mode()[0] == 1
         run(lambda: panel.wlod_windows_device(out.data_ptr(), W, ERR, MG, 7, 1e-9, use_gl=True), "wlod gl", want_wlod_gl, sel=wsel)
+        st = panel.stats()
+        assert st["n_stall_reruns"] == 0 and st["n_count_timeouts"] == 0      # the strip kernel's waits all ended in time
         del ld
 
         # ---- continuous likelihoods at this size: 100 GB of values, converted to terms in place

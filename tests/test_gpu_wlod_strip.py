@@ -44,6 +44,7 @@ def test_strip_kernel_against_oracle_and_tile_kernel(gpu_ctx, W, groups, monkeyp
             out = panel.wlod_windows(W, 0.001, mg, 7, 1e-9, pitch_align=pa, ind_begin=i0, ind_count=cnt, use_gl=True)
             for c in range(len(sizes)):
                 assert ol.bits_equal(np.ascontiguousarray(out[c]), want[c][i0:i0 + cnt]), (pa, i0, c)
+        assert panel.stats()["n_stall_reruns"] == 0        # no strip wave ran out of its poll budget
         monkeypatch.setenv("GARLIC_WLOD_GL_NO_STRIP", "1")
         out = panel.wlod_windows(W, 0.001, mg, 7, 1e-9, pitch_align=32, use_gl=True)
         for c in range(len(sizes)):
@@ -72,3 +73,32 @@ def test_strip_kernel_repeated_calls_and_plan_reuse(gpu_ctx, monkeypatch):
             out = panel.wlod_windows(W, 0.001, mg, 7, 1e-9, pitch_align=32, use_gl=True)
             for c in range(len(sizes)):
                 assert ol.bits_equal(np.ascontiguousarray(out[c]), want[c]), (step, c)
+
+
+def test_a_stalled_strip_launch_is_repaired_on_the_device_and_counted(gpu_ctx, monkeypatch):
+    """GARLIC_WLOD_STRIP_FORCE_RERUN sets the strip kernel's stall flag after every launch: the tile form enqueued behind
+    it (it runs only when the flag is set; no copy back, no synchronisation) recomputes the scores, and
+    garlic_call_stats.n_stall_reruns says how often that happened -- 0 without the switch"""
+    rng = np.random.default_rng(78)
+    W, mg, sizes, nind = 80, 10 ** 9, [2500, 700], 128
+    chroms, gpos, lds, err = _panel(rng, sizes, nind, W, mg)
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms],
+                      gpos=np.concatenate(gpos))
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        panel.set_ld(W, np.concatenate(lds, axis=0))
+        panel.set_gl(np.concatenate(err, axis=0))
+        want = [ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, 0.001, mg, 1e-9, 7, gl=err[c])
+                for c, (g, f, p, cs, ce) in enumerate(chroms)]
+        out = panel.wlod_windows(W, 0.001, mg, 7, 1e-9, pitch_align=32, use_gl=True)
+        assert panel.stats()["n_stall_reruns"] == 0
+        monkeypatch.setenv("GARLIC_WLOD_STRIP_FORCE_RERUN", "1")
+        for k in (1, 2):
+            out = panel.wlod_windows(W, 0.001, mg, 7, 1e-9, pitch_align=32, use_gl=True)
+            for c in range(len(sizes)):
+                assert ol.bits_equal(np.ascontiguousarray(out[c]), want[c]), (k, c)
+            assert panel.stats()["n_stall_reruns"] == k
+        monkeypatch.delenv("GARLIC_WLOD_STRIP_FORCE_RERUN")
+        panel.wlod_windows(W, 0.001, mg, 7, 1e-9, pitch_align=32, use_gl=True)
+        assert panel.stats()["n_stall_reruns"] == 2

@@ -81,7 +81,7 @@ def main():
     if "feed" in args.modes.split(","):
         # KDE feed (garlic_lod_feed, unweighted, step = W): chain kernel with the thinned write-out, then
         # the compaction.  chain_kernel_ms = the chain kernel alone; call_ms = wall clock incl. the D2H
-        # of the feed.  GARLIC_FEED_FULL=1 in the environment gives the full-scores-then-sample path.
+        # of the feed.
         import time
         panel.lod_feed(W, error, max_gap, W, copy=False)
         ms, wall = [], []
@@ -95,7 +95,7 @@ def main():
                           "feed_values": int(feed.shape[0]), "chain_kernel_ms": k,
                           "call_ms": float(np.mean(wall)) * 1e3,
                           "sliding_windows_per_s": nloci * nind / (k * 1e-3),
-                          "full_path": bool(os.environ.get("GARLIC_FEED_FULL"))}))
+                          }))
     for mode in [m for m in args.modes.split(",") if m not in ("ld", "feed")]:
         run(mode)
         ms = []

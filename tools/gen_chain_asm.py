@@ -134,8 +134,6 @@ S_TMP = 55
 S_K = 56
 S_F0, S_F1 = 57, 58
 S_ROWS = 59                # POST: valid individuals (rows) of this item
-S_NEXT, S_STEP = 40, 41    # thinned output, CHAIN and POST: next sampled window (from the loop's first), step
-S_MASK, S_EXEC = 42, 44    # thinned output, POST: lanes that are rows of the shard; saved exec
 
 CLOBBER_V = list(range(64, 188))
 CLOBBER_S = list(range(40, 60))
@@ -206,8 +204,7 @@ def gen_R(g, slot, n):
 
 
 def gen_C(g, n, a_ops, tbuf, write=True):
-    """chain of batch n, the next-but-one batch's address ops woven in (1 per step); write=False:
-    the tile holds no sampled window (thinned output), nothing of it is kept"""
+    """chain of batch n, the next-but-one batch's address ops woven in (1 per step)"""
     buf = V_BUF[n % 2]
     a_ops = list(a_ops)
     P0, P1 = V_ACC, V_ACC + 2
@@ -236,11 +233,8 @@ def gen_exp_reads(g, slot, eset):
     return last
 
 
-def chain_tile(g, slot, uid, thin=False):
-    """CHAIN, one tile k (unrolled position slot = k % NSLOT): COMB/EXP slot k % NEXP, tile buffer
-    k % NTILE.  thin: tiles without a sampled window (S_NEXT >= the tile's end) take a copy of the
-    schedule without the 16 tile writes -- a ds_write_b128 holds the wave for ~28 cycles, and with
-    the stores gone CHAIN's pace is the kernel's."""
+def chain_tile(g, slot, uid):
+    """CHAIN, one tile k (unrolled position slot = k % NSLOT): COMB/EXP slot k % NEXP, tile buffer k % NTILE"""
     tbuf = slot % NTILE
     nxt = (slot + 1) % NEXP
     slot = slot % NEXP
@@ -288,23 +282,7 @@ def chain_tile(g, slot, uid, thin=False):
         gen_R(g, nxt, 0)
         gen_C(g, 3, all_addr_ops(1, en), tbuf, write)
 
-    if thin:
-        e(f"s_lshl_b32 s{S_TMP}, s{S_K}, 5")
-        e(f"s_add_u32 s{S_TMP}, s{S_TMP}, 32")                 # first window of tile k + 1
-        e(f"s_cmp_lt_u32 s{S_NEXT}, s{S_TMP}")
-        e(f"s_cbranch_scc0 CHAIN_NOWR_{uid}_%=")
-        body(True)
-        e(f"CHAIN_ADV_{uid}_%=:")                                # past this tile's samples
-        e(f"s_add_u32 s{S_NEXT}, s{S_NEXT}, s{S_STEP}")
-        e(f"s_cmp_lt_u32 s{S_NEXT}, s{S_TMP}")
-        e(f"s_cbranch_scc1 CHAIN_ADV_{uid}_%=")
-        e(f"s_branch CHAIN_JOIN_{uid}_%=")
-        e(f"CHAIN_NOWR_{uid}_%=:")
-        g.drained()                                              # same state as at the branch
-        body(False)
-        e(f"CHAIN_JOIN_{uid}_%=:")
-    else:
-        body(True)
+    body(True)
     # publish: tile k complete in LDS (its writes are waited for), input slot k released
     e(f"s_add_u32 s{S_K}, s{S_K}, 1")
     e(f"v_mov_b32_e32 v{V_TMP0}, s{S_K}")
@@ -313,12 +291,9 @@ def chain_tile(g, slot, uid, thin=False):
     e(f"ds_write_b32 v{V_FLAG}, v{V_TMP0}")
 
 
-def gen_chain(g, thin=False):
+def gen_chain(g):
     e = g.emit
     e("ROLE_CHAIN_%=:")
-    if thin:
-        e(f"s_mov_b32 s{S_NEXT}, %[next]")
-        e(f"s_mov_b32 s{S_STEP}, %[step]")
     e(f"s_mov_b32 s{S_CNT}, %[ntiles]")
     e(f"s_mov_b32 s{S_K}, 0")
     e(f"v_mov_b64 {pair(V_ACC + 2)}, %[acc]")
@@ -356,7 +331,7 @@ def gen_chain(g, thin=False):
         e(op)
     e("CHAIN_LOOP_%=:")
     for slot in range(NSLOT):
-        chain_tile(g, slot, slot, thin)
+        chain_tile(g, slot, slot)
         e(f"s_cmp_eq_u32 s{S_K}, s{S_CNT}")
         if slot < NSLOT - 1:
             e("s_cbranch_scc1 CHAIN_DONE_%=")
@@ -529,75 +504,6 @@ def post_tile(g, slot, uid):
     e(f"s_add_u32 s{S_K}, s{S_K}, 1")
     e(f"v_mov_b32_e32 v{V_TMP0}, s{S_K}")
     e(f"ds_write_b32 v{V_FLAG}, v{V_TMP0} offset:4")
-
-
-# ---- POST, thinned output (KDE feed: every step-th locus of the chromosome, garlic-data.cpp:2036):
-# the tile's one or few sampled columns go to a [individual][sample] matrix, 8 B per lane; nothing
-# else is stored, so the kernel runs at CHAIN's pace.  S_NEXT = next sampled window, counted from
-# the loop's first window; S_OUT = address of that sample's column in the item's first row.
-def post_tile_thin(g, slot, uid):
-    tbuf = slot % NTILE
-    assert tbuf * TILE_BUF + 31 * 8 <= 65535
-    e = g.emit
-    e(f"POST_POLL_{uid}_%=:")  # wait for CHAIN to finish tile k
-    e(f"ds_read_b32 v{V_TMP0}, v{V_FLAG}")
-    e("s_waitcnt lgkmcnt(0)")
-    e(f"v_readfirstlane_b32 s{S_F0}, v{V_TMP0}")
-    e(f"s_cmp_gt_u32 s{S_F0}, s{S_K}")
-    e(f"s_cbranch_scc1 POST_GO_{uid}_%=")
-    e("s_sleep 1")
-    e(f"s_branch POST_POLL_{uid}_%=")
-    e(f"POST_GO_{uid}_%=:")
-    e(f"s_lshl_b32 s{S_TMP}, s{S_K}, 5")
-    e(f"s_add_u32 s{S_TMP}, s{S_TMP}, 32")                 # first window of tile k + 1
-    e(f"THIN_LOOP_{uid}_%=:")
-    e(f"s_cmp_lt_u32 s{S_NEXT}, s{S_TMP}")
-    e(f"s_cbranch_scc0 THIN_END_{uid}_%=")
-    e(f"s_and_b32 s{S_F1}, s{S_NEXT}, 31")                  # column inside the tile
-    e(f"s_lshl_b32 s{S_F1}, s{S_F1}, 3")
-    e(f"v_add_u32_e32 v{V_TMP1}, s{S_F1}, v{V_TRD}")
-    e(f"ds_read_b64 {pair(V_ST)}, v{V_TMP1} offset:{tbuf * TILE_BUF}")
-    e("s_waitcnt lgkmcnt(0)")
-    e(f"s_mov_b64 exec, s[{S_MASK}:{S_MASK + 1}]")          # rows past the shard's last individual: not stored
-    e(f"global_store_dwordx2 v{V_STOFF}, {pair(V_ST)}, s[{S_OUT}:{S_OUT + 1}]")
-    e(f"s_mov_b64 exec, s[{S_EXEC}:{S_EXEC + 1}]")
-    e(f"s_add_u32 s{S_OUT}, s{S_OUT}, 8")
-    e(f"s_addc_u32 s{S_OUT + 1}, s{S_OUT + 1}, 0")
-    e(f"s_add_u32 s{S_NEXT}, s{S_NEXT}, s{S_STEP}")
-    e(f"s_branch THIN_LOOP_{uid}_%=")
-    e(f"THIN_END_{uid}_%=:")
-    e(f"s_add_u32 s{S_K}, s{S_K}, 1")
-    e(f"v_mov_b32_e32 v{V_TMP0}, s{S_K}")
-    e(f"ds_write_b32 v{V_FLAG}, v{V_TMP0} offset:4")
-
-
-def gen_post_thin(g):
-    e = g.emit
-    e("ROLE_POST_%=:")
-    e(f"s_mov_b64 s[{S_EXEC}:{S_EXEC + 1}], exec")
-    e(f"s_mov_b32 s{S_ROWS}, %[rows]")
-    e(f"s_mov_b64 s[{S_OUT}:{S_OUT + 1}], %[out]")
-    e(f"s_mov_b32 s{S_CNT}, %[ntiles]")
-    e(f"s_mov_b32 s{S_NEXT}, %[next]")
-    e(f"s_mov_b32 s{S_STEP}, %[step]")
-    e(f"s_mov_b32 s{S_K}, 0")
-    e(f"v_mov_b32_e32 v{V_FLAG}, {FLAGS}")
-    e(f"v_cmp_lt_u32_e64 s[{S_MASK}:{S_MASK + 1}], %[lane], s{S_ROWS}")
-    e(f"v_mul_lo_u32 v{V_STOFF}, %[lane], %[pitch8]")       # row = lane: its byte offset in the sample matrix
-    e(f"v_mul_u32_u24_e32 v{V_TRD}, {TPITCH_B}, %[lane]")
-    e(f"v_add_u32_e32 v{V_TRD}, {TILE_BASE}, v{V_TRD}")
-    e("s_barrier")  # CHAIN has reset the counters
-    e("POST_LOOP_%=:")
-    for idx in range(NSLOT):
-        post_tile_thin(g, idx, idx)
-        e(f"s_cmp_eq_u32 s{S_K}, s{S_CNT}")
-        if idx < NSLOT - 1:
-            e("s_cbranch_scc1 POST_DONE_%=")
-        else:
-            e("s_cbranch_scc0 POST_LOOP_%=")
-    e("POST_DONE_%=:")
-    e("s_waitcnt lgkmcnt(0)")
-    e("s_branch DONE_%=")
 
 
 def gen_post(g):
@@ -784,7 +690,7 @@ def gen_comb(g):
     e("s_branch DONE_%=")
 
 
-def gen_all(thin=False):
+def gen_all():
     g = Gen()
     e = g.emit
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
@@ -794,11 +700,8 @@ def gen_all(thin=False):
     e("s_cbranch_scc1 ROLE_PRE_%=")
     e("s_cmp_eq_u32 %[wave], 3")
     e("s_cbranch_scc1 ROLE_COMB_%=")
-    gen_chain(g, thin)
-    if thin:
-        gen_post_thin(g)
-    else:
-        gen_post(g)
+    gen_chain(g)
+    gen_post(g)
     gen_pre(g)
     gen_comb(g)
     e("DONE_%=:")
@@ -822,7 +725,7 @@ def main():
         f.write(f"#define GARLIC_CHAIN_MAX_DW {WROWS - 2 * NSLOT - 3 * CHROWS}\n")
         f.write(f"#define GARLIC_CHAIN_CHROWS {CHROWS}\n")
         f.write(f"#define GARLIC_CHAIN_SPREAD_IN {SPREAD_IN}\n#define GARLIC_CHAIN_SPREAD_OUT {SPREAD_OUT}\n")
-        for name, body in (("GARLIC_CHAIN_LOOP_ASM", lines), ("GARLIC_CHAIN_LOOP_ASM_THIN", gen_all(thin=True))):
+        for name, body in (("GARLIC_CHAIN_LOOP_ASM", lines),):
             f.write(f"#define {name} \\\n")
             for ln in body:
                 if ln.startswith(";"):

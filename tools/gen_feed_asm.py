@@ -32,7 +32,7 @@ Why by hand: the length of the longest run of windows x the pace of ONE wave is 
   into 8-word register rings two tiles after they were requested.
 
   samples (feed)   a sampled locus (every step-th, src/garlic-data.cpp:2036) is picked from the batch's 8 accumulators
-                   with s_set_gpr_idx and kept; four of them leave as one 32-byte piece per lane;
+                   with s_set_gpr_idx and kept; eight of them leave as one 64-byte piece per lane;
   bits             a tile's 32 bits are a dword per lane; eight tiles' dwords leave as one aligned 32-byte piece per lane.
 
 The block runs 8 n tiles, all of them interior (every window a rolling update); lod_feed_kernel runs the other tiles
@@ -80,10 +80,11 @@ V_CL = 119              # this lane's entering-SNP term:                      32
 V_CW = 120              # its pair in the table:                              256 * (8 wave + lane / 16) + 16 * (lane % 16)
 V_STOFF = 121           # the lane's row * row pitch (bytes) of the sample / bit matrix
 V_S = 122               # the sampled accumulator (2 registers)
-V_SR = 124              # feed: four kept samples (8 registers); bits: the dwords of the iteration's 8 tiles
-V_WSA = 132             # this wave's word staging area, the lane's column: WST_BASE + wave * 1024 + lane * 4
-V_WSW = 133             # ... the lane's 16 bytes of it:                      WST_BASE + wave * 1024 + lane * 16
-CLOBBER_V = list(range(20, 134))
+V_SR = 124              # feed: KEEP = 8 kept samples (16 registers); bits: the dwords of the iteration's 8 tiles
+KEEP = 8
+V_WSA = 140             # this wave's word staging area, the lane's column: WST_BASE + wave * 1024 + lane * 4
+V_WSW = 141             # ... the lane's 16 bytes of it:                      WST_BASE + wave * 1024 + lane * 16
+CLOBBER_V = list(range(20, 142))
 # ---- fixed SGPRs
 S_PLW, S_PTW = 40, 42   # genotype word streams: address of the block's word row 0 of the loop's first tile, + the loop's bias
 S_PTR = 44              # this wave's eighth of the term rows (waves 0, 1: entering SNPs, 2, 3: leaving; 16 rows each), RAW_AHEAD tiles ahead of the iteration's first tile
@@ -98,7 +99,7 @@ S_IDX = 57
 S_MASK, S_EXEC = 58, 60   # lanes that have a row in the sample matrix; saved exec
 S_CUT = 62              # bits variant: the LOD cutoff (2 registers)
 S_MCC = 64              # 0xcccccccc
-S_NCAP = 65             # feed: samples kept (0..3)
+S_NCAP = 65             # feed: samples kept (0 .. KEEP - 1)
 S_WAVE = 66
 CLOBBER_S = list(range(40, 67))
 # bits variant (GARLIC_FEED_BITS_LOOP_ASM): instead of sampled scores the loop leaves ONE BIT per window and lane --
@@ -244,7 +245,7 @@ def masked(e, lines):
 
 def gen_capture(g_, u, b):
     """out of line: the sampled accumulator(s) of batch b of tile u.  S_NEXT has gone below zero (mod 2^32).  The
-    sample joins the kept ones; four leave together as 32 bytes per lane."""
+    sample joins the kept ones; KEEP = 8 leave together as 64 bytes per lane."""
     e = g_.emit
     e(f"CAP_{u}_{b}_%=:")
     e(f"s_add_u32 s{S_IDX}, s{S_NEXT}, 8")                  # window of the batch
@@ -259,11 +260,10 @@ def gen_capture(g_, u, b):
     e(f"v_mov_b32_e32 v{V_SR + 1}, v{V_S + 1}")
     e("s_set_gpr_idx_off")
     e(f"s_add_u32 s{S_NCAP}, s{S_NCAP}, 1")
-    e(f"s_cmp_lg_u32 s{S_NCAP}, 4")
+    e(f"s_cmp_lg_u32 s{S_NCAP}, {KEEP}")
     e(f"s_cbranch_scc1 CAPK_{u}_{b}_%=")
-    masked(e, [f"global_store_dwordx4 v{V_STOFF}, {quad(V_SR)}, s[{S_OUT}:{S_OUT + 1}]",
-               f"global_store_dwordx4 v{V_STOFF}, {quad(V_SR + 4)}, s[{S_OUT}:{S_OUT + 1}] offset:16"])
-    bump(e, S_OUT, 32)
+    masked(e, [f"global_store_dwordx4 v{V_STOFF}, {quad(V_SR + 4 * k)}, s[{S_OUT}:{S_OUT + 1}] offset:{16 * k}" for k in range(KEEP // 2)])
+    bump(e, S_OUT, 8 * KEEP)
     e(f"s_mov_b32 s{S_NCAP}, 0")
     e(f"CAPK_{u}_{b}_%=:")
     e(f"s_add_i32 s{S_NEXT}, s{S_NEXT}, s{S_STEP}")
@@ -557,8 +557,8 @@ def gen_all(bits=False):
     e("s_cbranch_scc1 LOOP_%=")
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     if not bits and "nocapture" not in ABL:
-        # the samples still kept (fewer than four): 8 B each
-        for k in range(3):
+        # the samples still kept (fewer than KEEP): 8 B each
+        for k in range(KEEP - 1):
             e(f"s_cmp_le_u32 s{S_NCAP}, {k}")
             e("s_cbranch_scc1 FLUSHED_%=")
             masked(e, [f"global_store_dwordx2 v{V_STOFF}, {pair(V_SR + 2 * k)}, s[{S_OUT}:{S_OUT + 1}] offset:{8 * k}"])

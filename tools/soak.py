@@ -201,6 +201,12 @@ def soak(ctx, trials, seed, verbose=True):
                 if [len(w) for w in want] != list(per_chr[k]) or not ol.bits_equal(feeds[k], np.concatenate(want)):
                     fails += 1
                     print("FAIL feed_multi", Wk, sk, tag)
+            # liveness book-keeping: no strip launch had to be repaired, no count item timed out
+            st = panel.stats()
+            checks += 1
+            if st["n_stall_reruns"] or st["n_count_timeouts"]:
+                fails += 1
+                print("FAIL liveness counters", st["n_stall_reruns"], st["n_count_timeouts"], tag)
         if verbose and trial % 10 == 9:
             print(f"trial {trial + 1}: {checks} checks, {fails} failures, {time.time() - t0:.0f} s", flush=True)
     if strip_env is None:
