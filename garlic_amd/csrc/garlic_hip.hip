@@ -250,6 +250,8 @@ struct garlic_panel {
         // on the window size: kept across calls (--winsize-multi with --weighted: 3.5 of a call's 32 ms at 10M x 1250)
         uint64_t planes_key = 0;
         bool planes_valid = false;
+        // garlic_panel_compute_ld -> garlic_ld_counts: go on to the hr2 table in the pair kernel; -> garlic_ld_finish: it is there
+        bool fuse_request = false, fused_done = false;
         void release()
         {
             sub.release(); m.release(); h.release(); o.release(); loc.release(); pair.release(); loc_planes.release();
@@ -2185,6 +2187,22 @@ int garlic_panel_set_ld(garlic_panel *p, int32_t winsize, const double *ld, int3
 }
 
 // ---- LD weights on the device (ld_kernels.hpp)
+// unphased, 16 < W <= 129: the pair counts as banded Gram matrices on the matrix cores (ld_pair_mfma_kernel)
+static bool ld_pairs_on_mfma(int32_t winsize, int32_t phased)
+{
+    const int mfma_nj = 1 + (30 + winsize) / 32;
+    const bool pair_flat = getenv("GARLIC_LD_PAIR_FLAT") && winsize <= 32;
+    return !phased && !pair_flat && winsize > LD_SMALL_MAX_W && mfma_nj <= 5 && !getenv("GARLIC_LD_PAIR_NO_MFMA") &&
+           !getenv("GARLIC_LD_PAIR_TILED") && !getenv("GARLIC_LD_PAIR_L2");
+}
+// 32 < W <= 512: the ordered sums with a thread per SNP of the window (ld_sum_col_kernel), from the combined hr2 table
+static bool ld_sums_by_snp(int32_t winsize)
+{
+    const int col_threads = (winsize + 16 + WAVE - 1) / WAVE * WAVE;
+    return winsize > LD_COL_B && winsize <= 512 && col_threads <= LD_COL_MAX_THREADS && !getenv("GARLIC_LD_SUM_BY_COLUMN") &&
+           !getenv("GARLIC_LD_SUM_L2");
+}
+
 static int ld_check(garlic_panel *p, int32_t winsize, int32_t phased)
 {
     if (!p) return fail(GARLIC_ERR_INVALID, "panel is NULL");
@@ -2245,8 +2263,15 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
     const size_t lane_lds = sizeof(uint64_t) * (phased ? 4 : 2) * (size_t)lane_stage * (LD_LANE_T + winsize - 1);
     // unphased, 16 < W <= 129: the counts as banded Gram matrices on the matrix cores (ld_pair_mfma_kernel)
     const int mfma_nj = 1 + (30 + winsize) / 32;
-    const bool pair_mfma = !phased && !pair_flat && winsize > LD_SMALL_MAX_W && mfma_nj <= 5 && !getenv("GARLIC_LD_PAIR_NO_MFMA") &&
-                           !getenv("GARLIC_LD_PAIR_TILED") && !getenv("GARLIC_LD_PAIR_L2");
+    const bool pair_mfma = ld_pairs_on_mfma(winsize, phased);
+    // garlic_panel_compute_ld (every individual's counts are local): the pair kernel writes the hr2 table itself
+    const bool fuse_hr2 = p->lds.fuse_request && pair_mfma && ld_sums_by_snp(winsize);
+    if (p->lds.fuse_request && !fuse_hr2) {      // (the caller has sized the pair table for the fused form)
+        p->lds.fuse_request = false;
+        return fail(GARLIC_ERR_STATE, "internal: LD fusion requested for a shape the pair kernel does not take");
+    }
+    p->lds.fuse_request = false;
+    p->lds.fused_done = false;
     const bool pair_lane = !pair_mfma && !pair_flat && winsize - 1 <= 256 && lane_lds <= 150 * 1024 && !getenv("GARLIC_LD_PAIR_TILED") &&
                            !getenv("GARLIC_LD_PAIR_L2");
     const bool pair_tiled = !pair_mfma && !pair_flat && !pair_lane && winsize - 1 <= 256 && !getenv("GARLIC_LD_PAIR_L2");
@@ -2313,20 +2338,34 @@ int garlic_ld_counts(garlic_panel *p, int32_t winsize, int32_t phased, const int
         DevBuf<LdPairChr> &d_pc = p->lds.pair_chrs;
         if ((rc = d_pc.reserve(pc.size()))) return done(rc);
         e = hipMemcpyAsync(d_pc.p, pc.data(), sizeof(LdPairChr) * pc.size(), hipMemcpyHostToDevice, s);
-        const void *fn = mfma_nj <= 2 ? (const void *)ld_pair_mfma_kernel<2> : mfma_nj == 3 ? (const void *)ld_pair_mfma_kernel<3>
-                       : mfma_nj == 4 ? (const void *)ld_pair_mfma_kernel<4> : (const void *)ld_pair_mfma_kernel<5>;
+        const void *fn = fuse_hr2 ? (mfma_nj <= 2 ? (const void *)ld_pair_mfma_kernel<2, true> : mfma_nj == 3 ? (const void *)ld_pair_mfma_kernel<3, true>
+                                     : mfma_nj == 4 ? (const void *)ld_pair_mfma_kernel<4, true> : (const void *)ld_pair_mfma_kernel<5, true>)
+                                  : (mfma_nj <= 2 ? (const void *)ld_pair_mfma_kernel<2, false> : mfma_nj == 3 ? (const void *)ld_pair_mfma_kernel<3, false>
+                                     : mfma_nj == 4 ? (const void *)ld_pair_mfma_kernel<4, false> : (const void *)ld_pair_mfma_kernel<5, false>);
         const int nj = std::max(2, mfma_nj);
-        const size_t lds = (size_t)2 * 2 * (4 + nj - 1) * WAVE * 16;
+        const size_t lds = std::max((size_t)2 * 2 * (4 + nj - 1) * WAVE * 16, fuse_hr2 ? LDM_XT_BYTES : (size_t)0);
+        const double *a_hf = nullptr;
+        double *a_c = nullptr;
+        if (fuse_hr2) {      // homFreq from the locus counts, room for the combined table (+ 1 KB: ld_sum_col_kernel's last request)
+            const size_t n = (size_t)p->nloci * winsize;
+            if ((rc = p->lds.hf.reserve(p->nloci)) || (rc = p->lds.fwd.reserve(2 * n + 256))) return done(rc);
+            hipLaunchKernelGGL(ld_homfreq_kernel, dim3((unsigned)((p->nloci + 255) / 256)), dim3(256), 0, s, p->lds.loc_planes.p, p->nloci,
+                               p->lds.hf.p);
+            a_hf = p->lds.hf.p;
+            a_c = p->lds.fwd.p;
+        }
         if (e == hipSuccess && lds > 48 * 1024) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
         const uint64_t *a_m = d_m.p, *a_h = d_h.p;
         const LdPairChr *a_pc = d_pc.p;
         int a_nblk = nblk, a_nchr = p->nchr, a_w = winsize;
         int64_t a_nloci = p->nloci;
-        void *kargs[] = {(void *)&a_m, (void *)&a_h, (void *)&a_nblk, (void *)&a_nloci, (void *)&a_pc, (void *)&a_nchr, (void *)&a_w, (void *)&pair};
+        void *kargs[] = {(void *)&a_m, (void *)&a_h, (void *)&a_nblk, (void *)&a_nloci, (void *)&a_pc, (void *)&a_nchr, (void *)&a_w, (void *)&pair,
+                         (void *)&a_hf, (void *)&a_c};
         e = hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(256), kargs, lds, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);   // pc (host) is read by the copy above
         if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "LD counts: %s", hipGetErrorString(e)));
+        p->lds.fused_done = fuse_hr2;
     }
     if (pair_lane) {   // all chromosomes in one grid, tiles of 256 SNPs
         std::vector<LdPairChr> pc;
@@ -2435,8 +2474,9 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
     // ordered sums: LDS-tiled kernel (one thread per column of the LD row) unless the window is too wide
     // ... thread = SNP of the window, accumulators = window starts (ld_sum_col_kernel: 32 < W <= 512) unless switched off
     const int col_threads = (winsize + 16 + WAVE - 1) / WAVE * WAVE;
-    const bool by_snp = winsize > LD_COL_B && winsize <= 512 && col_threads <= LD_COL_MAX_THREADS && !getenv("GARLIC_LD_SUM_BY_COLUMN") &&
-                        !getenv("GARLIC_LD_SUM_L2");
+    const bool by_snp = ld_sums_by_snp(winsize);
+    const bool have_table = p->lds.fused_done && by_snp;      // the pair kernel has written the hr2 table (garlic_panel_compute_ld)
+    p->lds.fused_done = false;
     const bool tiled = by_snp || (winsize <= LD_SUM_MAX_W && !getenv("GARLIC_LD_SUM_L2"));
     const int sum_b = by_snp ? std::min(LD_COL_B, col_threads - winsize) : LD_SUM_B;      // (thread W + B - 1 reads one element further on odd steps)
     // (the SNP-per-thread kernel reads one combined row of 2W doubles per SNP, in d_fwd; + 1 KB the last row's
@@ -2479,7 +2519,9 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
     for (int c = 0; c < p->nchr; c++) {
         const int64_t lo = p->chr_off[c], hi = p->chr_off[c + 1];
         const size_t hr2_lds = sizeof(double) * (LD_HR2_T + winsize + (size_t)LD_HR2_T * (winsize + 1));
-        if (by_snp && hr2_lds <= 64 * 1024 && !getenv("GARLIC_LD_HR2_PLAIN"))
+        if (have_table)
+            ;
+        else if (by_snp && hr2_lds <= 64 * 1024 && !getenv("GARLIC_LD_HR2_PLAIN"))
             hipLaunchKernelGGL(ld_hr2_tile_kernel, dim3((unsigned)((hi - lo + LD_HR2_T - 1) / LD_HR2_T)), dim3(256),
                                hr2_lds, s, pair, d_hf.p, lo, hi, winsize, d_fwd.p);
         else if (by_snp)
@@ -2544,9 +2586,16 @@ int garlic_panel_compute_ld(garlic_panel *p, int32_t winsize, int32_t phased, co
     int rc;
     if ((rc = ld_check(p, winsize, phased))) return rc;
     DevBuf<int32_t> &d_loc = p->lds.loc, &d_pair = p->lds.pair;   // kept with the panel, as all LD scratch
-    if ((rc = d_loc.reserve((size_t)p->nloci * 2)) || (rc = d_pair.reserve((size_t)p->nloci * winsize * 2)))
+    // every individual's counts are here: the pair kernel can go on to the hr2 values, no pair table (GARLIC_LD_UNFUSED:
+    // the two steps of garlic_ld_counts / garlic_ld_finish, which a sharded panel needs)
+    const bool fuse = ld_pairs_on_mfma(winsize, phased) && ld_sums_by_snp(winsize) && !getenv("GARLIC_LD_UNFUSED");
+    if ((rc = d_loc.reserve((size_t)p->nloci * 2)) || (rc = d_pair.reserve(fuse ? 2 : (size_t)p->nloci * winsize * 2)))
         return rc;
-    if ((rc = garlic_ld_counts(p, winsize, phased, sub_idx, n_sub, d_loc.p, d_pair.p, GARLIC_DEVICE))) return rc;
+    p->lds.fuse_request = fuse;
+    if ((rc = garlic_ld_counts(p, winsize, phased, sub_idx, n_sub, d_loc.p, d_pair.p, GARLIC_DEVICE))) {
+        p->lds.fuse_request = false;
+        return rc;
+    }
     if (where == GARLIC_DEVICE || !ld_out)
         return garlic_ld_finish(p, winsize, phased, d_loc.p, d_pair.p, ld_out, GARLIC_DEVICE);
     // host output: finish on the device, then copy out

@@ -931,10 +931,22 @@ __device__ __forceinline__ uint32_t ldm_spread8(uint32_t x)
     return (t | (t << 3)) & 0x11111111u;
 }
 
-template <int NJ>
+// HR2 (round 4): the kernel turns its counts into the two hr2 values of every pair itself and writes them straight
+// into the combined table ld_sum_col_kernel reads (C[i][W-1 + d] = hr2(i, i+d), C[j][W-1 - d] = hr2(j, i), C[i][W-1] = 1)
+// -- ld_hr2_tile_kernel's arithmetic to the letter (hr2_from_counts both ways, garlic-data.cpp:558-583) -- so that the
+// 8-GB pair table is neither written nor read (that kernel moved 24 GB for 1.6 ms of arithmetic: 7.1 ms of the LD call at
+// 10M SNPs x 1250, W = 100).  Row i's values leave along d as they sit in the accumulator tile (32 lanes = 256
+// contiguous bytes); the partner rows' values are turned through an LDS tile [j][i] per wave (the operand buffers,
+// idle by then) and leave as 32 consecutive doubles of row j.  Only where the counts need no sum over shards:
+// garlic_panel_compute_ld; garlic_ld_counts / garlic_ld_finish keep the table.
+constexpr int LDM_XT = 33;                         // doubles per row of a wave's transposition tile (conflict-free)
+constexpr size_t LDM_XT_BYTES = ((size_t)4 * 32 * LDM_XT + 256) * 8;      // + homFreq of the workgroup's (up to) 256 staged SNPs
+
+template <int NJ, bool HR2>
 __global__ void __launch_bounds__(256, 2)
 ld_pair_mfma_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restrict__ planeH, int nblk, int64_t nloci,
-                    const LdPairChr *__restrict__ chrs, int nchr, int W, int32_t *__restrict__ pair)
+                    const LdPairChr *__restrict__ chrs, int nchr, int W, int32_t *__restrict__ pair,
+                    const double *__restrict__ hf, double *__restrict__ C)
 {
     constexpr int NT = 4 + NJ - 1;                 // staged tiles of 32 SNPs (<= 8: one SNP per thread)
     static_assert(NT * 32 <= 256, "one staged SNP per thread");
@@ -1004,6 +1016,55 @@ ld_pair_mfma_kernel(const uint64_t *__restrict__ planeM, const uint64_t *__restr
     // C layout (dtype-independent): column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     const int col = lane & 31, rh = 4 * (lane >> 5);
     const int64_t it = i0 + wave * 32;
+    if (HR2) {
+        // homFreq of the workgroup's NT x 32 SNPs behind the waves' transposition tiles
+        double *xt = reinterpret_cast<double *>(ldm_lds) + (size_t)wave * 32 * LDM_XT;     // [j][i] of one 32 x 32 tile
+        double *hfs = reinterpret_cast<double *>(ldm_lds) + (size_t)4 * 32 * LDM_XT;
+        if (mine) hfs[tid] = in ? hf[i0 + tid] : 0.0;
+        __syncthreads();
+        const int P = 2 * W;
+#pragma unroll
+        for (int q = 0; q < NJ; q++) {
+            const int64_t j = it + q * 32 + col;
+            const double HB = hfs[wave * 32 + q * 32 + col];
+            const bool okB = HB > 0 && HB < 1;
+            const double pB = HB * (1 - HB);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int base = (k & 3) + 8 * (k >> 2);           // il = base (lanes 0-31) or base + 4
+                // no lane of this (q, k) has 0 <= d < W (wave-uniform: d = 32 q + col - il): nothing to compute or keep
+                if (32 * q + 31 - base < 0 || 32 * q - (base + 4) >= W) continue;
+                const int il = base + rh;
+                const int64_t i = it + il;
+                const int64_t d = j - i;
+                const double HA = hfs[wave * 32 + il];
+                double f = 0.0, b = 0.0;
+                if (HA > 0 && HA < 1 && okB) {                     // hr2_from_counts(HA, HB, ..) and (HB, HA, ..)
+                    double HAB = (double)(int)(acc[q][1][k] * 4.0f);
+                    HAB /= (double)(int)(acc[q][0][k] * 4.0f);
+                    const double H = HAB - HA * HB, HH = H * H;
+                    const double vf = HH / (HA * (1 - HA) * HB * (1 - HB));
+                    const double vb = HH / (pB * HA * (1 - HA));
+                    f = (vf > 1) ? 1.0 : x86_nan_if_nan(vf);
+                    b = (vb > 1) ? 1.0 : x86_nan_if_nan(vb);
+                }
+                if (i < hi && j < hi && d >= 0 && d < W) C[i * P + W - 1 + d] = d == 0 ? 1.0 : f;
+                xt[col * LDM_XT + il] = b;
+                __builtin_amdgcn_sched_barrier(0);                 // one pair's divisions at a time: 160 accumulator registers are live
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // (the tile is this wave's own: its LDS operations execute in order)
+#pragma unroll 4
+            for (int r = 0; r < 16; r++) {
+                const int jl = 2 * r + (lane >> 5);
+                const int64_t jj = it + q * 32 + jl, ii = it + col;
+                const int64_t d = jj - ii;
+                const double v = xt[jl * LDM_XT + col];
+                if (ii < hi && jj < hi && d >= 1 && d < W) C[jj * P + W - 1 - d] = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < NJ; q++) {
         const int64_t j = it + q * 32 + col;
