@@ -397,8 +397,9 @@ def leg_ns(ctx, dev, steps):
         res[name] = {"call_ms": t * 1e3, "snps_per_s": nloci / t,
                      "roofline": {"bound": "fp64 valu adds (W^2 ordered adds per window start, ld_sum_col_kernel: one LDS read per "
                                            "up to 32 of them); the pair counts are banded Gram matrices of the subsample's bit "
-                                           "planes on the matrix cores (ld_pair_mfma_kernel, i8), hr2 two FP64 divisions per SNP pair",
-                                  "kernel": "ld_* (planes -- kept across calls --, pair counts, hr2 table, ordered sums + wLOD weights) -- the whole warm call",
+                                           "planes on the matrix cores (ld_pair_mfma_kernel, fp4 operands), which goes on to the pair's two hr2 "
+                                           "values (three FP64 divisions) and writes the combined table itself",
+                                  "kernel": "ld_* (planes -- kept across calls --, pair counts + hr2 table, ordered sums + wLOD weights) -- the whole warm call",
                                   "achieved": adds / t / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s (adds only; one separately rounded FP64 operation = one op, as in every other FP64 leg)",
                                   "frac": adds / t / 1e12 / FP64_PEAK_TFLOPS, "traffic": None,
                                   "ordered_adds_per_call": adds,

@@ -2484,13 +2484,16 @@ int garlic_ld_finish(garlic_panel *p, int32_t winsize, int32_t phased, const int
     if ((rc = d_hf.reserve(p->nloci)) || (rc = d_fwd.reserve(by_snp ? 2 * n + 256 : n)) || (!by_snp && (rc = d_bwd.reserve(n))))
         return done(rc);
     double *ld = ld_out;
-    if (where == GARLIC_HOST || !ld_out) {
+    // nobody asked for the LD matrix itself and the sum kernel writes the wLOD weights directly: it is not made at all
+    const bool weights_only = by_snp && !ld_out;
+    if (!weights_only && (where == GARLIC_HOST || !ld_out)) {
         if ((rc = d_ld.reserve(n))) return done(rc);
         ld = d_ld.p;
     }
     // initLDData zero-fills; ld_sum_col_kernel writes every entry of the window starts that have a full window, which
     // leaves the last W - 1 rows of each chromosome
-    if (by_snp) {
+    if (weights_only) {
+    } else if (by_snp) {
         for (int c = 0; c < p->nchr && e == hipSuccess; c++) {
             const int64_t lo = p->chr_off[c], hi = p->chr_off[c + 1], from = std::max(lo, hi - winsize + 1);
             if (hi > from) e = hipMemsetAsync(ld + from * winsize, 0, sizeof(double) * (size_t)(hi - from) * winsize, s);

@@ -862,10 +862,12 @@ ld_sum_col_kernel(const double *__restrict__ C, const LdSumChr *__restrict__ chr
         }
     }
 #ifndef GARLIC_LDS_ABL_NO_LD          // timing experiments (results wrong)
+    if (ld) {                         // (NULL: the caller wants the wLOD weights only -- 8 GB less to write at 10M SNPs, W = 100)
 #pragma unroll
-    for (int q = 0; q < LD_COL_B; q++) {
-        const int k = tl - q;
-        if (q < ns && k >= 0 && k < W) ld[(s0 + q) * W + k] = x86_nan_if_nan(acc[q]);
+        for (int q = 0; q < LD_COL_B; q++) {
+            const int k = tl - q;
+            if (q < ns && k >= 0 && k < W) ld[(s0 + q) * W + k] = x86_nan_if_nan(acc[q]);
+        }
     }
 #else
     if (acc[0] == 1.2345e-300) ld[s0 * W + tl] = acc[1] + acc[2] + acc[3] + acc[31] + acc[16];
