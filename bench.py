@@ -451,6 +451,10 @@ def leg_ns(ctx, dev, steps):
     clk = clock_under_load(lambda: panel.wlod_windows_device(out.data_ptr(), W, ERROR, MAX_GAP, M_GEN, MU, use_gl=True),
                            torch.cuda.synchronize)
     res["wlod_gl"] = dict(rate(k, dt), roofline=fp64_roofline("wlod_strip_gl_kernel", win, W, k, clock=clk))
+    st = panel.stats()
+    res["liveness"] = {"n_stall_reruns": int(st["n_stall_reruns"]), "n_count_timeouts": int(st["n_count_timeouts"]),
+                       "tgls_mode": list(panel.tgls_mode()),
+                       "note": "strip launches the tile form had to repair / count items that gave up: expected 0 (garlic_call_stats)"}
     # GARLIC's default --winsize 10 (windows narrower than the kernels' 16-window groups): bound by the scores written
     W10 = 10
     panel.compute_ld(W10, want_output=False)                     # scratch for this window size
@@ -840,6 +844,7 @@ def main():
                     ctx.set_async(False)
                     res["end_to_end"] = leg_end_to_end(ctx, dev)
                     ctx.set_async(True)
+                    ctx.trim()      # (the placement candidates of the host-output scratch: idle pooled memory)
                     continue
                 also[{"ns": "c4_c5_shard", "c3": "c3_multi_winsize"}[name]] = dict(
                     (leg_ns if name == "ns" else leg_c3)(ctx, dev, max(3, min(args.steps, 10))),

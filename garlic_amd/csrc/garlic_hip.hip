@@ -936,6 +936,11 @@ int ensure_gl_terms(garlic_panel *p, bool scaled = false, int32_t M = 0, double 
         if ((rc = ensure_log10(p->ctx)) || (rc = ensure_dfreq(p))) return rc;
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        if (p->d_glterms.cap < n && (free_b < n * sizeof(double) || free_b - n * sizeof(double) < (size_t)(0.45 * (double)total_b))) {
+            HIP_TRY(hipStreamSynchronize(s));      // idle pooled score buffers are not a reason to give the values up
+            (void)score_pool_trim();
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        }
         // a second matrix only while it leaves plenty of room for the scores (it is what lets the panel
         // switch between raw and weighted terms later); otherwise the values become the terms
         bool separate = p->d_glterms.cap >= n ||
@@ -992,6 +997,14 @@ int ensure_gl_terms(garlic_panel *p, bool scaled = false, int32_t M = 0, double 
     } else if (rebuild) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GARLIC_OK;
+        if (p->d_glterms.cap < n && n * sizeof(double) + ((size_t)8 << 30) > free_b) {
+            // score buffers idle in the pool (candidates of an earlier placement probe, freed score matrices) are worth
+            // nothing next to the term matrix: give them back first.  (Round 4: 70 GB of them left the 10M x 1250 shard
+            // without its term matrix -- the chain then looks its terms up, 4.4 x slower, the weighted strip kernel 60 x.)
+            HIP_TRY(hipStreamSynchronize(s));
+            (void)score_pool_trim();
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return GARLIC_OK;
+        }
         if (p->d_glterms.cap < n && n * sizeof(double) + ((size_t)8 << 30) > free_b) {
             // not enough room: the LD scratch the panel keeps for the next window size is worth less
             // than the term matrix (the look-up-in-the-chain kernel is 10x slower)
