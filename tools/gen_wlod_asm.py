@@ -95,6 +95,7 @@ class Gen:
         e = self.e
         # requests issued after the one that brought the row: GL_AHEAD/2 when this step has just
         # issued one (even steps), one less otherwise
+        assert GL_AHEAD // 2 <= 63           # (counted waits: the VM counter holds 63)
         e(f"s_waitcnt vmcnt({GL_AHEAD // 2 if parity == 0 else GL_AHEAD // 2 - 1})")
         e("v_add_u32_e32 %[vt], %[rd], %[lane8b]")
         e(f"ds_read_b64 %[{dst}], %[vt]")
@@ -234,7 +235,11 @@ class StripGen(Gen):
                 e(f"s_cbranch_vccz WL_NOPF_{uid}_%=")
                 for off in (0, 64, 124)[:PFW_LOADS]:
                     e(f"global_load_dword %[vd], %[vz], s[{S_DP}:{S_DP + 1}] offset:{off}")
-                e("s_waitcnt vmcnt(32)")      # the touches are this loop's only vector loads: never more than the VM counter holds
+                # a throttle, not a wait for data (the touches are never read): at most 32 + this step's touches are ever
+                # outstanding.  The VM counter holds 63: a counted wait past that lets requests through unseen (round 3's
+                # 1-in-100 wrong group in the two-block loop)
+                assert 32 + PFW_LOADS <= 63
+                e("s_waitcnt vmcnt(32)")
                 e(f"WL_NOPF_{uid}_%=:")
         scb = "scb" if sc == "sc" else "scnb"
         for r in windows:
