@@ -1421,13 +1421,18 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
             HIP_TRY(hipMemsetAsync(p->d_counter.p + 3, 0, sizeof(int32_t), ctx->stream));
             const unsigned grid = (sa.n_work + 7u) / 8u * 8u;
             const bool wide = strip_waves == WS_WAVES_WIDE;
-            const void *fn = wide ? (aligned16 ? (const void *)wlod_strip_gl_kernel<true, WS_WAVES_WIDE>
-                                               : (const void *)wlod_strip_gl_kernel<false, WS_WAVES_WIDE>)
-                                  : (aligned16 ? (const void *)wlod_strip_gl_kernel<true, WS_WAVES>
-                                               : (const void *)wlod_strip_gl_kernel<false, WS_WAVES>);
-            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WS_LDS_BYTES));
+            // scores into 16-B aligned rows at W <= 113: the 80-VGPR form, three workgroups per CU (wlod_strip_kernel.hpp)
+            bool three = !wide && aligned16 && !sa.cov.bits && !getenv("GARLIC_WLOD_STRIP_TWO_PER_CU");
+            for (int k = 0; three && k < p->nchr; k++) three = L.pitch[k] * 8 < ((int64_t)1 << 32);
+            const void *fn = three ? (const void *)wlod_strip_gl3_kernel
+                             : wide ? (aligned16 ? (const void *)wlod_strip_gl_kernel<true, WS_WAVES_WIDE>
+                                                 : (const void *)wlod_strip_gl_kernel<false, WS_WAVES_WIDE>)
+                                    : (aligned16 ? (const void *)wlod_strip_gl_kernel<true, WS_WAVES>
+                                                 : (const void *)wlod_strip_gl_kernel<false, WS_WAVES>);
+            const uint32_t strip_lds = three ? WF_LDS_BYTES : WS_LDS_BYTES;
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)strip_lds));
             void *kargs[] = {(void *)&sa};
-            HIP_TRY(hipLaunchKernel(fn, dim3(grid), dim3((strip_waves + 1) * WAVE), kargs, WS_LDS_BYTES, ctx->stream));
+            HIP_TRY(hipLaunchKernel(fn, dim3(grid), dim3((strip_waves + 1) * WAVE), kargs, strip_lds, ctx->stream));
             // A wave of the strip kernel that ran out of its poll budget flags the launch (its scores are wrong).  The tile
             // form, which computes the same values without waits between waves, is enqueued behind it and runs only if
             // the flag is set -- on the device: no copy back, no synchronisation, the call stays asynchronous -- and

@@ -29,6 +29,7 @@ SWITCHES = [
     "GARLIC_WLOD_GL_NO_RING",           # weighted with likelihoods: no LDS rings
     "GARLIC_WLOD_GL_NO_PATCH",
     "GARLIC_WLOD_STRIP_NARROW_ONLY",    # ... strips only up to W = 113
+    "GARLIC_WLOD_STRIP_TWO_PER_CU",     # ... the 96-VGPR strip kernel (two workgroups per CU) where the 80-VGPR one would run
     "GARLIC_LD_UNFUSED",                # LD weights: pair table, then hr2 table (the two steps a sharded panel takes)
     "GARLIC_LD_PAIR_NO_MFMA",           # ... pair counts without the matrix cores
     "GARLIC_LD_PAIR_TILED",

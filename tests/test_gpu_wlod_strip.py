@@ -51,6 +51,35 @@ def test_strip_kernel_against_oracle_and_tile_kernel(gpu_ctx, W, groups, monkeyp
             assert ol.bits_equal(np.ascontiguousarray(out[c]), want[c]), ("tile kernel", c)
 
 
+@pytest.mark.parametrize("W", [40, 100, 113])
+def test_both_narrow_strip_kernels_agree_with_the_oracle(gpu_ctx, W, monkeypatch):
+    """W <= 113, scores into 16-B aligned rows: the 80-VGPR kernel (three workgroups per CU, write-out inside the generated
+    loop) by default, the 96-VGPR one under GARLIC_WLOD_STRIP_TWO_PER_CU -- odd and even chromosome lengths (the last
+    window alone in its 16-B piece), a last block of 2 individuals, windows without a score between scored ones"""
+    rng = np.random.default_rng(5200 + W)
+    mg = 30000
+    sizes = [2 * W + 17, 2 * W + 18, 1203, W]
+    nind = 130
+    chroms, gpos, lds, err = _panel(rng, sizes, nind, W, mg)
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms],
+                      gpos=np.concatenate(gpos))
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        panel.set_ld(W, np.concatenate(lds, axis=0))
+        panel.set_gl(np.concatenate(err, axis=0))
+        want = [ol.oracle_calc_wlod(g, f, p, gpos[c], lds[c], cs, ce, W, 0.001, mg, 1e-9, 7, gl=err[c])
+                for c, (g, f, p, cs, ce) in enumerate(chroms)]
+        for two in (False, True):
+            if two:
+                monkeypatch.setenv("GARLIC_WLOD_STRIP_TWO_PER_CU", "1")
+            for pa in (32, 2):
+                out = panel.wlod_windows(W, 0.001, mg, 7, 1e-9, pitch_align=pa, use_gl=True)
+                for c in range(len(sizes)):
+                    assert ol.bits_equal(np.ascontiguousarray(out[c]), want[c]), (two, pa, c)
+        assert panel.stats()["n_stall_reruns"] == 0
+
+
 def test_strip_kernel_repeated_calls_and_plan_reuse(gpu_ctx, monkeypatch):
     """the same call twice (plan reused), then with the strip form switched off and on again (plan rebuilt)"""
     rng = np.random.default_rng(77)

@@ -187,8 +187,9 @@ GLS_MASK = GLS_RING * 512 - 1
 
 
 class StripGen(Gen):
-    def __init__(self):
+    def __init__(self, fast=False):
         super().__init__(gl=False, nb=2)
+        self.fast = fast      # the 80-VGPR form: registers by number (FAST_REGS), one product register, write-out inside
 
     def read_next(self, dst, dstb, uid):
         e = self.e
@@ -209,8 +210,9 @@ class StripGen(Gen):
         e(f"s_branch WS_POLL_{uid}_%=")
         e(f"WS_OK_{uid}_%=:")
         e("v_add_u32_e32 %[vt], %[rd], %[lane8b]")
-        e(f"ds_read_b64 %[{dst}], %[vt]")
-        e(f"ds_read_b64 %[{dstb}], %[vt] offset:{GLS_RING * 512}")
+        if "nolds" not in ABL:
+            e(f"ds_read_b64 %[{dst}], %[vt]")
+            e(f"ds_read_b64 %[{dstb}], %[vt] offset:{GLS_RING * 512}")
         e("s_add_u32 %[rd], %[rd], 512")
         e(f"s_and_b32 %[rd], %[rd], {GLS_MASK}")
         e("s_add_u32 %[rown], %[rown], 1")
@@ -223,15 +225,16 @@ class StripGen(Gen):
         if prefetch:
             e(f"s_add_u32 s{S_DP}, s{S_DP}, %[stride]")
             e(f"s_addc_u32 s{S_DP + 1}, s{S_DP + 1}, 0")
-            e(f"s_load_dwordx16 {tup(nxt, 0)}, s[{S_DP}:{S_DP + 1}], 0x0")
-            e(f"s_load_dwordx16 {tup(nxt, 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
+            if "nosload" not in ABL:
+                e(f"s_load_dwordx16 {tup(nxt, 0)}, s[{S_DP}:{S_DP + 1}], 0x0")
+                e(f"s_load_dwordx16 {tup(nxt, 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
             if parity == 0:
                 e("s_min_u32 %[stmp], %[rown], %[nextrow]")      # the wave's next group may start below this one's end
                 e("v_add_u32_e32 %[vt], %[needoff], %[lane8b]")  # the lane's copy of this wave's row of need[]
                 e("v_mov_b32_e32 %[vtmp], %[stmp]")
                 e("ds_write_b32 %[vt], %[vtmp]")
             self.read_next(scn, "scnb" if scn == "scn" else "scb", uid)
-            if GLS_PFW and pf:
+            if GLS_PFW and pf and not self.fast:
                 e(f"s_cbranch_vccz WL_NOPF_{uid}_%=")
                 for off in (0, 64, 124)[:PFW_LOADS]:
                     e(f"global_load_dword %[vd], %[vz], s[{S_DP}:{S_DP + 1}] offset:{off}")
@@ -242,7 +245,17 @@ class StripGen(Gen):
                 e("s_waitcnt vmcnt(32)")
                 e(f"WL_NOPF_{uid}_%=:")
         scb = "scb" if sc == "sc" else "scnb"
+        if "halffp" in ABL:
+            windows = list(windows)[::2]
         for r in windows:
+            if self.fast:
+                # one product register: a dependent FP64 pair issues as fast as an independent one on gfx950
+                # (profiles/r04_chain_body_ubench.txt: 4.3 cycles per v_add_f64 either way)
+                e(f"v_mul_f64 %[t0], %[{sc}], {weight(cur, r)}")
+                e(f"v_add_f64 %[a{r}], %[a{r}], %[t0]")
+                e(f"v_mul_f64 %[t0], %[{scb}], {weight(cur, r)}")
+                e(f"v_add_f64 %[b{r}], %[b{r}], %[t0]")
+                continue
             e(f"v_mul_f64 %[t0], %[{sc}], {weight(cur, r)}")
             e(f"v_mul_f64 %[t1], %[{scb}], {weight(cur, r)}")
             e(f"v_add_f64 %[a{r}], %[a{r}], %[t0]")
@@ -251,14 +264,108 @@ class StripGen(Gen):
             e("s_waitcnt lgkmcnt(0)")
 
 
-def build_strip():
-    g = StripGen()
+# ---- the 80-VGPR strip form (three workgroups per CU): every vector register by number, nothing comes back in registers.
+# hipcc cannot keep 64 accumulators + the loop's temporaries as asm operands at 80 VGPRs (it spills every accumulator right
+# behind the block, whatever the write-out looks like), so the block owns v4 .. v78 outright (clobbers), computes its lane
+# addresses itself and ends with the write-out: per block, quarter by quarter, 16 lanes put their 16 sums into the wave's
+# own patch in LDS (16 rows of WQ_PITCH bytes: no lock), then all 64 lanes take 16 B each -- 8 lanes one individual's
+# 128 B -- and store them non-temporally.  v0 .. v3 and v79 stay with the compiler.
+FAST_V_A, FAST_V_B = 4, 36
+FAST_REGS = {"sc": "v[68:69]", "scb": "v[70:71]", "scn": "v[72:73]", "scnb": "v[74:75]", "t0": "v[76:77]",
+             "vt": "v76", "vtmp": "v77",          # addresses / flag values of a step: dead before its first product
+             "lane8b": "v78"}
+for _r in range(R):
+    FAST_REGS[f"a{_r}"] = f"v[{FAST_V_A + 2 * _r}:{FAST_V_A + 2 * _r + 1}]"
+    FAST_REGS[f"b{_r}"] = f"v[{FAST_V_B + 2 * _r}:{FAST_V_B + 2 * _r + 1}]"
+FAST_CLOBBER_V = list(range(4, 79))
+WQ_PITCH = 144                 # bytes per patch row: 16 doubles + 16 B (wlod_strip_kernel.hpp: WT_PITCH * 8)
+MISSING_HI = 0xC0C38780        # -9999.0
+
+
+def fast_epilogue(e):
+    Q, PW, PR, DST, ROWS, COLS, T = "v[68:71]", "v72", "v73", "v[74:75]", "v76", "v77", "v78"
+    S_EXEC, S_C2, S_C1, S_ROW8, S_M2, S_M1 = "s[36:37]", "s[38:39]", "s[40:41]", "s[42:43]", "s[44:45]", "s[46:47]"
+    # the next row this wave reads (its next group's first), published before anything else
+    e("v_add_u32_e32 v76, %[needoff], v78")
+    e("v_mov_b32_e32 v77, %[nextrow]")
+    e("ds_write_b32 v76, v77")
+    e(f"s_mov_b64 {S_EXEC}, exec")
+    # MISSING where no scored window starts
+    e("s_cmp_eq_u32 %[gm], 0xffff")
+    e("s_cbranch_scc1 WF_SCORED_%=")
+    for r in range(R):
+        e(f"s_bitcmp1_b32 %[gm], {r}")
+        e(f"s_cbranch_scc1 WF_KEEP{r}_%=")
+        for base in (FAST_V_A, FAST_V_B):
+            e(f"v_mov_b32_e32 v{base + 2 * r}, 0")
+            e(f"v_mov_b32_e32 v{base + 2 * r + 1}, 0x{MISSING_HI:x}")
+        e(f"WF_KEEP{r}_%=:")
+    e("WF_SCORED_%=:")
+    # lane addresses: patch row to write (lane & 15), patch piece to read (row lane >> 3, columns 2 (lane & 7) ..),
+    # the piece's place in the score matrix, how many rows / columns exist from there
+    e("v_mbcnt_lo_u32_b32 v77, -1, 0")
+    e("v_mbcnt_hi_u32_b32 v77, -1, v77")
+    e(f"v_lshrrev_b32_e32 {T}, 3, v77")                       # lane >> 3 (the ring address is dead)
+    e("v_and_b32_e32 v76, 15, v77")
+    e(f"v_mul_u32_u24_e32 {PW}, {WQ_PITCH}, v76")
+    e(f"v_add_u32_e32 {PW}, %[wpatch], {PW}")
+    e("v_and_b32_e32 v77, 7, v77")                            # lane & 7
+    e(f"v_mul_u32_u24_e32 {PR}, {WQ_PITCH}, {T}")
+    e(f"v_lshl_add_u32 {PR}, v77, 4, {PR}")
+    e(f"v_add_u32_e32 {PR}, %[wpatch], {PR}")
+    e(f"v_mad_u64_u32 {DST}, vcc, {T}, %[pitchb], 0")
+    e("v_lshlrev_b32_e32 v76, 4, v77")
+    e("v_add_co_u32_e32 v74, vcc, v74, v76")
+    e("v_addc_co_u32_e32 v75, vcc, 0, v75, vcc")
+    e(f"v_lshl_add_u64 {DST}, {DST}, 0, %[dst]")
+    e(f"v_sub_u32_e32 {ROWS}, %[rows], {T}")                  # row 8 q + (lane >> 3) of the block exists iff 8 q < this
+    e("v_lshlrev_b32_e32 v77, 1, v77")
+    e(f"v_sub_u32_e32 {COLS}, %[cols], v77")                  # >= 2: both doubles of the piece exist; 1: the first
+    e(f"v_cmp_lt_i32_e64 {S_C2}, 1, {COLS}")
+    e(f"v_cmp_eq_u32_e64 {S_C1}, 1, {COLS}")
+    e("s_lshl_b32 s42, %[pitchb], 3")                         # eight rows further down, bytes
+    e("s_lshr_b32 s43, %[pitchb], 29")
+    for blk, base in enumerate((FAST_V_A, FAST_V_B)):
+        if blk == 1:
+            e(f"v_subrev_u32_e32 {ROWS}, 64, {ROWS}")         # the second block's rows
+        for h in range(4):
+            lo, hi = ((0xffff << (16 * h)) & 0xffffffff, 0) if h < 2 else (0, (0xffff << (16 * (h - 2))) & 0xffffffff)
+            e(f"s_mov_b32 exec_lo, 0x{lo:x}")
+            e(f"s_mov_b32 exec_hi, 0x{hi:x}")
+            for r in range(0, R, 2):
+                e(f"ds_write2_b64 {PW}, v[{base + 2 * r}:{base + 2 * r + 1}], v[{base + 2 * r + 2}:{base + 2 * r + 3}] "
+                  f"offset0:{r} offset1:{r + 1}")
+            e(f"s_mov_b64 exec, {S_EXEC}")
+            for j in range(2):
+                k = 16 * h + 8 * j
+                e(f"ds_read_b128 {Q}, {PR}" + (f" offset:{8 * WQ_PITCH}" if j else ""))
+                e(f"v_cmp_lt_i32_e32 vcc, {k}, {ROWS}")
+                e(f"s_and_b64 {S_M2}, vcc, {S_C2}")
+                e(f"s_and_b64 {S_M1}, vcc, {S_C1}")
+                e("s_waitcnt lgkmcnt(0)")
+                e(f"s_mov_b64 exec, {S_M2}")
+                e(f"global_store_dwordx4 {DST}, {Q}, off nt")
+                e(f"s_cmp_lg_u64 {S_M1}, 0")
+                e(f"s_cbranch_scc0 WF_NOODD{blk}_{h}_{j}_%=")
+                e(f"s_mov_b64 exec, {S_M1}")                  # the chromosome's last window has an even index
+                e(f"global_store_dwordx2 {DST}, v[68:69], off")
+                e(f"WF_NOODD{blk}_{h}_{j}_%=:")
+                e(f"s_mov_b64 exec, {S_EXEC}")
+                e(f"v_lshl_add_u64 {DST}, {DST}, 0, {S_ROW8}")
+
+
+def build_strip(fast=False):
+    g = StripGen(fast)
     e = g.e
+    if fast:
+        e("v_mbcnt_lo_u32_b32 v78, -1, 0")
+        e("v_mbcnt_hi_u32_b32 v78, -1, v78")
+        e("v_lshl_add_u32 v78, v78, 3, %[ringlds]")         # the lane's place in a ring row
     e(f"s_mov_b64 s[{S_DP}:{S_DP + 1}], %[dp]")
     e(f"s_load_dwordx16 {tup('A', 0)}, s[{S_DP}:{S_DP + 1}], 0x0")
     e(f"s_load_dwordx16 {tup('A', 1)}, s[{S_DP}:{S_DP + 1}], 0x40")
     g.read_next("sc", "scb", 0)                       # row 0 of the group
-    if GLS_PFW:
+    if GLS_PFW and not fast:
         e("s_cmp_lg_u32 %[pfon], 0")
         e("s_cselect_b64 vcc, -1, 0")
     for r in range(R):
@@ -285,6 +392,16 @@ def build_strip():
         if first == 1:
             e("s_branch WL_DONE_%=")
     e("WL_DONE_%=:")
+    if fast:
+        if "noepi" in ABL:
+            e("v_add_u32_e32 v76, %[needoff], v78")
+            e("v_mov_b32_e32 v77, %[nextrow]")
+            e("ds_write_b32 v76, v77")
+            e("s_waitcnt lgkmcnt(0)")
+        else:
+            fast_epilogue(e)
+        import re
+        return [re.sub(r"%\[(\w+)\]", lambda m: FAST_REGS.get(m.group(1), m.group(0)), ln) for ln in g.out]
     if GLS_PFW:
         e("s_waitcnt vmcnt(0)")                        # the touches' results (never read) have landed
     return g.out
@@ -387,8 +504,9 @@ def main():
         f.write(f"#define GARLIC_WLOD_PFW {PFW}\n#define GARLIC_WLOD_PFW_MAX_W {PFW_MAX_W}\n")
         f.write(f"#define GARLIC_WLOD_GLS_RING_ROWS {GLS_RING}\n#define GARLIC_WLOD_GLS_PFW {GLS_PFW}\n")
         for name, gl, nb in (("GARLIC_WLOD_LOOP_ASM", False, 1), ("GARLIC_WLOD_GL_LOOP_ASM", True, 1),
-                             ("GARLIC_WLOD2_LOOP_ASM", False, 2), ("GARLIC_WLOD_GLS_LOOP_ASM", None, 2)):
-            lines = build_strip() if gl is None else build(gl, nb)
+                             ("GARLIC_WLOD2_LOOP_ASM", False, 2), ("GARLIC_WLOD_GLS_LOOP_ASM", None, 2),
+                             ("GARLIC_WLOD_GLF_LOOP_ASM", "fast", 2)):
+            lines = build_strip(gl == "fast") if gl in (None, "fast") else build(gl, nb)
             total += sum(1 for x in lines if not x.endswith(":"))
             f.write(f"#define {name} \\\n")
             for ln in lines:
@@ -397,7 +515,11 @@ def main():
         regs = ['"s%d"' % r for r in range(S_DP, 100)] + ['"scc"', '"vcc"']
         f.write("#define GARLIC_WLOD_LOOP_CLOBBERS \\\n    ")
         f.write(", \\\n    ".join(", ".join(regs[i:i + 12]) for i in range(0, len(regs), 12)) + "\n")
-    print(f"wrote {os.path.normpath(path)}: {total} instructions in four variants")
+        vregs = ['"v%d"' % r for r in FAST_CLOBBER_V]
+        f.write("#define GARLIC_WLOD_GLF_CLOBBERS GARLIC_WLOD_LOOP_CLOBBERS, \\\n    ")
+        f.write(", \\\n    ".join(", ".join(vregs[i:i + 12]) for i in range(0, len(vregs), 12)) + "\n")
+        f.write(f"#define GARLIC_WLOD_GLF_PATCH_PITCH_BYTES {WQ_PITCH}\n")
+    print(f"wrote {os.path.normpath(path)}: {total} instructions in five variants")
 
 
 if __name__ == "__main__":
