@@ -3059,7 +3059,12 @@ static int segments_from_bits(garlic_panel *p, const uint32_t *d_bits, const Chr
     DevBuf<uint32_t> d_brk;
     DevBuf<int32_t> d_wbase;
     DevBuf<unsigned long long> d_count;
-    auto done = [&](int code) { d_mask.release(); d_brk.release(); d_wbase.release(); d_segs.release(); d_count.release(); return code; };
+    DevBuf<int32_t> d_w0, d_wedge_chr;             // chromosomes whose first SNP is at position 0 (roh_segments_kernel.hpp)
+    std::vector<int32_t> wedge_chr;
+    for (int c = 0; c < p->nchr; c++)
+        if (p->chr_nloci[c] > 0 && p->pos[(size_t)p->chr_off[c]] == 0) wedge_chr.push_back(c);
+    auto done = [&](int code) { d_mask.release(); d_brk.release(); d_wbase.release(); d_segs.release(); d_count.release();
+                                d_w0.release(); d_wedge_chr.release(); return code; };
     int rc;
     const int64_t cap = std::max<int64_t>(sink.cap, 0);
     if ((rc = d_mask.reserve(ctx, (size_t)std::max<int64_t>(bit_words, 1))) || (rc = d_brk.reserve((size_t)std::max<int64_t>(total_words, 1))) ||
@@ -3077,8 +3082,21 @@ static int segments_from_bits(garlic_panel *p, const uint32_t *d_bits, const Chr
                                p->d_chr_off.p, d_wbase.p, p->nchr, d_brk.p);
         const dim3 grid((unsigned)((total_words + 255) / 256), (unsigned)((p->nind + ROH_ROWS - 1) / ROH_ROWS));
         hipLaunchKernelGGL(roh_mask_from_bits_kernel, grid, dim3(256), 0, s, d_bits, d_bchrs, d_wbase.p, p->nchr, p->nind, W, thr, d_mask.p);
+        const int32_t *a_w0 = nullptr;
+        if (!wedge_chr.empty()) {
+            const size_t n_w0 = nchr * (size_t)p->nind;
+            if ((rc = d_w0.reserve(n_w0)) || (rc = d_wedge_chr.reserve(wedge_chr.size()))) return done(rc);
+            e = hipMemsetAsync(d_w0.p, 0xff, sizeof(int32_t) * n_w0, s);            // -1: an ordinary row
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(d_wedge_chr.p, wedge_chr.data(), sizeof(int32_t) * wedge_chr.size(), hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "roh segments: %s", hipGetErrorString(e)));
+            const int n_threads = (int)wedge_chr.size() * p->nind;
+            hipLaunchKernelGGL(roh_wedge_kernel, dim3((unsigned)((n_threads + 63) / 64)), dim3(64), 0, s, d_mask.p, d_bchrs, d_brk.p, d_wbase.p,
+                               d_wedge_chr.p, (int)wedge_chr.size(), p->nind, T, d_w0.p, d_segs.p, (long long)cap, d_count.p);
+            a_w0 = d_w0.p;
+        }
         hipLaunchKernelGGL(roh_segments_from_mask_kernel, grid, dim3(256), 0, s, d_mask.p, d_bchrs, d_brk.p, d_wbase.p, p->nchr, p->nind, T,
-                           d_segs.p, (long long)cap, d_count.p);
+                           d_segs.p, (long long)cap, d_count.p, a_w0);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&found, d_count.p, sizeof found, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -3392,11 +3410,12 @@ int garlic_roh_segments(garlic_panel *p, int32_t winsize, double error, int32_t 
     if (p->nind > 65535) return fail(GARLIC_ERR_INVALID, "coverage: at most 65535 individuals per call");
     if (!(overlap_frac == overlap_frac)) return fail(GARLIC_ERR_INVALID, "overlap_frac is not a number");
     *n_segments = 0;
-    // (the reference tells "a segment is open" by its first position being > 0: src/garlic-roh.cpp:493, 514)
+    // (the reference tells "a segment is open" by its first position being > 0 and "none" by < 0, src/garlic-roh.cpp:456, 493,
+    // 514: a chromosome that starts at 0 takes the device's restatement of what that does; a negative position has no meaning)
     if (p->have_map)
         for (int c = 0; c < p->nchr; c++)
-            if (p->chr_nloci[c] > 0 && p->pos[(size_t)p->chr_off[c]] <= 0)
-                return fail(GARLIC_ERR_INVALID, "chromosome %d starts at position %d: ROH segments need positions >= 1", c,
+            if (p->chr_nloci[c] > 0 && p->pos[(size_t)p->chr_off[c]] < 0)
+                return fail(GARLIC_ERR_INVALID, "chromosome %d starts at position %d: ROH segments need positions >= 0", c,
                             (int)p->pos[(size_t)p->chr_off[c]]);
     CovSink sink;
     sink.segments = true;

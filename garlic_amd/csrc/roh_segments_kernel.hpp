@@ -9,7 +9,12 @@
 //               kept when their SNP count reaches the same threshold -- except a stretch that BEGINS at the
 //               chromosome's last SNP, which the machine opens and never closes (:456-468 take the first or second
 //               branch there, the closing fourth one is an else-if behind them).
-// (Positions of 0 would wedge the reference's "winStart > 0" tests; the host refuses a chromosome that starts at 0.)
+// A chromosome whose first SNP sits at position 0 (a 0-based map) is the one case where the machine's tests on winStart --
+// a POSITION, "< 0" for no segment open, "> 0" for one open (:456, :493, :514) -- disagree: a stretch opened at SNP 0 is
+// neither.  It cannot be closed by an uncovered SNP or by the chromosome's end, nothing can be opened while it lasts, and
+// it ends at the first covered SNP behind a break (second branch), reported as SNPs 0 .. that SNP - 1 whatever lies
+// between.  roh_wedge_kernel finds that SNP per individual (rows whose SNP 0 is in ROH), reports the one segment and
+// tells roh_segments_from_mask_kernel to drop everything in front of it.  Negative positions are refused by the host.
 // So nothing 2-byte-per-SNP has to exist: roh_mask_from_bits_kernel turns the window bits into r (the sliding count of
 // cov_counts.hpp in registers, compared, 32 SNPs per thread = one dword), roh_segments_from_mask_kernel finds every
 // segment's last SNP, walks back to its first and appends (individual, chromosome, first, last) to a list: a few MB
@@ -108,10 +113,41 @@ __device__ __forceinline__ uint32_t roh_start_bits(const uint32_t *mrow, const u
     return R & (~((R << 1) | prev) | brk[t]);
 }
 
+// chromosomes that start at position 0 (wedge_chr[0 .. n_wedge)): thread per (individual, such chromosome).
+// w0[chr * nind + row] = -1: SNP 0 not in ROH, the row is an ordinary one; otherwise the first covered SNP behind a break
+// (INT_MAX: none -- the row reports nothing on this chromosome)
+constexpr int ROH_NO_BREAK = 0x7fffffff;
+__global__ void __launch_bounds__(64)
+roh_wedge_kernel(const uint32_t *__restrict__ mask, const ChrDev *__restrict__ bchrs, const uint32_t *__restrict__ brk,
+                 const int32_t *__restrict__ word_base, const int32_t *__restrict__ wedge_chr, int n_wedge, int nind, double T,
+                 int32_t *__restrict__ w0, garlic_roh_segment *__restrict__ segs, long long cap, unsigned long long *__restrict__ count)
+{
+    const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (g >= n_wedge * nind) return;
+    const int chr = wedge_chr[g / nind], row = g % nind;
+    const ChrDev bc = bchrs[chr];
+    const uint32_t *mrow = mask + bc.out_base + (int64_t)row * bc.out_pitch, *b = brk + word_base[chr];
+    int first = -1;
+    if (bc.nloci > 0 && (mrow[0] & 1u)) {
+        first = ROH_NO_BREAK;
+        const int nwords = (bc.nloci + 31) >> 5;
+        for (int t = 0; t < nwords; t++) {
+            const uint32_t hit = mrow[t] & b[t];        // (bit 0 of word 0 is never a break)
+            if (hit) { first = 32 * t + __builtin_ctz(hit); break; }
+        }
+        if (first != ROH_NO_BREAK && (double)first >= T) {      // SNPs 0 .. first - 1: first of them
+            const unsigned long long slot = atomicAdd(count, 1ull);
+            if ((long long)slot < cap) segs[slot] = garlic_roh_segment{row, chr, 0, first - 1};
+        }
+    }
+    w0[(int64_t)chr * nind + row] = first;
+}
+
 __global__ void __launch_bounds__(256)
 roh_segments_from_mask_kernel(const uint32_t *__restrict__ mask, const ChrDev *__restrict__ bchrs,
                               const uint32_t *__restrict__ brk, const int32_t *__restrict__ word_base, int nchr, int nind,
-                              double T, garlic_roh_segment *__restrict__ segs, long long cap, unsigned long long *__restrict__ count)
+                              double T, garlic_roh_segment *__restrict__ segs, long long cap, unsigned long long *__restrict__ count,
+                              const int32_t *__restrict__ w0)
 {
     const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (g >= word_base[nchr]) return;
@@ -125,6 +161,7 @@ roh_segments_from_mask_kernel(const uint32_t *__restrict__ mask, const ChrDev *_
         const uint32_t *mrow = mask + bc.out_base + (int64_t)row * bc.out_pitch;
         const uint32_t R = mrow[t];
         if (!R) continue;
+        const int from = w0 ? w0[(int64_t)chr * nind + row] : -1;     // (w0: NULL unless a chromosome starts at position 0)
         const uint32_t next = t + 1 < nwords ? (mrow[t + 1] & 1u) : 0u;
         uint32_t end = R & (~((R >> 1) | (next << 31)) | ((bt >> 1) | (bnext << 31)));
         if (!end) continue;
@@ -141,7 +178,7 @@ roh_segments_from_mask_kernel(const uint32_t *__restrict__ mask, const ChrDev *_
             }
             const int s = 32 * x + 31 - __builtin_clz(s_bits), stop = 32 * t + e;
             const int len = stop - s + 1;
-            if ((double)len >= T && s != bc.nloci - 1) {
+            if ((double)len >= T && s != bc.nloci - 1 && s >= from) {     // (a break cuts at `from`: no segment straddles it)
                 const unsigned long long slot = atomicAdd(count, 1ull);
                 if ((long long)slot < cap) segs[slot] = garlic_roh_segment{row, chr, s, stop};
             }

@@ -318,7 +318,10 @@ int garlic_roh_coverage_fused(garlic_panel *panel, int32_t winsize, double error
  *   Ordered by individual, chromosome, first SNP -- the order the reference appends them in.
  * *n_segments is the number found; when it exceeds `capacity` nothing usable is in `segments` (call again with room;
  * capacity 0 / segments NULL just counts).  A few MB for a 10M-SNP x 1250-individual shard, against 25 GB of counts.
- * Positions must be >= 1 (the reference's "winStart > 0" means "a segment is open"). */
+ * Positions must be >= 0.  The reference tells "a segment is open" by its first POSITION being > 0 and "none" by
+ * < 0 (:456, :493, :514): on a 0-based map a stretch opened at a chromosome's SNP 0 is neither -- nothing closes it but
+ * a covered SNP behind a break, and it is reported from SNP 0 to the SNP in front of that one whatever lies between.
+ * Reproduced as is (pinned against the real assembleROHWindows). */
 typedef struct garlic_roh_segment {
     int32_t ind, chr, start, stop;
 } garlic_roh_segment;

@@ -586,13 +586,40 @@ def test_roh_segments_and_counts_over_many_small_chromosomes(gpu_ctx):
         assert len(want) > 50
 
 
-def test_roh_segments_refuses_a_chromosome_that_starts_at_position_zero(gpu_ctx):
-    rng = np.random.default_rng(3)
-    g, f, p, cs, ce = ol.random_panel(rng, 300, 5, max_gap=200000)
-    p = p - p[0]
-    with abi.Panel(gpu_ctx, [300], 5) as panel:
-        panel.set_map(p, [cs], [ce])
+@pytest.mark.parametrize("W", [4, 30])
+def test_roh_segments_of_chromosomes_that_start_at_position_zero(gpu_ctx, W):
+    """0-based maps: a stretch opened at SNP 0 is neither open nor closed to the reference's tests on its first position
+    (garlic-roh.cpp:456, 493, 514; pinned against the real assembleROHWindows in tests/test_oracle_vs_ref.py): it ends at
+    the first covered SNP behind a break and everything in front of that is one segment or none.  Chromosomes that start
+    at 0 beside ones that do not, with breaks early, late and not at all; a negative position is refused"""
+    rng = np.random.default_rng(640 + W)
+    mg, nind = 200000, 70
+    sizes = [700, 40, 1, 3000, 33, 900]
+    chroms = []
+    for k, n in enumerate(sizes):
+        g, f, p, cs, ce = ol.random_panel(rng, n, nind, max_gap=mg, gaps=(0, 1, 0, 4, 2, 3)[k], centro=(k % 2 == 0))
+        if k != 5:
+            shift = int(p[0])
+            p = (p - shift).astype(np.int32)
+            cs, ce = (cs - shift, ce - shift) if (cs or ce) else (0, 0)
+        chroms.append((g, f, p, cs, ce))
+    with abi.Panel(gpu_ctx, sizes, nind) as panel:
+        panel.set_map(np.concatenate([c[2] for c in chroms]), [c[3] for c in chroms], [c[4] for c in chroms])
+        panel.set_freq(np.concatenate([c[1] for c in chroms]))
+        panel.set_genotypes(np.concatenate([c[0] for c in chroms], axis=0))
+        scores = [ol.oracle_calc_lod(g, f, p, cs, ce, W, 0.001, mg) for (g, f, p, cs, ce) in chroms]
+        from_zero = 0
+        for cutoff in (-2.0, 0.0, -20000.0):
+            for frac in (1e-9, 0.25, 1.0):          # (SNP 0 lies in one window: it is "in ROH" only at a threshold of one SNP)
+                want = _oracle_segments(chroms, scores, W, cutoff, mg, frac)
+                got = panel.roh_segments(W, 0.001, mg, cutoff, frac)
+                assert [tuple(int(v) for v in r) for r in got] == want, (W, cutoff, frac, len(got), len(want))
+                from_zero += sum(1 for r in want if r[2] == 0 and r[1] != 5)
+        assert from_zero > 20
+    g, f, p, cs, ce = chroms[0]
+    with abi.Panel(gpu_ctx, [sizes[0]], nind) as panel:
+        panel.set_map((p - 1).astype(np.int32), [cs], [ce])
         panel.set_freq(f)
         panel.set_genotypes(g)
-        with pytest.raises(abi.GarlicError, match="positions >= 1"):
-            panel.roh_segments(20, 0.001, 200000, 0.0, 0.25)
+        with pytest.raises(abi.GarlicError, match="positions >= 0"):
+            panel.roh_segments(20, 0.001, mg, 0.0, 0.25)

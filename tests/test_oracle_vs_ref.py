@@ -197,6 +197,37 @@ def test_roh_segments_at_the_edges_of_the_state_machine():
     assert checked > 100
 
 
+def test_roh_segments_of_a_chromosome_that_starts_at_position_zero():
+    """a 0-based map: the reference tells 'a segment is open' by its first POSITION being > 0 and 'none' by < 0
+    (garlic-roh.cpp:456, 493, 514), so a stretch opened at SNP 0 is neither -- it closes only at a covered SNP behind a
+    break and is reported from SNP 0 whatever lies between.  The oracle's walk against the real assembleROHWindows there:
+    SNP 0 covered or not, with and without a covered break further on"""
+    rng = np.random.default_rng(11)
+    checked = wedged = 0
+    for trial in range(60):
+        nloci, nind, W = int(rng.integers(1, 90)), int(rng.integers(1, 4)), int(rng.integers(2, 9))
+        pos = np.cumsum(rng.integers(1, 3000, size=nloci)).astype(np.int32)
+        pos -= pos[0]
+        mg = 5000
+        if trial % 3:
+            for k in rng.integers(1, max(2, nloci), size=2):
+                if 0 < k < nloci:
+                    pos[k:] += mg + 1
+        cS, cE = (int(pos[nloci // 2]) + 1, int(pos[nloci // 2]) + 2) if trial % 2 else (0, 0)
+        win = np.where(rng.random((nind, nloci)) < 0.6, 5.0, -5.0)
+        if trial % 4 == 0:
+            win[:, 0] = 5.0
+        win[:, max(0, nloci - W + 1):] = ol.MISSING
+        cov = ol.oracle_roh_coverage(win, W, 0.0)
+        for frac in (1e-9, 0.3, 1.0):
+            ref = ol.ref_assemble_roh(win, pos, cS, cE, 0.0, W, mg, frac)
+            segs = ol.oracle_roh_segments(cov, pos, cS, cE, W, mg, frac)
+            assert [(i, float(pos[a]), float(pos[b])) for i, a, b in segs] == ref, (trial, nloci, W, frac)
+            checked += len(ref)
+            wedged += sum(1 for i, a, b in segs if a == 0)
+    assert checked > 100 and wedged > 10
+
+
 def test_genetic_map_interpolation_of_the_host_adapter(tmp_path):
     """garlic_amd/host's loadMapScaffold + interpolateGeneticmap (what --weighted feeds wLOD with) against
     the reference's own functions (garlic-data.cpp:702-757 through oracle/_ref): every genetic position
