@@ -352,7 +352,7 @@ __device__ __forceinline__ void lod_feed_body(const FeedArgs &p)
     }
 }
 
-__global__ void __launch_bounds__(FEED_G * WAVE, 3)
+__global__ void __launch_bounds__(FEED_G * WAVE, GARLIC_FEED_WG_PER_CU)
 lod_feed_kernel(FeedArgs p)
 {
     lod_feed_body<false>(p);
@@ -360,7 +360,7 @@ lod_feed_kernel(FeedArgs p)
 
 // the same chains leaving one bit per window and individual (score >= cutoff) instead of sampled scores: the first
 // half of the coverage counts without a score matrix (coverage_kernel.hpp)
-__global__ void __launch_bounds__(FEED_G * WAVE, 3)
+__global__ void __launch_bounds__(FEED_G * WAVE, GARLIC_FEED_WG_PER_CU)
 lod_bits_kernel(FeedArgs p)
 {
     lod_feed_body<true>(p);

@@ -18,7 +18,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <mutex>
+#include <queue>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -324,6 +326,7 @@ struct garlic_panel {
         bool wlod_fast = false, wlod_strip = false, feed_kernel = false;
         int32_t thin_step = 0;
         size_t n_feed_items = 0;
+        int feed_per_cu = 1;      // persistent workgroups per CU the feed kernel of this plan is launched with (feed_grid)
         uint64_t blocks_hash = 0;                  // 0: every 64-individual block; else a hash of the block subset
         int32_t n_tiles = 0, n_segs = 0, n_strips = 0;
         int64_t n_runs = 0, n_valid = 0;
@@ -670,13 +673,70 @@ void build_feed_items(const std::vector<Run> &runs, const std::vector<int> &orde
     }
 }
 
-// persistent workgroups of lod_feed_kernel: as many as stay resident (four per CU)
-int feed_grid(garlic_ctx *ctx, size_t n_items, int *grid)
+// How many persistent workgroups of lod_feed_kernel per CU.  Not "as many as stay resident": the items are whole runs (a
+// chain cannot be cut), a workgroup's pace depends on how many share its CU (measured, 5M x 5k and 2M x 10k: 52 cycles per
+// window and wave alone, 80 with one neighbour, 109 with two -- a SIMD gives two chains 1.3 x and three 1.43 x the rate of
+// one), and with about as many items as slots the last slots' long items finish alone on an idle chip.  C3 (880 items): three
+// per CU 30.8 ms for the four sizes, two per CU 25.6; 2M x 10k (1760 shorter items): three 18.5, two 20.0.  So the launch
+// is simulated -- the queue in its order, every CU sharing its pace among the workgroups it holds -- for each count
+// that fits, and the shortest one taken.
+static double feed_makespan(const std::vector<int32_t> &len, int n_cu, int per_cu)
+{
+    static const double pace[5] = {0.0, 52.0, 79.6, 109.0, 150.0};       // cycles per window and wave, k workgroups on the CU
+    struct Cu { double t; int k; double rem[4]; };
+    std::vector<Cu> cus((size_t)n_cu, Cu{0.0, 0, {0, 0, 0, 0}});
+    size_t q = 0;
+    for (int s = 0; s < per_cu; s++)
+        for (int c = 0; c < n_cu && q < len.size(); c++) cus[(size_t)c].rem[cus[(size_t)c].k++] = (double)len[q++];
+    typedef std::pair<double, int> Ev;     // (time of the CU's next completion, CU)
+    std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> heap;
+    auto next_of = [&](const Cu &u) {
+        double m = u.rem[0];
+        for (int i = 1; i < u.k; i++) m = std::min(m, u.rem[i]);
+        return u.t + m * pace[u.k];
+    };
+    for (int c = 0; c < n_cu; c++)
+        if (cus[(size_t)c].k) heap.push(Ev(next_of(cus[(size_t)c]), c));
+    double end = 0.0;
+    while (!heap.empty()) {
+        const Ev ev = heap.top();
+        heap.pop();
+        Cu &u = cus[(size_t)ev.second];
+        const double adv = (ev.first - u.t) / pace[u.k];
+        u.t = ev.first;
+        end = std::max(end, u.t);
+        int k = 0;
+        for (int i = 0; i < u.k; i++) {
+            const double r = u.rem[i] - adv;
+            if (r > 0.5) u.rem[k++] = r;
+            else if (q < len.size()) u.rem[k++] = (double)len[q++];     // the workgroup pulls the next item
+        }
+        u.k = k;
+        if (k) heap.push(Ev(next_of(u), ev.second));
+    }
+    return end;
+}
+
+int feed_grid(garlic_ctx *ctx, const std::vector<FeedItem> &items, int *grid, int *per_cu_out)
 {
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)lod_feed_kernel, FEED_G * WAVE, 0));
     per_cu = std::max(1, std::min(per_cu, 16 / FEED_G));
+    const size_t n_items = items.size();
     if (const char *e = getenv("GARLIC_FEED_PER_CU")) per_cu = std::max(1, atoi(e));
+    else if (n_items > (size_t)ctx->n_cu && n_items <= (size_t)64 * ctx->n_cu * per_cu) {
+        // (fewer items than CUs: one each; very many: whatever order they finish in, the chip stays full)
+        std::vector<int32_t> len(n_items);
+        for (size_t i = 0; i < n_items; i++) len[i] = items[i].b - items[i].a + 1 + 64;      // (+ an item's fixed costs)
+        int best = per_cu;
+        double best_t = feed_makespan(len, ctx->n_cu, per_cu);
+        for (int k = per_cu - 1; k >= 1; k--) {
+            const double t = feed_makespan(len, ctx->n_cu, k);
+            if (t < 0.98 * best_t) { best_t = t; best = k; }
+        }
+        per_cu = best;
+    }
+    if (per_cu_out) *per_cu_out = per_cu;
     *grid = (int)std::min<size_t>(n_items, (size_t)ctx->n_cu * per_cu);
     return GARLIC_OK;
 }
@@ -1496,8 +1556,8 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
                 f.trace = d_ftrace.p;
             }
             const void *fn = (const void *)lod_feed_kernel;
-            int grid = 1;
-            if ((rc = feed_grid(ctx, n_feed_items, &grid))) return rc;
+            int grid = (int)std::min<size_t>(n_feed_items, (size_t)ctx->n_cu * std::max(1, p->plan.feed_per_cu));
+            if (!reuse && (rc = feed_grid(ctx, feed_items, &grid, &p->plan.feed_per_cu))) return rc;
             void *kargs[] = {(void *)&f};
             HIP_TRY(hipLaunchKernel(fn, dim3((unsigned)grid), dim3(FEED_G * WAVE), kargs, 0, ctx->stream));
             if (f.trace) {
@@ -2929,6 +2989,7 @@ int garlic_lod_feed_multi(garlic_panel *p, const int32_t *winsizes, const int32_
     // ---- plans and their uploads, all sizes, before any kernel is enqueued (an upload from pageable memory waits
     //      for the device to take it: behind a running chain kernel it would hold back the sizes that follow)
     std::vector<size_t> n_items((size_t)n_sizes, 0);
+    std::vector<int> grids((size_t)n_sizes, 1);      // workgroups each size's kernel is launched with (feed_grid)
     std::vector<int64_t> total((size_t)n_sizes, 0);
     for (int i = 0; i < n_sizes; i++) {
         garlic_panel::FeedSlot &sl = *p->feed_slots[(size_t)i];
@@ -2964,6 +3025,7 @@ int garlic_lod_feed_multi(garlic_panel *p, const int32_t *winsizes, const int32_
         counts[i] = off;
         n_items[(size_t)i] = items.size();
         if (off > feed_capacity[i] || off == 0) { n_items[(size_t)i] = 0; continue; }
+        if (!items.empty() && (rc = feed_grid(ctx, items, &grids[(size_t)i], nullptr))) return done(rc);
         if (!feeds[i]) return done(fail(GARLIC_ERR_INVALID, "feed %d is NULL", i));
         if ((rc = sl.items.reserve(std::max<size_t>(items.size(), 1)))) return done(rc);
         if ((rc = sl.chrs.reserve((size_t)p->nchr))) return done(rc);
@@ -2982,10 +3044,8 @@ int garlic_lod_feed_multi(garlic_panel *p, const int32_t *winsizes, const int32_
             FeedArgs f{p->d_packed.p, p->d_tab.p, sl.items.p, sl.chrs.p, sl.feed.p, ind_idx ? d_rowmap.p : nullptr, p->nwordrows, 0,
                        p->nind, winsizes[i], (int32_t)n_items[(size_t)i], steps[i], getenv("GARLIC_FEED_NO_ASM") ? 0 : 1,
                        sl.counter.p, nullptr};
-            int grid = 1;
-            if ((rc = feed_grid(ctx, n_items[(size_t)i], &grid))) return done(rc);
             void *kargs[] = {(void *)&f};
-            FEED_TRY(hipLaunchKernel((const void *)lod_feed_kernel, dim3((unsigned)grid), dim3(FEED_G * WAVE), kargs, 0, sl.stream));
+            FEED_TRY(hipLaunchKernel((const void *)lod_feed_kernel, dim3((unsigned)grids[(size_t)i]), dim3(FEED_G * WAVE), kargs, 0, sl.stream));
         }
         FEED_TRY(hipEventRecord(sl.ev1, sl.stream));
         FEED_TRY(hipGetLastError());
@@ -3333,11 +3393,11 @@ static int coverage_impl(garlic_panel *p, int32_t winsize, double error, int32_t
                 (void)hipMemsetAsync(d_ftrace.p, 0, sizeof(int64_t) * 8 * items.size(), s);
                 f.trace = d_ftrace.p;
             }
-            int per_cu = 0;
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)lod_bits_kernel, FEED_G * WAVE, 0);
-            if (e != hipSuccess) return done3(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
-            per_cu = std::max(1, std::min(per_cu, 16 / FEED_G));
-            // (persistent workgroups, all resident: a count item that waits must not keep a chain item from starting)
+            // workgroups per CU as the chains want them (feed_grid: the same chains, the same paces); the count items behind
+            // them in the queue are short and fill whatever is idle.  (Persistent workgroups, all resident: a count item
+            // that waits must not keep a chain item from starting.)
+            int per_cu = 1, chain_grid = 1;
+            if ((rc = feed_grid(ctx, items, &chain_grid, &per_cu))) return done3(rc);
             const int grid = (int)std::min<size_t>(items.size() + (size_t)n_cnt_items, (size_t)ctx->n_cu * per_cu);
             void *kargs[] = {(void *)&f};
             e = hipLaunchKernel((const void *)lod_bits_kernel, dim3((unsigned)grid), dim3(FEED_G * WAVE), kargs, 0, s);

@@ -11,7 +11,7 @@ build() {   # name, env assignments...
   cp garlic_amd/csrc/*.hip garlic_amd/csrc/*.hpp garlic_amd/csrc/*.inc $d/
   sed -i "s#\"../../include/garlic_hip.h\"#\"$PWD/include/garlic_hip.h\"#" $d/garlic_hip.hip
   env "$@" GARLIC_GEN_OUT=$d python3 tools/gen_feed_asm.py > /dev/null
-  /opt/rocm/bin/hipcc $FLAGS -I include -I garlic_amd/csrc -o build/abl/feed_$name.so $d/garlic_hip.hip 2>&1 | grep -E "error" || true
+  /opt/rocm/bin/hipcc $FLAGS -I include -I garlic_amd/csrc -Rpass-analysis=kernel-resource-usage -o build/abl/feed_$name.so $d/garlic_hip.hip 2>&1 | grep -A9 "Name: _ZN6garlic15lod_feed_kernelE" | grep -E "error|VGPRs|Scratch|Occupancy" | tr "\n" " " || true
   rm -rf $d
   echo built $name
 }

@@ -1,13 +1,13 @@
 """The final pass to the host, 10M SNPs x 1250 individuals, W = 100: ROH segments from the device (garlic_roh_segments)
 against the coverage counts to the host (garlic_roh_coverage_fused, where = host: 25 GB over PCIe, and the per-individual
 walk still to do there) and against the counts left on the device."""
-import ctypes, sys, time
+import ctypes, os, sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from garlic_amd import abi, synth
 import bench
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
-nloci, nind, W = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000, 1250, 100
+nloci, nind, W = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000, int(os.environ.get("NIND", 1250)), 100
 spec = synth.PanelSpec(nloci, seed=20260101 + 3, max_gap=200000)
 ctx = abi.Context(0)
 panel, _ = bench.load_panel(ctx, spec, nind, dev, gq=len(sys.argv) > 2)

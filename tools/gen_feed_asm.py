@@ -50,7 +50,7 @@ WAITEVERY = int(os.environ.get("GARLIC_FEED_WAITEVERY", "4"))  # windows per cou
 
 # ---- LDS map (bytes, workgroup-relative; feed_kernel.hpp takes GARLIC_FEED_LDS_TOTAL from the generated file)
 LDS_MISC = 0            # item word etc. (compiler-generated code only)
-COMB_BASE = 1024
+COMB_BASE = int(os.environ.get("GARLIC_FEED_COMB_BASE", "1024"))   # 0: the item word shares slot 0's first bytes (only written between items)
 COMB_SLOT = 8192        # 32 windows x 16 pairs x 16 B
 NSLOT = 4
 RAW_BASE = COMB_BASE + NSLOT * COMB_SLOT
@@ -65,26 +65,28 @@ V_WL = 20               # lead word ring, 8 registers: word row i of the stream 
 V_WT = 28               # trail word ring
 V_H = 36                # 4-bit codes 4 g_out + g_in: LO_A {even, odd} | LO_B {even, odd} | HI {even, odd}
 V_FUN = 42              # funnel-shifted genotype words (2 registers: entering, leaving)
-V_BUF = 44              # look-up buffers of NBUF = 8 windows in flight or in use: {t_out, t_in} (4 registers each); a window's offset is extracted into its first register
-NBUF = 8
-V_ACC = 76              # 8 accumulators of the current batch (16 registers)
-V_TB = 92               # builder: 2 passes x {t_out, t_in} between the raw rows and the pair table (8 registers)
-V_TL = 100              # this wave's eighth of a tile's raw rows on its way, 8 B per lane: two requests in flight (2 x 2 registers)
-V_L8 = 104              # lane * 8
-V_RAWW = 105            # ... its place in a raw slot: RAW_BASE + (wave / 2) * 1024 + (wave % 2) * 512 + lane * 8
-V_WSL, V_WST = 108, 112   # 4 word rows of the entering / leaving stream on their way (4 registers each)
-V_L16 = 116             # lane * 16
-V_L4 = 117              # lane * 4
-V_CT = 118              # this lane's leaving-SNP term in a tile's raw rows:  32 * (8 wave + lane / 16) + 8 * ((lane % 16) / 4)
-V_CL = 119              # this lane's entering-SNP term:                      32 * (8 wave + lane / 16) + 8 * (lane % 4)
-V_CW = 120              # its pair in the table:                              256 * (8 wave + lane / 16) + 16 * (lane % 16)
-V_STOFF = 121           # the lane's row * row pitch (bytes) of the sample / bit matrix
-V_S = 122               # the sampled accumulator (2 registers)
-V_SR = 124              # feed: KEEP = 8 kept samples (16 registers); bits: the dwords of the iteration's 8 tiles
+V_BUF = 44              # look-up buffers of NBUF windows in flight or in use: {t_out, t_in} (4 registers each); a window's offset is extracted into its first register
+NBUF = int(os.environ.get("GARLIC_FEED_NBUF", "8"))     # (a power of two: a tile's window 32 takes the buffer of the next tile's window 0)
+assert NBUF in (4, 8)
+_SH = 4 * (8 - NBUF)    # registers the map below moves down by
+V_ACC = 76 - _SH        # 8 accumulators of the current batch (16 registers)
+V_TB = 92 - _SH         # builder: 2 passes x {t_out, t_in} between the raw rows and the pair table (8 registers)
+V_TL = 100 - _SH        # this wave's eighth of a tile's raw rows on its way, 8 B per lane: two requests in flight (2 x 2 registers)
+V_L8 = 104 - _SH        # lane * 8
+V_RAWW = 105 - _SH      # ... its place in a raw slot: RAW_BASE + (wave / 2) * 1024 + (wave % 2) * 512 + lane * 8
+V_WSL, V_WST = 108 - _SH, 112 - _SH   # 4 word rows of the entering / leaving stream on their way (4 registers each)
+V_L16 = 116 - _SH       # lane * 16
+V_L4 = 117 - _SH        # lane * 4
+V_CT = 118 - _SH        # this lane's leaving-SNP term in a tile's raw rows:  32 * (8 wave + lane / 16) + 8 * ((lane % 16) / 4)
+V_CL = 119 - _SH        # this lane's entering-SNP term:                      32 * (8 wave + lane / 16) + 8 * (lane % 4)
+V_CW = 120 - _SH        # its pair in the table:                              256 * (8 wave + lane / 16) + 16 * (lane % 16)
+V_STOFF = 121 - _SH     # the lane's row * row pitch (bytes) of the sample / bit matrix
+V_S = 122 - _SH         # the sampled accumulator (2 registers)
+V_SR = 124 - _SH        # feed: KEEP = 8 kept samples (16 registers); bits: the dwords of the iteration's 8 tiles
 KEEP = 8
-V_WSA = 140             # this wave's word staging area, the lane's column: WST_BASE + wave * 1024 + lane * 4
-V_WSW = 141             # ... the lane's 16 bytes of it:                      WST_BASE + wave * 1024 + lane * 16
-CLOBBER_V = list(range(20, 142))
+V_WSA = 140 - _SH       # this wave's word staging area, the lane's column: WST_BASE + wave * 1024 + lane * 4
+V_WSW = 141 - _SH       # ... the lane's 16 bytes of it:                      WST_BASE + wave * 1024 + lane * 16
+CLOBBER_V = list(range(20, 142 - _SH))
 # ---- fixed SGPRs
 S_PLW, S_PTW = 40, 42   # genotype word streams: address of the block's word row 0 of the loop's first tile, + the loop's bias
 S_PTR = 44              # this wave's eighth of the term rows (waves 0, 1: entering SNPs, 2, 3: leaving; 16 rows each), RAW_AHEAD tiles ahead of the iteration's first tile
@@ -600,6 +602,7 @@ def main():
         f.write("// One inline-asm block: interior tiles of lod_feed_kernel, every wave a chain of its own (gfx950).\n")
         f.write(f"#define GARLIC_FEED_LDS_TOTAL {LDS_TOTAL}\n")
         f.write(f"#define GARLIC_FEED_UNROLL {UNROLL}\n")
+        f.write(f"#define GARLIC_FEED_WG_PER_CU {4 if (LDS_TOTAL <= 40960 and 142 - _SH <= 128) else 3}   // what the loop's registers and LDS allow\n")
         f.write(f"#define GARLIC_FEED_REACH {(RAW_AHEAD + UNROLL + 4) * 32}   // SNPs past a run's last window the loop may request\n")
         f.write("#define GARLIC_FEED_LOOP_ASM \\\n")
         for ln in lines:
