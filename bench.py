@@ -315,16 +315,16 @@ def leg_ns(ctx, dev, steps):
                          torch.cuda.synchronize)
     res["lod"] = dict(rate(k, dt), roofline=hbm_roofline("lod_chain_kernel", BYTES_LOD * win, k))
     # the first half of assembleROHWindows on the resident scores (garlic_roh_coverage): 8 B of scores in, 2 B of counts out
-    _, _, tcov = panel.out_layout(1, nind)
+    _, _, tcov = panel.out_layout(8, nind)              # rows of whole 16-B pieces: the kernel stores eight counts at a time
     cov = torch.empty(tcov, dtype=torch.int16, device=dev)
     torch.cuda.synchronize()
-    panel.roh_coverage_device(out.data_ptr(), W, 2.5, cov.data_ptr())
+    panel.roh_coverage_device(out.data_ptr(), W, 2.5, cov.data_ptr(), inwin_pitch_align=8)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
     ts = []
     for _ in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        panel.roh_coverage_device(out.data_ptr(), W, 2.5, cov.data_ptr())     # synchronous call: wall = kernel + two tiny uploads
+        panel.roh_coverage_device(out.data_ptr(), W, 2.5, cov.data_ptr(), inwin_pitch_align=8)     # synchronous call: wall = kernel + two tiny uploads
         ts.append(time.perf_counter() - t0)
     tcv = float(np.min(ts))
     res["roh_coverage"] = {"call_ms": tcv * 1e3, "sliding_windows_per_s": win / tcv,

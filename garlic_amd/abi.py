@@ -521,14 +521,15 @@ class Panel:
         check(lib().garlic_panel_tgls_mode(self.handle, C.byref(mode), C.byref(by)))
         return mode.value, by.value
 
-    def roh_coverage(self, scores_ptr, winsize, cutoff, pitch_align=32, nind_out=None):
+    def roh_coverage(self, scores_ptr, winsize, cutoff, pitch_align=32, nind_out=None, inwin_pitch_align=1):
         """assembleROHWindows' coverage counts of device-resident scores: list of per-chromosome int16
-        [nind_out][nloci_c] host arrays."""
+        [nind_out][pitch_c] host arrays (pitch_c = nloci_c rounded up to inwin_pitch_align; a multiple of 8 lets the kernel
+        store 16 bytes at a time)."""
         nind_out = self.nind if nind_out is None else nind_out
-        base, pitch, total = self.out_layout(1, nind_out)
+        base, pitch, total = self.out_layout(inwin_pitch_align, nind_out)
         out = np.empty(total, dtype=np.int16)
         check(lib().garlic_roh_coverage(self.handle, _vp(scores_ptr), pitch_align, nind_out, winsize, cutoff,
-                                        _vp(out.ctypes.data), 1, HOST))
+                                        _vp(out.ctypes.data), inwin_pitch_align, HOST))
         return [out[base[c]: base[c] + nind_out * pitch[c]].reshape(nind_out, pitch[c])
                 for c in range(self.nchr)]
 
@@ -564,11 +565,11 @@ class Panel:
         check(lib().garlic_roh_coverage_fused(self.handle, winsize, error, max_gap, int(use_gl), int(weighted), M, mu, cutoff,
                                               _vp(out_ptr), pitch_align, DEVICE))
 
-    def roh_coverage_device(self, scores_ptr, winsize, cutoff, out_ptr, pitch_align=32, nind_out=None):
-        """the same counts into device memory (int16, dense rows: out_layout(1, nind_out))"""
+    def roh_coverage_device(self, scores_ptr, winsize, cutoff, out_ptr, pitch_align=32, nind_out=None, inwin_pitch_align=1):
+        """the same counts into device memory (int16 rows: out_layout(inwin_pitch_align, nind_out))"""
         nind_out = self.nind if nind_out is None else nind_out
         check(lib().garlic_roh_coverage(self.handle, _vp(scores_ptr), pitch_align, nind_out, winsize, cutoff,
-                                        _vp(out_ptr), 1, DEVICE))
+                                        _vp(out_ptr), inwin_pitch_align, DEVICE))
 
     def stats(self):
         st = CallStats()

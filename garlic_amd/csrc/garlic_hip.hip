@@ -3532,9 +3532,11 @@ int garlic_roh_coverage(garlic_panel *p, const double *scores, int32_t pitch_ali
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(roh_coverage_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return done(fail(GARLIC_ERR_HIP, "coverage: %s", hipGetErrorString(e)));
+    bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;        // eight counts per store: every row 16-B aligned
+    for (int c = 0; c < p->nchr && vec_ok; c++) vec_ok = Lo.base[c] % 8 == 0 && Lo.pitch[c] % 8 == 0;
     hipLaunchKernelGGL(roh_coverage_kernel, dim3((unsigned)seg_base[p->nchr], (unsigned)nind_out),
                        dim3(COV_THREADS), lds, s, scores, d_chrs.p, d_chrs.p + p->nchr, d_seg.p, p->nchr, nind_out,
-                       winsize, cutoff, dst);
+                       winsize, cutoff, dst, vec_ok ? 1 : 0);
     e = hipGetLastError();
     if (e == hipSuccess && where == GARLIC_HOST)
         e = hipMemcpyAsync(inwin, dst, sizeof(int16_t) * (size_t)Lo.total, hipMemcpyDeviceToHost, s);

@@ -1209,7 +1209,7 @@ constexpr int COV_SEG = 8192, COV_THREADS = 256;   // (2048-window segments: 1.2
 __global__ void __launch_bounds__(COV_THREADS)
 roh_coverage_kernel(const double *__restrict__ scores, const ChrDev *__restrict__ chrs,
                     const ChrDev *__restrict__ ochrs, const int32_t *__restrict__ seg_base, int nchr,
-                    int nind, int W, double cutoff, int16_t *__restrict__ inwin)
+                    int nind, int W, double cutoff, int16_t *__restrict__ inwin, int vec_ok)
 {
     // (16-bit counts: 16.5 KB per workgroup, eight workgroups per CU instead of four -- measured: no faster, 5.3 ms at
     // 2M x 1280 either way; 4.8 TB/s of mixed reads and writes is what the kernel moves)
@@ -1257,10 +1257,29 @@ roh_coverage_kernel(const double *__restrict__ scores, const ChrDev *__restrict_
         for (int k = lo + lane; k < hi; k += WAVE) pre[k + 1] = (uint16_t)(pre[k + 1] + offset);
     __syncthreads();
     int16_t *orow = inwin + oc.out_base + (int64_t)ind * oc.out_pitch;
-    for (int k = halo + (int)threadIdx.x; k < n; k += COV_THREADS) {
-        // SNP l = first + k is covered by windows l-W+1 .. l = positions k-halo .. k
-        orow[first + k] = (int16_t)((int)pre[k + 1] - (int)pre[k - halo]);
+    // SNP l = first + k is covered by windows l-W+1 .. l = positions k-halo .. k
+    int done = 0;                                       // SNPs of the segment written eight at a time
+    if (vec_ok) {
+        // rows 16-B aligned (the caller's inwin_pitch_align a multiple of 8; the segment starts at a multiple of 8192):
+        // eight counts per lane and store -- 1 KB per wave instruction instead of 128 B (a vector-memory instruction
+        // costs the CU ~50 cycles whatever it moves: the 2-B stores were as many instructions as the loads)
+        const int nseg = n - halo;
+        done = nseg & ~7;
+        uint4 *o4 = reinterpret_cast<uint4 *>(orow + seg0);
+        for (int j = 8 * (int)threadIdx.x; j < done; j += 8 * COV_THREADS) {
+            const int k = halo + j;
+            uint32_t w[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t a = (uint32_t)((int)pre[k + 2 * u + 1] - (int)pre[k + 2 * u - halo]) & 0xffffu;
+                const uint32_t b = (uint32_t)((int)pre[k + 2 * u + 2] - (int)pre[k + 2 * u + 1 - halo]) & 0xffffu;
+                w[u] = a | (b << 16);
+            }
+            o4[j >> 3] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
     }
+    for (int k = halo + done + (int)threadIdx.x; k < n; k += COV_THREADS)
+        orow[first + k] = (int16_t)((int)pre[k + 1] - (int)pre[k - halo]);
 }
 
 } // namespace garlic

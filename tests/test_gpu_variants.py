@@ -223,9 +223,11 @@ def test_roh_coverage_counts_on_device(gpu_ctx, W):
         rows = [host[base[c]: base[c] + nind * pitch[c]].reshape(nind, pitch[c])[:, :n] for c, n in enumerate(sizes)]
         for cutoff in (0.0, -2.5, 3.0, -10000.0):
             got = panel.roh_coverage(dev.data_ptr(), W, cutoff, pitch_align=32)
+            got8 = panel.roh_coverage(dev.data_ptr(), W, cutoff, pitch_align=32, inwin_pitch_align=8)   # eight counts per store
             for c in range(len(sizes)):
                 want = ol.oracle_roh_coverage(rows[c], W, cutoff)
                 assert np.array_equal(got[c], want), (W, cutoff, c)
+                assert np.array_equal(got8[c][:, :sizes[c]], want), (W, cutoff, c, "16-B aligned rows")
 
 
 @pytest.mark.parametrize("W", [2, 30, 100, 250])
