@@ -483,7 +483,7 @@ def leg_ns(ctx, dev, steps):
     # ... and with per-genotype likelihoods (round 2's tile kernel: the scaled term matrix is its second stream)
     dt, k = timed_passes(ctx, lambda: panel.wlod_windows_device(out.data_ptr(), W10, ERROR, MAX_GAP, M_GEN, MU, use_gl=True), steps, 1,
                          torch.cuda.synchronize)
-    res["wlod_gl_winsize10"] = dict(rate(k, dt), roofline=hbm_roofline("wlod_tile_small_kernel", BYTES_TGLS * win, k,
+    res["wlod_gl_winsize10"] = dict(rate(k, dt), roofline=hbm_roofline("wlod_stream_small_gl_kernel", BYTES_TGLS * win, k,
                                                                       note="8 B of scaled terms in, 8 B of score out per window"))
     panel.close()
     out.free()

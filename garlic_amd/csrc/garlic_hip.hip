@@ -1232,7 +1232,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
     if (mode == MODE_WLOD && !wlod_fast && (rc = ensure_rld(p))) return rc;
     // narrow windows, plain scores: the streaming kernel (wlod_small_kernel.hpp) reads the plain reciprocals, a window's
     // W weights contiguous
-    const bool wlod_stream = wlod_fast && wlod_small && !wlod_gl && !p->cov_pending.bits && !getenv("GARLIC_WLOD_SMALL_TILES");
+    const bool wlod_stream = wlod_fast && wlod_small && !p->cov_pending.bits && !getenv("GARLIC_WLOD_SMALL_TILES");
     if (p->cov_pending.bits && mode == MODE_WLOD && !wlod_fast) return GARLIC_INTERNAL_NO_BITS;
     if (wlod_stream && (rc = ensure_rld(p))) return rc;
     // continuous likelihoods have no code table: the generic kernel takes its terms from the raw matrix
@@ -1460,7 +1460,7 @@ int launch_lod(garlic_panel *p, Mode mode, int32_t W, double error, int32_t max_
             as.nquad = nquad8;
             as.n_work = (uint32_t)((int64_t)p->plan.n_segs * nquad8);
             as.use_patch = 1;
-            const void *fn = wlod_stream_small_fn(W);
+            const void *fn = wlod_gl ? wlod_stream_small_gl_fn(W) : wlod_stream_small_fn(W);
             const size_t lds = wlod_small_lds_bytes(W);
             if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const double *a_rld = p->d_rld.p;

@@ -91,7 +91,12 @@ __device__ __forceinline__ WsmGeno wsm_align(uint32_t w0, uint32_t w1, uint32_t 
     return g;
 }
 
-template <int WC>
+// GL: per-genotype likelihoods -- the lane's score of a SNP is its own entry of the scaled term matrix (wtab =
+// [block][row][64], p.score_rows rows per block) instead of a look-up by genotype.  wlod_tile_small_gl_kernel read the
+// W + 15 rows of every 16-window group afresh, 1.56 x the matrix at W = 10, and they came from memory every time (2M x
+// 1280: FETCH x 2 = 32 GB for 20.5 GB of terms; the kernel moved 6.3 TB/s and still took 8.3 ms).  Here a wave walks 256
+// consecutive windows and carries the W - 1 rows two neighbouring groups share in registers: 1.04 x.
+template <int WC, bool GL>
 __device__ __forceinline__ void
 wlod_small_body(const uint32_t *__restrict__ packed, const double *__restrict__ wtab, const double *__restrict__ rld,
                 double *__restrict__ out, const WlodArgs &p, double *dyn)
@@ -114,10 +119,12 @@ wlod_small_body(const uint32_t *__restrict__ packed, const double *__restrict__ 
     const int64_t G0 = c.loc_base + GOFF + s0;
     const int64_t lb = c.loc_base + s0;
     {   // score rows of the SNPs s0 .. and the windows' weights, coalesced, once
-        const int nrows = min(WSM_ROWS, c.nloci - s0);
-        const double2 *src = reinterpret_cast<const double2 *>(wtab + G0 * 4);
-        double2 *dst = reinterpret_cast<double2 *>(rows);
-        for (int k = threadIdx.x; k < nrows * 2; k += WLOD_WAVES * WAVE) dst[k] = src[k];
+        if (!GL) {
+            const int nrows = min(WSM_ROWS, c.nloci - s0);
+            const double2 *src = reinterpret_cast<const double2 *>(wtab + G0 * 4);
+            double2 *dst = reinterpret_cast<double2 *>(rows);
+            for (int k = threadIdx.x; k < nrows * 2; k += WLOD_WAVES * WAVE) dst[k] = src[k];
+        }
         const double *wsrc = rld + lb * WC;
         for (int k = threadIdx.x; k < nwin * WC; k += WLOD_WAVES * WAVE) wts[k] = wsrc[k];
     }
@@ -136,16 +143,27 @@ wlod_small_body(const uint32_t *__restrict__ packed, const double *__restrict__ 
     const uint32_t shift = 2 * (uint32_t)(G0 & 15);
     const bool wholeA = ind0A + WAVE <= p.ind_count, wholeB = ind0B + WAVE <= p.ind_count;
     // group g reads the words g, g+1, g+2 of the lane's stream: two carried over, one requested a group ahead
-    uint32_t a0 = gA[0], a1 = gA[WAVE], a2 = gA[2 * WAVE];
-    uint32_t b0 = gB[0], b1 = gB[WAVE], b2 = gB[2 * WAVE];
+    uint32_t a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+    if (!GL) {
+        a0 = gA[0]; a1 = gA[WAVE]; a2 = gA[2 * WAVE];
+        b0 = gB[0]; b1 = gB[WAVE]; b2 = gB[2 * WAVE];
+    }
+    // GL: the lanes' own rows of the term matrix, row i of the segment at tA[i * 64] (rows past a chromosome's end exist:
+    // GPAD_BACK; what they hold only reaches windows without a score)
+    const double *tA = wtab + ((colA >> 6) * p.score_rows + G0) * WAVE + (colA & 63);
+    const double *tB = wtab + ((colB >> 6) * p.score_rows + G0) * WAVE + (colB & 63);
+    double sa[WC + 15], sb[WC + 15];    // the lanes' scores of a group's 16 + WC - 1 SNPs
+    bool carried = false;               // GL: sa / sb [16 ..] are the next group's first WC - 1
     const int ngroups = (nwin + 15) >> 4;
 #pragma unroll 1
     for (int g = 0; g < ngroups; g++) {
         const int sg = s0 + 16 * g;
         const uint64_t vmq = g < 4 ? vm0 : g < 8 ? vm1 : g < 12 ? vm2 : vm3;
         const uint32_t gm = (uint32_t)((vmq >> (16 * (g & 3))) & 0xFFFFu);
-        const uint32_t a3 = gA[(g + 3) * WAVE], b3 = gB[(g + 3) * WAVE];      // (the genotype array is padded far beyond)
+        uint32_t a3 = 0, b3 = 0;
+        if (!GL) { a3 = gA[(g + 3) * WAVE]; b3 = gB[(g + 3) * WAVE]; }      // (the genotype array is padded far beyond)
         double acc[16], bcc[16];
+        if (GL && gm == 0) carried = false;
         if (gm != 0) {
             const WsmGeno ga = wsm_align(a0, a1, a2, shift), gb = wsm_align(b0, b1, b2, shift);
             const double *rw = rows + 16 * g * 4;
@@ -156,14 +174,33 @@ wlod_small_body(const uint32_t *__restrict__ packed, const double *__restrict__ 
             double wv[NWV];
 #pragma unroll
             for (int m = 0; m < NWV; m++) wv[m] = wts[16 * g * WC + min(lane + WAVE * m, 16 * WC - 1)];
-            // the lanes' scores of the group's 16 + WC - 1 SNPs, looked up as the windows need them
-            double sa[WC + 15], sb[WC + 15];
+            if (GL) {
+                const double *ra = tA + (int64_t)(16 * g) * WAVE, *rb = tB + (int64_t)(16 * g) * WAVE;
+                if (carried) {
 #pragma unroll
-            for (int i = 0; i < WC + 15; i++) {
-                const uint32_t qa = ((i < 16 ? ga.lo : ga.hi) >> (2 * (i & 15))) & 3u;
-                const uint32_t qb = ((i < 16 ? gb.lo : gb.hi) >> (2 * (i & 15))) & 3u;
-                sa[i] = rw[i * 4 + qa];
-                sb[i] = rw[i * 4 + qb];
+                    for (int i = 0; i < WC - 1; i++) { sa[i] = sa[16 + i]; sb[i] = sb[16 + i]; }
+#pragma unroll
+                    for (int i = WC - 1; i < WC + 15; i++) {
+                        sa[i] = __builtin_nontemporal_load(ra + i * WAVE);
+                        sb[i] = __builtin_nontemporal_load(rb + i * WAVE);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < WC + 15; i++) {
+                        sa[i] = __builtin_nontemporal_load(ra + i * WAVE);
+                        sb[i] = __builtin_nontemporal_load(rb + i * WAVE);
+                    }
+                }
+                carried = true;
+            } else {
+                // the lanes' scores of the group's 16 + WC - 1 SNPs, looked up as the windows need them
+#pragma unroll
+                for (int i = 0; i < WC + 15; i++) {
+                    const uint32_t qa = ((i < 16 ? ga.lo : ga.hi) >> (2 * (i & 15))) & 3u;
+                    const uint32_t qb = ((i < 16 ? gb.lo : gb.hi) >> (2 * (i & 15))) & 3u;
+                    sa[i] = rw[i * 4 + qa];
+                    sb[i] = rw[i * 4 + qb];
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -200,7 +237,38 @@ wlod_stream_small_kernel(const uint32_t *__restrict__ packed, const double *__re
                          const double *__restrict__ rld, double *__restrict__ out, WlodArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double dyn[];
-    wlod_small_body<WC>(packed, wtab, rld, out, p, dyn);
+    wlod_small_body<WC, false>(packed, wtab, rld, out, p, dyn);
+}
+
+// ... with per-genotype likelihoods: wtab is the scaled term matrix
+template <int WC>
+__global__ void __launch_bounds__(WLOD_WAVES * WAVE, WC <= 7 ? 4 : 3)
+wlod_stream_small_gl_kernel(const uint32_t *__restrict__ packed, const double *__restrict__ terms,
+                            const double *__restrict__ rld, double *__restrict__ out, WlodArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
+    wlod_small_body<WC, true>(packed, terms, rld, out, p, dyn);
+}
+
+inline const void *wlod_stream_small_gl_fn(int W)
+{
+    switch (W) {
+    case 2: return (const void *)wlod_stream_small_gl_kernel<2>;
+    case 3: return (const void *)wlod_stream_small_gl_kernel<3>;
+    case 4: return (const void *)wlod_stream_small_gl_kernel<4>;
+    case 5: return (const void *)wlod_stream_small_gl_kernel<5>;
+    case 6: return (const void *)wlod_stream_small_gl_kernel<6>;
+    case 7: return (const void *)wlod_stream_small_gl_kernel<7>;
+    case 8: return (const void *)wlod_stream_small_gl_kernel<8>;
+    case 9: return (const void *)wlod_stream_small_gl_kernel<9>;
+    case 10: return (const void *)wlod_stream_small_gl_kernel<10>;
+    case 11: return (const void *)wlod_stream_small_gl_kernel<11>;
+    case 12: return (const void *)wlod_stream_small_gl_kernel<12>;
+    case 13: return (const void *)wlod_stream_small_gl_kernel<13>;
+    case 14: return (const void *)wlod_stream_small_gl_kernel<14>;
+    case 15: return (const void *)wlod_stream_small_gl_kernel<15>;
+    default: return nullptr;
+    }
 }
 
 inline const void *wlod_stream_small_fn(int W)
