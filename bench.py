@@ -108,7 +108,7 @@ class ClockSampler:
 def clock_under_load(call, sync, seconds=2.5):
     """loops `call` for a few seconds with the sampler running; None when rocm-smi is not there"""
     import shutil
-    if not shutil.which("rocm-smi"):
+    if not shutil.which("rocm-smi") or os.environ.get("GARLIC_BENCH_NO_CLOCK"):      # (no child processes under rocprofv3 --pmc)
         return None
     with ClockSampler() as cs:
         t0 = time.perf_counter()
