@@ -6,7 +6,7 @@
 #include <cstdint>
 #include <vector>
 
-template <int SEG>   // bytes per row per iteration: 256, 512, 1024
+template <int SEG>   // bytes per row per iteration: 128 (the wLOD write-out), 256 (the chain's), 512, 1024
 __global__ void __launch_bounds__(64) k(double *out, int64_t pitch /*doubles*/, int iters, int waves_per_blockrow)
 {
     const int lane = threadIdx.x;
@@ -47,6 +47,7 @@ int main()
     double *d;
     if (hipMalloc(&d, rows * pitch * 8) != hipSuccess) { printf("alloc failed\n"); return 1; }
     for (int nb : {256, 512, 1024, 2048, 4096}) {
+        run<128>(d, pitch, nb, (int)(pitch * 8 / 128));
         run<256>(d, pitch, nb, (int)(pitch * 8 / 256));
         run<512>(d, pitch, nb, (int)(pitch * 8 / 512));
         run<1024>(d, pitch, nb, (int)(pitch * 8 / 1024));
